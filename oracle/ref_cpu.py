@@ -1,0 +1,467 @@
+"""CPU oracle for the MergeRec merged-model inference path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is product code: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it, and there only
+as the checker / the timed CPU baseline -- never as the thing shipped.  The product path
+(``mergerec_amd``) calls hand-written HIP kernels through ``libmergerec_hip.so`` and fails loudly
+when that library is missing.
+
+This file is a plain fp32 ``torch`` (CPU) restatement of the reference's arithmetic for the path
+named by BASELINE.json's ``north_star``; every function cites the reference file:line it follows
+(paths relative to the upstream repo root).  It does not import ``transformers``, ``lightning``,
+``tyro`` or anything from the reference, so it travels to the GPU box.
+
+Pinning ("parity pinned"): ``oracle/gen_golden.py`` (run in the build container only) imports the
+runnable subset of the reference (``rec_retrieval.evaluator`` as-is; ``rec_retrieval.merger``
+algorithms; the reference's own ``RecformerEmbeddings``/mask helpers) plus the third-party library
+the reference delegates the encoder arithmetic to (``transformers`` RobertaModel / LongformerEncoder,
+reference pins ~=4.51.3, container has 5.15.0) and writes small input/output vectors to
+``tests/golden/``.  ``tests/test_oracle_golden.py`` checks every function here against them.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+StateDict = Dict[str, torch.Tensor]
+
+# --------------------------------------------------------------------------------------------
+# a1..a3: checkpoint key handling, flatten, task vectors
+# --------------------------------------------------------------------------------------------
+
+
+def remove_duplicate_prefix(state_dict: StateDict) -> StateDict:
+    """utils.py:17-29 -- strip the first ``"model."`` from every key that has it."""
+    out = {}
+    for k, v in state_dict.items():
+        out[k.replace("model.", "", 1) if k.startswith("model.") else k] = v
+    return out
+
+
+def align_state_dicts(
+    pretrain: StateDict, finetunes: Sequence[StateDict], ignore_keys: Sequence[str] = ()
+) -> Tuple[StateDict, List[StateDict]]:
+    """merger/weight_learning/module/_factory.py:55-66 -- keep ``pre ∩ ft[0]`` minus ignored, ordered
+    by the PRETRAINED dict's insertion order; fine-tuned dicts re-ordered to match."""
+    keep = (set(pretrain.keys()) & set(finetunes[0].keys())) - set(ignore_keys)
+    pre = OrderedDict((k, v) for k, v in pretrain.items() if k in keep)
+    fts = [OrderedDict((k, ft[k]) for k in pre.keys()) for ft in finetunes]
+    return pre, fts
+
+
+def flatten_model(model: StateDict) -> Tuple[torch.Tensor, "OrderedDict[str, torch.Size]"]:
+    """merger/utils/model_operations.py:47-63 -- ``torch.cat([v.reshape(-1)])`` in dict order.
+    ``torch.cat`` type-promotes, so an int64 buffer (Recformer ``position_ids``) becomes fp32."""
+    shape_dict = OrderedDict((k, v.shape) for k, v in model.items())
+    flat = torch.cat([v.reshape(-1) for v in model.values()])
+    return flat, shape_dict
+
+
+def get_task_vectors(base: torch.Tensor, models: Sequence[torch.Tensor]) -> torch.Tensor:
+    """merger/algorithms/task_vector.py:8-10 -- ``stack([m - base])`` -> (N, P)."""
+    return torch.stack([m - base for m in models])
+
+
+def get_state_dict(params: torch.Tensor, shape_dict) -> StateDict:
+    """merger/weight_learning/utils.py:29-40 -- slice the flat vector into named views."""
+    out, start = OrderedDict(), 0
+    for name, shape in shape_dict.items():
+        n = math.prod(shape)
+        out[name] = params[start : start + n].reshape(shape)
+        start += n
+    assert start == params.numel(), "Not all parameters are loaded."
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# a4/a5: the merge
+# --------------------------------------------------------------------------------------------
+
+
+def effective_alpha(gw: torch.Tensor, gb: torch.Tensor, per: torch.Tensor, disable_softmax: bool) -> torch.Tensor:
+    """task_wise.py:37-42 / layer_wise.py:67-73 -- ``alpha = gw * (softmax?)(per) + gb``."""
+    if not disable_softmax:
+        per = torch.softmax(per, dim=0)
+    return gw * per + gb
+
+
+def merge_task_wise(base: torch.Tensor, tv: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+    """task_wise.py:43-47 -- ``base + (alpha[:, None] * T).sum(0)`` (products rounded, then a
+    sequential i=0..N-1 sum from 0, then ``base + sum``; no fused multiply-add)."""
+    return base + (alpha.unsqueeze(1) * tv).sum(dim=0)
+
+
+def group_parameters_by_layer(shape_dict) -> "OrderedDict[str, List[Tuple[str, int, int]]]":
+    """layer_wise.py:13-33 -- group id = ``name.split('.')[3]`` when ``'encoder.layer.'`` is in the
+    name, else ``'others'``; groups keep first-seen order."""
+    groups: "OrderedDict[str, list]" = OrderedDict()
+    off = 0
+    for name, shape in shape_dict.items():
+        n = math.prod(shape)
+        key = name.split(".")[3] if "encoder.layer." in name else "others"
+        groups.setdefault(key, []).append((name, off, off + n))
+        off += n
+    return groups
+
+
+def merge_layer_wise(base: torch.Tensor, tv: torch.Tensor, groups, alpha_by_group: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """layer_wise.py:64-83 -- the task-wise expression applied per (name, start, end) chunk with
+    the chunk's group coefficients, written into a zero-initialised vector."""
+    merged = torch.zeros_like(base)
+    for key, chunks in groups.items():
+        a = alpha_by_group[key]
+        for _, s, e in chunks:
+            merged[s:e] = base[s:e] + (a.unsqueeze(1) * tv[:, s:e]).sum(dim=0)
+    return merged
+
+
+def merge_bwd_alpha(tv: torch.Tensor, grad: torch.Tensor) -> torch.Tensor:
+    """Backward of task_wise.py:43-47 w.r.t. alpha: ``dalpha_i = <tau_i, g>`` (fp64 accumulate so
+    the oracle is an accuracy anchor for the device's two-stage fp32 reduction)."""
+    return (tv.double() @ grad.double()).float()
+
+
+# --------------------------------------------------------------------------------------------
+# a8/a11/a13/a14: RoBERTa (BLaIR) encoder; the reference delegates to transformers RobertaModel
+# via module/models/encoder/_base.py:32-39.  Restated from the library's published architecture.
+# --------------------------------------------------------------------------------------------
+
+
+@dataclass
+class EncoderConfig:
+    hidden: int = 768
+    heads: int = 12
+    layers: int = 12
+    intermediate: int = 3072
+    vocab: int = 50265
+    max_pos: int = 514
+    pad_id: int = 1
+    ln_eps: float = 1e-5
+    # Recformer extras (module/models/encoder/recformer/interface.py:19-25)
+    token_type_size: int = 1
+    max_item_embeddings: int = 0
+    one_sided_window: int = 0  # 0 => full attention (RoBERTa); 32 => Longformer window 64
+
+
+def position_ids_from_input_ids(input_ids: torch.Tensor, pad_id: int) -> torch.Tensor:
+    """recformer/models.py:64-75 (== transformers create_position_ids_from_input_ids):
+    ``cumsum(ids != pad) * (ids != pad) + pad``."""
+    mask = input_ids.ne(pad_id).int()
+    return (torch.cumsum(mask, dim=1).type_as(mask) * mask).long() + pad_id
+
+
+def _ln(x, w, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def roberta_embeddings(p: StateDict, input_ids: torch.Tensor, cfg: EncoderConfig, prefix: str = "") -> torch.Tensor:
+    """transformers RobertaEmbeddings.forward: ``LN((word[ids] + type[0]) + pos[position_ids])``."""
+    pos = position_ids_from_input_ids(input_ids, cfg.pad_id)
+    e = p[prefix + "embeddings.word_embeddings.weight"][input_ids]
+    e = e + p[prefix + "embeddings.token_type_embeddings.weight"][torch.zeros_like(input_ids)]
+    e = e + p[prefix + "embeddings.position_embeddings.weight"][pos]
+    return _ln(e, p[prefix + "embeddings.LayerNorm.weight"], p[prefix + "embeddings.LayerNorm.bias"], cfg.ln_eps)
+
+
+def _ffn_block(p: StateDict, lp: str, attn_ctx: torch.Tensor, x: torch.Tensor, cfg: EncoderConfig) -> torch.Tensor:
+    """BertSelfOutput + BertIntermediate + BertOutput (shared by RoBERTa and Longformer layers):
+    ``h = LN(x + ctx W_o^T + b_o)``; ``y = LN(h + gelu_erf(h W_i^T + b_i) W_o2^T + b_o2)``."""
+    h = F.linear(attn_ctx, p[lp + "attention.output.dense.weight"], p[lp + "attention.output.dense.bias"])
+    h = _ln(h + x, p[lp + "attention.output.LayerNorm.weight"], p[lp + "attention.output.LayerNorm.bias"], cfg.ln_eps)
+    i = F.gelu(F.linear(h, p[lp + "intermediate.dense.weight"], p[lp + "intermediate.dense.bias"]))
+    o = F.linear(i, p[lp + "output.dense.weight"], p[lp + "output.dense.bias"])
+    return _ln(o + h, p[lp + "output.LayerNorm.weight"], p[lp + "output.LayerNorm.bias"], cfg.ln_eps)
+
+
+def roberta_layer(p: StateDict, lp: str, x: torch.Tensor, attention_mask: torch.Tensor, cfg: EncoderConfig) -> torch.Tensor:
+    """transformers RobertaLayer: softmax(QK^T/sqrt(dh) + (1-mask)*finfo.min) V, 12 heads."""
+    B, L, d = x.shape
+    H, dh = cfg.heads, d // cfg.heads
+    q = F.linear(x, p[lp + "attention.self.query.weight"], p[lp + "attention.self.query.bias"]).view(B, L, H, dh).transpose(1, 2)
+    k = F.linear(x, p[lp + "attention.self.key.weight"], p[lp + "attention.self.key.bias"]).view(B, L, H, dh).transpose(1, 2)
+    v = F.linear(x, p[lp + "attention.self.value.weight"], p[lp + "attention.self.value.bias"]).view(B, L, H, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * (dh**-0.5)
+    s = s + ((1.0 - attention_mask.to(s.dtype)) * torch.finfo(s.dtype).min)[:, None, None, :]
+    ctx = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, d)
+    return _ffn_block(p, lp, ctx, x, cfg)
+
+
+def roberta_encode(
+    p: StateDict, input_ids: torch.Tensor, attention_mask: torch.Tensor, cfg: EncoderConfig, prefix: str = "",
+    return_hidden: bool = False,
+):
+    """encoder/_base.py:32-49 -- ``self.model(**batch)`` then CLS pooling ``last_hidden_state[:, 0]``."""
+    x = roberta_embeddings(p, input_ids, cfg, prefix)
+    hidden = [x]
+    for l in range(cfg.layers):
+        x = roberta_layer(p, f"{prefix}encoder.layer.{l}.", x, attention_mask, cfg)
+        hidden.append(x)
+    cls = x[:, 0, :]
+    return (cls, hidden) if return_hidden else cls
+
+
+# --------------------------------------------------------------------------------------------
+# a9/a10/a12: Recformer (Longformer encoder + 4-table embeddings)
+# --------------------------------------------------------------------------------------------
+
+
+def recformer_embeddings(
+    p: StateDict, input_ids, token_type_ids, item_position_ids, cfg: EncoderConfig, prefix: str = ""
+) -> torch.Tensor:
+    """recformer/models.py:104-136 -- ``LN(word + pos + token_type + item_pos)`` in that order."""
+    pos = position_ids_from_input_ids(input_ids, cfg.pad_id)
+    e = p[prefix + "embeddings.word_embeddings.weight"][input_ids]
+    e = e + p[prefix + "embeddings.position_embeddings.weight"][pos]
+    e = e + p[prefix + "embeddings.token_type_embeddings.weight"][token_type_ids]
+    e = e + p[prefix + "embeddings.item_position_embeddings.weight"][item_position_ids]
+    return _ln(e, p[prefix + "embeddings.LayerNorm.weight"], p[prefix + "embeddings.LayerNorm.bias"], cfg.ln_eps)
+
+
+def longformer_layer(p: StateDict, lp: str, x: torch.Tensor, mask012: torch.Tensor, cfg: EncoderConfig) -> torch.Tensor:
+    """transformers LongformerSelfAttention (reached via recformer/models.py:189,340-348), restated
+    densely.  mask012: 0 = no attention, 1 = local, 2 = global (recformer/models.py:261-271).
+
+    local query i (mask 1): softmax over {global keys} U {j : |i-j| <= w, mask[j] == 1}, using the
+    ``query/key/value`` projections, query pre-scaled by 1/sqrt(dh); global keys are removed from the
+    band and enter once through the extra column; masked keys get finfo.min (probability 0).
+    global query g (mask 2): full attention over every non-masked key with the ``*_global``
+    projections; its row overwrites the local result.  Masked query rows are zero.
+    """
+    B, L, d = x.shape
+    H, dh, w = cfg.heads, d // cfg.heads, cfg.one_sided_window
+    sp = lp + "attention.self."
+    scale = 1.0 / math.sqrt(dh)
+
+    def proj(name, t):
+        return F.linear(t, p[sp + name + ".weight"], p[sp + name + ".bias"]).view(B, L, H, dh).transpose(1, 2)
+
+    q = proj("query", x) * scale
+    k = proj("key", x)
+    v = proj("value", x)
+    is_masked = mask012 == 0
+    is_global = mask012 == 2
+    idx = torch.arange(L)
+    band = (idx[:, None] - idx[None, :]).abs() <= w  # (L, L)
+    # allowed[b, i, j]: key j visible to local query i
+    key_local = (mask012 == 1)[:, None, :] & band[None, :, :]
+    allowed = key_local | is_global[:, None, :]
+    s = q @ k.transpose(-1, -2)  # (B,H,L,L)
+    s = s.masked_fill(~allowed[:, None, :, :], float("-inf"))
+    pr = torch.softmax(s.float(), dim=-1)
+    pr = torch.nan_to_num(pr, nan=0.0)
+    pr = pr.masked_fill(is_masked[:, None, :, None], 0.0)
+    ctx = pr @ v  # (B,H,L,dh)
+    # global rows
+    if is_global.any():
+        qg = proj("query_global", x) * scale
+        kg = proj("key_global", x)
+        vg = proj("value_global", x)
+        sg = qg @ kg.transpose(-1, -2)
+        sg = sg.masked_fill(is_masked[:, None, None, :], torch.finfo(sg.dtype).min)
+        cg = torch.softmax(sg.float(), dim=-1) @ vg
+        ctx = torch.where(is_global[:, None, :, None], cg, ctx)
+    ctx = ctx.transpose(1, 2).reshape(B, L, d)
+    return _ffn_block(p, lp, ctx, x, cfg)
+
+
+def recformer_encode(
+    p: StateDict, input_ids, attention_mask, global_attention_mask, token_type_ids, item_position_ids,
+    cfg: EncoderConfig, prefix: str = "", return_hidden: bool = False,
+):
+    """recformer/interface.py:67-84 -> recformer/models.py:273-361.  Window padding
+    (models.py:209-259) only appends masked positions, which never influence a non-masked row in
+    the dense restatement, so it is not materialised; CLS pooling per encoder/_base.py:44-45."""
+    mask012 = attention_mask * (global_attention_mask + 1)  # models.py:261-271
+    x = recformer_embeddings(p, input_ids, token_type_ids, item_position_ids, cfg, prefix)
+    hidden = [x]
+    for l in range(cfg.layers):
+        x = longformer_layer(p, f"{prefix}encoder.layer.{l}.", x, mask012, cfg)
+        hidden.append(x)
+    cls = x[:, 0, :]
+    return (cls, hidden) if return_hidden else cls
+
+
+# --------------------------------------------------------------------------------------------
+# a14/a16/a17: normalise, score, loss
+# --------------------------------------------------------------------------------------------
+
+
+def maybe_normalize(x: torch.Tensor, similarity: str = "cosine") -> torch.Tensor:
+    """module/recommender/module.py:74-77 -- ``F.normalize(x, p=2, dim=-1)`` for cosine."""
+    return F.normalize(x, p=2, dim=-1) if similarity == "cosine" else x
+
+
+def score(user: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
+    """module/recommender/module.py:137 -- ``scores = user @ item_embeddings.T``."""
+    return user @ items.T
+
+
+def ce_loss(scores: torch.Tensor, labels: torch.Tensor, temperature: float = 0.05) -> float:
+    """module/recommender/module.py:356 -- ``cross_entropy(scores / T, labels)``."""
+    return F.cross_entropy(scores / temperature, labels).item()
+
+
+# --------------------------------------------------------------------------------------------
+# a18/a19: top-k and metrics
+# --------------------------------------------------------------------------------------------
+
+
+def topk_canonical(scores: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """evaluator/evaluator.py:43 -- ``torch.topk(scores, k, dim=1)``.  torch leaves the order of
+    equal scores unspecified; the build fixes it as (score desc, index asc), NaN first (torch.topk
+    treats NaN as the largest value).  Stable descending sort gives exactly that order."""
+    key = torch.where(torch.isnan(scores), torch.full_like(scores, float("inf")), scores)
+    # push NaN strictly above +inf: sort NaN-flag first
+    order = torch.sort(key, dim=1, descending=True, stable=True).indices
+    nan_rows = torch.isnan(scores).any(dim=1)
+    if nan_rows.any():
+        for r in torch.nonzero(nan_rows).flatten().tolist():
+            row = scores[r]
+            isn = torch.isnan(row)
+            nan_idx = torch.nonzero(isn).flatten()
+            rest = torch.nonzero(~isn).flatten()
+            rest = rest[torch.sort(row[rest], descending=True, stable=True).indices]
+            order[r] = torch.cat([nan_idx, rest])
+    idx = order[:, :k]
+    return torch.gather(scores, 1, idx), idx
+
+
+def recall_at_k(labels: torch.Tensor, pred: torch.Tensor, k: int) -> float:
+    """evaluator/metrics.py:38-59."""
+    rows = pred[:, :k].tolist()
+    hits = [1.0 if t in r else 0.0 for r, t in zip(rows, labels.tolist())]
+    return sum(hits) / len(hits) if hits else 0.0
+
+
+def ndcg_at_k(labels: torch.Tensor, pred: torch.Tensor, k: int) -> float:
+    """evaluator/metrics.py:65-88 -- single positive, gain ``1 / float32(log2(rank + 2))``."""
+    rows = pred[:, :k].tolist()
+    out = []
+    for r, t in zip(rows, labels.tolist()):
+        out.append(1 / (torch.log2(torch.tensor(r.index(t) + 2)).item()) if t in r else 0.0)
+    return sum(out) / len(out) if out else 0.0
+
+
+def evaluate(scores: torch.Tensor, labels: torch.Tensor, metrics: Sequence[str], ks: Sequence[int], prefix: str = "") -> Dict[str, float]:
+    """evaluator/evaluator.py:31-49 -- metric-major, k-minor key order."""
+    _, pred = topk_canonical(scores, max(ks))
+    out: Dict[str, float] = OrderedDict()
+    for m in metrics:
+        for k in ks:
+            if m == "NDCG":
+                out[f"{prefix}NDCG@{k}"] = ndcg_at_k(labels, pred, k)
+            elif m == "RECALL":
+                out[f"{prefix}Recall@{k}"] = recall_at_k(labels, pred, k)
+            else:
+                raise KeyError(m)
+    return out
+
+
+def ranks_equal_up_to_ties(scores: torch.Tensor, idx_a: torch.Tensor, idx_b: torch.Tensor, atol: float) -> bool:
+    """Checker helper: two ranked index lists agree if, position by position, either the indices
+    are equal or the two indices' oracle scores differ by <= atol (a near-tie swapped by fp32
+    summation order); and the score sequence along idx_a is non-increasing within atol."""
+    sa = torch.gather(scores, 1, idx_a)
+    sb = torch.gather(scores, 1, idx_b)
+    ok = (idx_a == idx_b) | ((sa - sb).abs() <= atol)
+    return bool(ok.all())
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic weights at true architecture dims (no checkpoints are available offline)
+# --------------------------------------------------------------------------------------------
+
+
+def roberta_param_shapes(cfg: EncoderConfig, prefix: str = "model.", pooler: bool = True):
+    """Key order of ``BLaIRBase(...).state_dict()`` = ``'model.' + RobertaModel.state_dict()``
+    (models/_base.py:56): 5 embedding tensors, 16 per layer, 2 pooler."""
+    d, i = cfg.hidden, cfg.intermediate
+    sh = OrderedDict()
+    e = prefix + "embeddings."
+    sh[e + "word_embeddings.weight"] = (cfg.vocab, d)
+    sh[e + "position_embeddings.weight"] = (cfg.max_pos, d)
+    sh[e + "token_type_embeddings.weight"] = (cfg.token_type_size, d)
+    sh[e + "LayerNorm.weight"] = (d,)
+    sh[e + "LayerNorm.bias"] = (d,)
+    for l in range(cfg.layers):
+        lp = f"{prefix}encoder.layer.{l}."
+        for n in ("query", "key", "value"):
+            sh[lp + f"attention.self.{n}.weight"] = (d, d)
+            sh[lp + f"attention.self.{n}.bias"] = (d,)
+        sh[lp + "attention.output.dense.weight"] = (d, d)
+        sh[lp + "attention.output.dense.bias"] = (d,)
+        sh[lp + "attention.output.LayerNorm.weight"] = (d,)
+        sh[lp + "attention.output.LayerNorm.bias"] = (d,)
+        sh[lp + "intermediate.dense.weight"] = (i, d)
+        sh[lp + "intermediate.dense.bias"] = (i,)
+        sh[lp + "output.dense.weight"] = (d, i)
+        sh[lp + "output.dense.bias"] = (d,)
+        sh[lp + "output.LayerNorm.weight"] = (d,)
+        sh[lp + "output.LayerNorm.bias"] = (d,)
+    if pooler:
+        sh[prefix + "pooler.dense.weight"] = (d, d)
+        sh[prefix + "pooler.dense.bias"] = (d,)
+    return sh
+
+
+def recformer_param_shapes(cfg: EncoderConfig, prefix: str = "model."):
+    """Key order of ``RecformerModel.state_dict()`` (recformer/models.py:84-103,177-193): the
+    persistent int64 ``embeddings.position_ids`` buffer comes first (a module's own buffers are
+    saved before its children), then 4 tables + LN, then per layer q/k/v, q/k/v_global, out, FFN."""
+    d, i = cfg.hidden, cfg.intermediate
+    sh = OrderedDict()
+    e = prefix + "embeddings."
+    sh[e + "position_ids"] = (1, cfg.max_pos)
+    sh[e + "word_embeddings.weight"] = (cfg.vocab, d)
+    sh[e + "position_embeddings.weight"] = (cfg.max_pos, d)
+    sh[e + "token_type_embeddings.weight"] = (cfg.token_type_size, d)
+    sh[e + "item_position_embeddings.weight"] = (cfg.max_item_embeddings, d)
+    sh[e + "LayerNorm.weight"] = (d,)
+    sh[e + "LayerNorm.bias"] = (d,)
+    for l in range(cfg.layers):
+        lp = f"{prefix}encoder.layer.{l}."
+        for n in ("query", "key", "value", "query_global", "key_global", "value_global"):
+            sh[lp + f"attention.self.{n}.weight"] = (d, d)
+            sh[lp + f"attention.self.{n}.bias"] = (d,)
+        sh[lp + "attention.output.dense.weight"] = (d, d)
+        sh[lp + "attention.output.dense.bias"] = (d,)
+        sh[lp + "attention.output.LayerNorm.weight"] = (d,)
+        sh[lp + "attention.output.LayerNorm.bias"] = (d,)
+        sh[lp + "intermediate.dense.weight"] = (i, d)
+        sh[lp + "intermediate.dense.bias"] = (i,)
+        sh[lp + "output.dense.weight"] = (d, i)
+        sh[lp + "output.dense.bias"] = (d,)
+        sh[lp + "output.LayerNorm.weight"] = (d,)
+        sh[lp + "output.LayerNorm.bias"] = (d,)
+    return sh
+
+
+def random_state_dict(shapes, seed: int, std: float = 0.02) -> StateDict:
+    """HF-style init: N(0, std^2) weights, LayerNorm gamma=1 beta=0, zero biases get
+    small noise so bias paths are exercised; ``position_ids`` = arange (int64)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for k, shp in shapes.items():
+        if k.endswith("position_ids"):
+            sd[k] = torch.arange(shp[-1], dtype=torch.int64).expand(shp).clone()
+        elif "LayerNorm.weight" in k:
+            sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            sd[k] = std * torch.randn(shp, generator=g)
+        else:
+            sd[k] = std * torch.randn(shp, generator=g)
+    return sd
+
+
+def perturbed_state_dict(base: StateDict, seed: int, std: float = 1e-3) -> StateDict:
+    """A synthetic 'fine-tuned' checkpoint: theta_i = theta_pre + tau_i, tau ~ N(0, std^2)."""
+    g = torch.Generator().manual_seed(seed)
+    out = OrderedDict()
+    for k, v in base.items():
+        out[k] = v.clone() if not v.is_floating_point() else v + std * torch.randn(v.shape, generator=g)
+    return out

@@ -1,0 +1,135 @@
+"""Pins oracle/ref_cpu.py against outputs of the reference itself (tests/golden, made by
+oracle/gen_golden.py in the build container).  CPU only."""
+import math
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from tests.conftest import load_golden
+
+
+def _cfg(d):
+    return O.EncoderConfig(**d)
+
+
+# ------------------------------------------------------------------ G1: evaluator (a18, a19)
+def test_evaluator_matches_reference():
+    for case in load_golden("g1_evaluator.pt"):
+        got = O.evaluate(case["scores"], case["labels"], ["NDCG", "RECALL"], case["ks"], "test/")
+        assert list(got.keys()) == case["metric_key_order"]
+        for k, v in case["metrics"].items():
+            assert got[k] == v, (k, got[k], v)  # same float32 gain table, same Python float sum
+        # canonical top-k == torch.topk as a multiset of (score) and exactly where no ties exist
+        val, idx = O.topk_canonical(case["scores"], case["ref_topk_idx"].shape[1])
+        assert torch.equal(val, case["ref_topk_val"])
+        s = case["scores"]
+        for r in range(s.shape[0]):
+            v = val[r]
+            if len(torch.unique(v)) == len(v):
+                assert torch.equal(idx[r], case["ref_topk_idx"][r])
+            # canonical: ties broken by ascending index
+            same = v[1:] == v[:-1]
+            assert bool((idx[r][1:][same] > idx[r][:-1][same]).all())
+
+
+def test_topk_canonical_nan_first():
+    s = torch.tensor([[0.1, float("nan"), 0.5, 0.5, float("nan"), -1.0]])
+    val, idx = O.topk_canonical(s, 4)
+    assert idx.tolist() == [[1, 4, 2, 3]]
+
+
+# ------------------------------------------------------------------ G2: merger (a2..a7)
+def _alpha(case, key, n):
+    w = case["weights"]
+    gw = torch.tensor(w["global_weights"][key])
+    gb = torch.tensor(w["global_biases"][key])
+    per = torch.tensor(w["per_weights"][key])[:n]  # _base.py:72 truncation
+    return O.effective_alpha(gw, gb, per, disable_softmax=not case["use_softmax"])
+
+
+def test_merge_matches_reference_bitwise():
+    g2 = load_golden("g2_merger.pt")
+    pre, fts = O.align_state_dicts(g2["pretrain"], g2["finetunes"])
+    assert "item_embeddings" not in pre
+    base, shape_dict = O.flatten_model(pre)
+    models = [O.flatten_model(ft)[0] for ft in fts]
+    tv = O.get_task_vectors(base, models)
+    assert torch.equal(base, g2["base_flat"])
+    assert torch.equal(tv, g2["tv_flat"])
+    n = tv.shape[0]
+    for case in g2["cases"]:
+        assert list(shape_dict.keys()) == case["shape_keys"]
+        assert [tuple(s) for s in shape_dict.values()] == case["shapes"]
+        if case["learn_type"] == "TASK_WISE":
+            assert case["groups"] == ["all"]
+            merged = O.merge_task_wise(base, tv, _alpha(case, "all", n))
+            init = O.merge_task_wise(base, tv, O.effective_alpha(torch.tensor([1.0]), torch.tensor([0.0]), torch.full((n,), 0.3), not case["use_softmax"]))
+        else:
+            groups = O.group_parameters_by_layer(shape_dict)
+            assert list(groups.keys()) == case["groups"]
+            merged = O.merge_layer_wise(base, tv, groups, {k: _alpha(case, k, n) for k in groups})
+            a0 = O.effective_alpha(torch.tensor([1.0]), torch.tensor([0.0]), torch.full((n,), 0.3), not case["use_softmax"])
+            init = O.merge_layer_wise(base, tv, groups, {k: a0 for k in groups})
+        assert torch.equal(merged, case["merged_flat"]), case["learn_type"]
+        assert torch.equal(init, case["init_merged_flat"])
+        # a6: named views
+        sd = O.get_state_dict(merged, shape_dict)
+        assert list(sd.keys()) == case["shape_keys"]
+        # G5: the reference module's own forward (re-merge + functional HF model) -> CLS
+        cfg = _cfg(g2["cfg"])
+        cls = O.roberta_encode(sd, g2["input_ids"], g2["attention_mask"], cfg, prefix="model.")
+        assert torch.allclose(cls, case["cls"], atol=2e-5, rtol=1e-5), (cls - case["cls"]).abs().max()
+
+
+def test_flatten_promotes_int_buffer():
+    g2 = load_golden("g2_merger.pt")
+    sd = OrderedDict([("model.embeddings.position_ids", torch.arange(10).view(1, 10))] + list(g2["pretrain"].items()))
+    flat, _ = O.flatten_model(sd)
+    assert str(flat.dtype) == g2["flatten_with_int_buffer_dtype"] == "torch.float32"
+    assert torch.equal(flat[:12], g2["flatten_with_int_buffer_head"])
+
+
+# ------------------------------------------------------------------ G3: RoBERTa (a8, a11, a13)
+def test_roberta_matches_library():
+    g3 = load_golden("g3_roberta.pt")
+    cfg = _cfg(g3["cfg"])
+    cls, hidden = O.roberta_encode(g3["state_dict"], g3["input_ids"], g3["attention_mask"], cfg, "model.", return_hidden=True)
+    m = g3["attention_mask"].bool()
+    for h, ref in zip(hidden, g3["hidden_states"]):
+        assert torch.allclose(h[m], ref[m], atol=3e-5, rtol=1e-5), (h[m] - ref[m]).abs().max()
+    assert torch.allclose(cls, g3["cls"], atol=3e-5, rtol=1e-5)
+
+
+def test_roberta_true_dims_single_layer():
+    big = load_golden("g3_roberta.pt")["big"]
+    cfg = _cfg(big["cfg"])
+    sd = O.random_state_dict(O.roberta_param_shapes(cfg), seed=big["seed"], std=big["std"])
+    assert abs(float(sum(v.double().sum() for v in sd.values())) - big["checksum"]) < 1e-6, "seeded weight generator drifted"
+    _, hidden = O.roberta_encode(sd, big["input_ids"], big["attention_mask"], cfg, "model.", return_hidden=True)
+    m = big["attention_mask"].bool()
+    assert torch.allclose(hidden[0][m], big["emb"][m], atol=1e-5)
+    assert torch.allclose(hidden[-1][m], big["last"][m], atol=2e-5), (hidden[-1][m] - big["last"][m]).abs().max()
+
+
+# ------------------------------------------------------------------ G4: Recformer (a9, a10, a12)
+def test_recformer_matches_reference():
+    g4 = load_golden("g4_recformer.pt")
+    for case in g4["cases"]:
+        cfg = _cfg(case["cfg"])
+        b = case["batch"]
+        cls, hidden = O.recformer_encode(
+            case["state_dict"], b["input_ids"], b["attention_mask"], b["global_attention_mask"], b["token_type_ids"],
+            b["item_position_ids"], cfg, "model.", return_hidden=True,
+        )
+        m = b["attention_mask"].bool()
+        assert torch.allclose(hidden[0][m], case["emb"][m], atol=1e-5)
+        for li, (h, ref) in enumerate(zip(hidden, case["hidden_states"])):
+            assert torch.allclose(h[m], ref[m], atol=5e-5, rtol=1e-5), (li, (h[m] - ref[m]).abs().max())
+        assert torch.allclose(cls, case["cls"], atol=5e-5, rtol=1e-5)
+
+
+def test_position_ids():
+    ids = torch.tensor([[0, 5, 1, 7, 1, 1], [0, 2, 1, 1, 1, 1]])
+    assert O.position_ids_from_input_ids(ids, 1).tolist() == [[2, 3, 1, 4, 1, 1], [2, 3, 1, 1, 1, 1]]
