@@ -1,0 +1,182 @@
+/*
+ * mergerec_hip.h -- C ABI of libmergerec_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (DIALLab-SKKU/MergeRec) is pure Python and has no FFI of its own: every device op
+ * on its merged-model inference path is a stock torch / transformers call made from Python.  Each
+ * entry point below replaces the torch op sequence of one reference function; the citation after
+ * "replaces:" is the reference file:line (relative to the upstream repo root) whose arithmetic the
+ * kernel reproduces.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - return 0 on success, a negative MR_E* code otherwise; no C++ exception crosses the ABI.
+ *   - every pointer is a caller-owned DEVICE pointer (hipMalloc'd, e.g. a torch tensor's
+ *     data_ptr()), contiguous, 16-byte aligned unless stated; the library never allocates or frees
+ *     caller-visible memory.  Scratch is passed in (`ws`, size from the matching *_ws_bytes()).
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no hidden synchronisation.
+ *   - re-entrant, no global mutable state; one host thread per GPU.
+ *   - "packed tokens": the encoder works on the T = sum(len_b) non-masked tokens of a batch, rows
+ *     [cu_seqlens[b], cu_seqlens[b+1]) of a (T, d) fp32 matrix belong to sequence b.
+ *   - "arena": all parameters of one model live in one flat fp32 buffer; each tensor starts on a
+ *     64-float boundary (reference key order is kept; pads are zero).  Task vectors use the same
+ *     layout, so the merge is one elementwise pass and the encoder reads weights in place.
+ */
+#ifndef MERGEREC_HIP_H
+#define MERGEREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MR_OK 0
+#define MR_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
+#define MR_EALIGN (-2)   /* pointer or leading dimension not aligned as required */
+#define MR_ELAUNCH (-3)  /* hipLaunch / runtime error (message via mr_last_hip_error) */
+#define MR_EWS (-4)      /* workspace too small */
+#define MR_EUNSUPPORTED (-5)
+
+#define MR_ACT_NONE 0
+#define MR_ACT_GELU_ERF 1
+
+#define MR_EMBED_ROBERTA 0   /* LN((word + type) + pos)            -- transformers RobertaEmbeddings */
+#define MR_EMBED_RECFORMER 1 /* LN(((word + pos) + type) + itempos) -- recformer/models.py:130-133   */
+
+typedef void* mr_stream_t; /* hipStream_t */
+
+int mr_version(void);
+const char* mr_strerror(int code);
+/* text of the last HIP runtime error seen by the calling thread ("" if none) */
+const char* mr_last_hip_error(void);
+
+/* ---- merger ------------------------------------------------------------------------------- */
+
+/* tv[p] = theta[p] - base[p], p in [0, n).
+ * replaces: rec_retrieval/merger/algorithms/task_vector.py:8-10 (get_task_vectors, one row). */
+int mr_task_vector_f32(const float* theta, const float* base, int64_t n, float* tv, mr_stream_t stream);
+
+/* out[p] = base[p] + sum_{i<N} round(alpha[s(p)*N + i] * tv[i*tv_stride + p]),  p in [p_begin, p_begin+p_count)
+ * with the sum taken sequentially i = 0..N-1 from the first product and NO fused multiply-add, i.e.
+ * bit-for-bit torch's `base + (alpha[:, None] * T).sum(0)` on CPU.
+ * s(p) is the segment containing p: seg_off[s] <= p < seg_off[s+1] (int64, S+1 entries, every entry a
+ * multiple of 4, seg_off[0] <= p_begin, seg_off[S] >= p_begin+p_count); seg_off == NULL means S == 1.
+ * alpha is a DEVICE array of S*N floats (the effective coefficients gw*per+gb of each segment's group).
+ * p_begin and p_count are multiples of 4 (they let one rank merge only its slice of the arena).
+ * replaces: merger/weight_learning/module/task_wise.py:36-48 (S == 1) and
+ *           merger/weight_learning/module/layer_wise.py:64-83 (S > 1; group table :13-33). */
+int mr_merge_nway_f32(const float* base, const float* tv, int64_t tv_stride, const float* alpha,
+                      const int64_t* seg_off, int N, int S, int64_t p_begin, int64_t p_count, float* out,
+                      mr_stream_t stream);
+
+/* dalpha[s*N + i] = sum_{p in segment s} tv[i*tv_stride + p] * g[p]   (the backward of the merge w.r.t.
+ * the effective coefficients).  Deterministic two-stage reduction (fixed chunking, fixed order).
+ * replaces: autograd backward through task_wise.py:43-47 / layer_wise.py:75-81 (merge_train.py path). */
+size_t mr_merge_bwd_alpha_ws_bytes(int N, int S, int64_t P);
+int mr_merge_bwd_alpha_f32(const float* tv, int64_t tv_stride, const float* g, const int64_t* seg_off, int N, int S,
+                           int64_t P, float* dalpha, void* ws, size_t ws_bytes, mr_stream_t stream);
+
+/* ---- encoder: token packing + embeddings --------------------------------------------------- */
+
+/* From the reference's padded batch tensors (int64 (B, L), row-major) build packed per-token index
+ * arrays (int32, T entries each): word id, position id = cumsum(ids != pad) * (ids != pad) + pad
+ * (computed over the WHOLE row, masked positions included), token type, item position.
+ * Token t of row b is the t-th position of that row with attention_mask != 0; cu_seqlens (int32,
+ * B+1, device) must hold the exclusive prefix sums of the per-row mask counts.
+ * token_type_ids / item_position_ids / tok_tt / tok_ip may be NULL (RoBERTa).
+ * replaces: recformer/models.py:64-75 (create_position_ids_from_input_ids; same formula in
+ *           transformers RobertaEmbeddings) and the padding contract of
+ *           datamodule/collator/recommender/recommender.py:27-32, utils/recformer_utils.py:71-113. */
+int mr_pack_tokens(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
+                   const int64_t* item_position_ids, int B, int L, int pad_id, const int32_t* cu_seqlens,
+                   int32_t* tok_word, int32_t* tok_pos, int32_t* tok_tt, int32_t* tok_ip, mr_stream_t stream);
+
+/* out[t, :] = LayerNorm(sum of gathered rows) * gamma + beta, one wavefront per token.
+ * mode MR_EMBED_ROBERTA:   (word[tok_word] + type[tok_tt or 0]) + pos[tok_pos]
+ * mode MR_EMBED_RECFORMER: ((word[tok_word] + pos[tok_pos]) + type[tok_tt]) + itempos[tok_ip]
+ * d % 4 == 0, d <= 2048.  n_word / n_pos / n_type / n_ip are the tables' row counts: indices are clamped
+ * into range on the device so a corrupt id can never fault the GPU (callers validate ids up front).
+ * replaces: transformers RobertaEmbeddings.forward (reached from module/models/encoder/_base.py:37) and
+ *           recformer/models.py:104-136 (RecformerEmbeddings.forward). */
+int mr_embed_gather_ln_f32(const int32_t* tok_word, const int32_t* tok_pos, const int32_t* tok_tt,
+                           const int32_t* tok_ip, const float* word, const float* pos, const float* type,
+                           const float* itempos, int n_word, int n_pos, int n_type, int n_ip, const float* gamma,
+                           const float* beta, float eps, int T, int d, int mode, float* out, mr_stream_t stream);
+
+/* ---- encoder: dense layers ------------------------------------------------------------------ */
+
+/* C[m, s*seg_n + n] = act( sum_k A[m,k] * W_s[n,k] + bias_s[n] ) (+ R[m, s*seg_n + n] if R != NULL)
+ * for m < M, s < nseg (<= 3), n < seg_n.  A is (M, K) with leading dimension lda, every W_s is
+ * (seg_n, K) row-major contiguous (torch nn.Linear layout), bias_s may be NULL.  The k-sum of each
+ * output element is ONE fp32 fused-multiply-add chain in ascending k starting from 0 (exactly what
+ * v_mfma_f32_32x32x2_f32 computes), so results are bit-identical to oracle/oracle_c.c gemm_nt_ref.
+ * K % 16 == 0; lda, ldc, ldr % 4 == 0; nseg > 1 requires seg_n % 128 == 0.
+ * replaces: torch.nn.functional.linear inside transformers RobertaSelfAttention / RobertaSelfOutput /
+ *           RobertaIntermediate / RobertaOutput and the Longformer equivalents (reached from
+ *           module/models/encoder/_base.py:37 and recformer/models.py:340-348); with bias == NULL it is
+ *           `user_encoding @ self.item_embeddings.T` of module/recommender/module.py:137. */
+int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float* w0, const float* w1, const float* w2,
+                            const float* b0, const float* b1, const float* b2, int nseg, int M, int seg_n, int K,
+                            int act, const float* R, int64_t ldr, float* C, int64_t ldc, mr_stream_t stream);
+
+/* out[t,:] = LayerNorm(x[t,:]) * gamma + beta   (x already holds dense(...) + residual).
+ * replaces: the LayerNorm of transformers RobertaSelfOutput / RobertaOutput (post-LN blocks). */
+int mr_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int T, int d,
+                     float* out, int64_t ldo, mr_stream_t stream);
+
+/* ---- encoder: attention --------------------------------------------------------------------- */
+
+/* Multi-head self-attention over packed tokens.  qkv is (T, 3*H*dh): [q | k | v] per token, head h at
+ * columns h*dh.  ctx is (T, H*dh).  dh == 64.  Keys of a sequence are its own tokens only.
+ * window < 0  : full attention   softmax(q k^T * scale) v                     (RoBERTa / BLaIR)
+ * window >= 0 : Longformer local attention with the first token of every sequence global:
+ *               query i >= 1 sees key j iff j == 0 or |i - j| <= window; row 0 is NOT written
+ *               (it is produced by mr_attn_global_row_f32 from the *_global projections).
+ * replaces: transformers RobertaSelfAttention.forward (eager/sdpa) and LongformerSelfAttention.forward
+ *           (sliding_chunks + global key column), reached from recformer/models.py:340-348. */
+int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, int B, int H, int dh, int max_len, float scale,
+                int window, float* ctx, mr_stream_t stream);
+
+/* Global-token row of Longformer attention: for each sequence b, ctx[cu[b], :] =
+ * softmax(qg_b kg^T * scale) vg over all tokens of b, where qg is (B, H*dh) (the global query of
+ * each sequence's first token) and kvg is (T, 2*H*dh) = [k_global | v_global] per token.
+ * replaces: LongformerSelfAttention._compute_global_attn_output_from_hidden. */
+int mr_attn_global_row_f32(const float* qg, const float* kvg, const int32_t* cu_seqlens, int B, int H, int dh,
+                           int max_len, float scale, float* ctx, mr_stream_t stream);
+
+/* out[b,:] = x[cu_seqlens[b], :]  (CLS pooling), then if normalize: out / max(||out||_2, 1e-12).
+ * replaces: module/models/encoder/_base.py:44-45 (pool 'cls') + module/recommender/module.py:74-77. */
+int mr_cls_pool_normalize_f32(const float* x, int64_t ldx, const int32_t* cu_seqlens, int B, int d, int normalize,
+                              float* out, mr_stream_t stream);
+
+/* Gather rows x[row_idx[i], :] -> out[i, :] (used to run the last layer's dense blocks on CLS rows only). */
+int mr_gather_rows_f32(const float* x, int64_t ldx, const int32_t* row_idx, int n, int d, float* out, int64_t ldo,
+                       mr_stream_t stream);
+
+/* ---- scoring + evaluator -------------------------------------------------------------------- */
+
+/* Per row of scores (nrows, ncols; leading dimension ld): the k largest entries in canonical order
+ * (score descending, index ascending among equal scores, NaN ranks above everything as in torch.topk)
+ * -> top_val (nrows, k) fp32, top_idx (nrows, k) int64.  Optionally (labels != NULL):
+ *   row_lse[r]   = logsumexp(scores[r,:] * inv_temp)
+ *   row_lab[r]   = scores[r, labels[r]] * inv_temp          (CE loss = mean(row_lse - row_lab))
+ *   label_rank[r]= position of labels[r] in top_idx[r,:] or -1
+ * ncols >= k, k <= 64.
+ * replaces: evaluator/evaluator.py:43 (torch.topk), the `true in pred` / `pred.index(true)` scans of
+ *           evaluator/metrics.py:51-57,79-86 and the cross-entropy of module/recommender/module.py:356. */
+int mr_topk_rows_f32(const float* scores, int64_t ld, int nrows, int ncols, int k, float* top_val, int64_t* top_idx,
+                     const int64_t* labels, float inv_temp, float* row_lse, float* row_lab, int32_t* label_rank,
+                     mr_stream_t stream);
+
+/* Full-catalog scoring + top-k in one call: scores = U E^T (U: (nU, d), E: (M, d), both row-major),
+ * then mr_topk_rows_f32 semantics.  If scores_out == NULL the (nU, M) block lives in `ws`.
+ * replaces: module/recommender/module.py:133-139 + evaluator/evaluator.py:43. */
+size_t mr_score_topk_ws_bytes(int64_t nU, int64_t M);
+int mr_score_topk_f32(const float* U, const float* E, int64_t nU, int64_t M, int d, int k, float* top_val,
+                      int64_t* top_idx, float* scores_out, const int64_t* labels, float inv_temp, float* row_lse,
+                      float* row_lab, int32_t* label_rank, void* ws, size_t ws_bytes, mr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERGEREC_HIP_H */

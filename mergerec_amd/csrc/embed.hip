@@ -1,0 +1,256 @@
+// K2 / K2b and the row-wise helpers of the encoder: token packing, embedding gather + LayerNorm,
+// LayerNorm, CLS pooling + L2 normalise, row gather.  All HBM-bound: one wavefront per row,
+// 16-byte loads, wave shuffles for the reductions, one write per output element.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWavesPerBlock = kThreads / MR_WAVE;
+
+__global__ __launch_bounds__(MR_WAVE) void pack_tokens_kernel(const int64_t* __restrict__ ids,
+                                                             const int64_t* __restrict__ mask,
+                                                             const int64_t* __restrict__ tt,
+                                                             const int64_t* __restrict__ ip, int L, int pad_id,
+                                                             const int32_t* __restrict__ cu,
+                                                             int32_t* __restrict__ tok_word,
+                                                             int32_t* __restrict__ tok_pos,
+                                                             int32_t* __restrict__ tok_tt,
+                                                             int32_t* __restrict__ tok_ip) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t row = (int64_t)b * L;
+    const int t0 = cu[b], t1 = cu[b + 1];
+    int run_pos = 0, run_tok = 0;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int l0 = 0; l0 < L; l0 += MR_WAVE) {
+        const int l = l0 + lane;
+        const bool valid = l < L;
+        const int64_t id = valid ? ids[row + l] : (int64_t)pad_id;
+        const bool m = valid && mask[row + l] != 0;
+        const bool nonpad = valid && id != (int64_t)pad_id;
+        const unsigned long long bnp = __ballot(nonpad), bm = __ballot(m);
+        if (m) {
+            const int t = t0 + run_tok + __popcll(bm & lt);
+            if (t < t1) {  // cu_seqlens is caller data: never write past this row's slot
+                const int incl = run_pos + __popcll(bnp & lt) + 1;
+                tok_word[t] = (int32_t)id;
+                tok_pos[t] = nonpad ? incl + pad_id : pad_id;
+                if (tok_tt) tok_tt[t] = tt ? (int32_t)tt[row + l] : 0;
+                if (tok_ip) tok_ip[t] = ip ? (int32_t)ip[row + l] : 0;
+            }
+        }
+        run_pos += __popcll(bnp);
+        run_tok += __popcll(bm);
+    }
+}
+
+__device__ __forceinline__ int clampi(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// LayerNorm of a row held as NV float4 per lane (column = (j*64 + lane)*4); two-pass mean/variance.
+template <int NV>
+__device__ __forceinline__ void ln_row_store(float4 (&x)[NV], int d, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float eps, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * MR_WAVE + lane) * 4;
+        if (c < d) s += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+    }
+    const float mean = mr::wave_sum(s) / (float)d;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * MR_WAVE + lane) * 4;
+        if (c < d) {
+            const float a = x[j].x - mean, b = x[j].y - mean, cc = x[j].z - mean, dd = x[j].w - mean;
+            v += (a * a + b * b) + (cc * cc + dd * dd);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(mr::wave_sum(v) / (float)d + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * MR_WAVE + lane) * 4;
+        if (c < d) {
+            const float4 g = ld4(gamma + c), b = ld4(beta + c);
+            float4 o;
+            o.x = (x[j].x - mean) * rstd * g.x + b.x;
+            o.y = (x[j].y - mean) * rstd * g.y + b.y;
+            o.z = (x[j].z - mean) * rstd * g.z + b.z;
+            o.w = (x[j].w - mean) * rstd * g.w + b.w;
+            *reinterpret_cast<float4*>(out + c) = o;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(kThreads) void embed_gather_ln_kernel(
+    const int32_t* __restrict__ tok_word, const int32_t* __restrict__ tok_pos, const int32_t* __restrict__ tok_tt,
+    const int32_t* __restrict__ tok_ip, const float* __restrict__ word, const float* __restrict__ pos,
+    const float* __restrict__ type, const float* __restrict__ itempos, int n_word, int n_pos, int n_type, int n_ip,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int T, int d, int mode,
+    float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float* wr = word + (int64_t)clampi(tok_word[t], n_word) * d;
+    const float* pr = pos + (int64_t)clampi(tok_pos[t], n_pos) * d;
+    const float* tr = type + (int64_t)clampi(tok_tt ? tok_tt[t] : 0, n_type) * d;
+    const float* ir = (mode == MR_EMBED_RECFORMER) ? itempos + (int64_t)clampi(tok_ip[t], n_ip) * d : nullptr;
+    float4 x[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * MR_WAVE + lane) * 4;
+        if (c < d) {
+            const float4 w = ld4(wr + c), p = ld4(pr + c), ty = ld4(tr + c);
+            if (mode == MR_EMBED_RECFORMER) {
+                x[j] = add4(add4(add4(w, p), ty), ld4(ir + c));  // recformer/models.py:131
+            } else {
+                x[j] = add4(add4(w, ty), p);  // RobertaEmbeddings: (inputs + token_type) + position
+            }
+        } else {
+            x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    ln_row_store<NV>(x, d, gamma, beta, eps, out + (int64_t)t * d);
+}
+
+template <int NV>
+__global__ __launch_bounds__(kThreads) void layernorm_kernel(const float* __restrict__ xin, int64_t ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, int T, int d,
+                                                            float* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= T) return;
+    float4 x[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * MR_WAVE + lane) * 4;
+        x[j] = (c < d) ? ld4(xin + (int64_t)t * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    ln_row_store<NV>(x, d, gamma, beta, eps, out + (int64_t)t * ldo);
+}
+
+template <int NV>
+__global__ __launch_bounds__(kThreads) void cls_pool_kernel(const float* __restrict__ xin, int64_t ldx,
+                                                           const int32_t* __restrict__ cu, int B, int d,
+                                                           int normalize, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* r = xin + (int64_t)cu[b] * ldx;
+    float4 x[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * MR_WAVE + lane) * 4;
+        x[j] = (c < d) ? ld4(r + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+    }
+    float inv = 1.0f;
+    if (normalize) inv = 1.0f / fmaxf(sqrtf(mr::wave_sum(s)), 1e-12f);  // F.normalize eps
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * MR_WAVE + lane) * 4;
+        if (c < d) {
+            float4 o = x[j];
+            if (normalize) { o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv; }
+            *reinterpret_cast<float4*>(out + (int64_t)b * d + c) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __restrict__ xin, int64_t ldx,
+                                                              const int32_t* __restrict__ idx, int n, int d,
+                                                              float* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* r = xin + (int64_t)idx[i] * ldx;
+    for (int c = lane * 4; c < d; c += MR_WAVE * 4) *reinterpret_cast<float4*>(out + (int64_t)i * ldo + c) = ld4(r + c);
+}
+
+#define MR_DISPATCH_NV(d, CALL)                                  \
+    do {                                                         \
+        const int nv_ = ((d) / 4 + MR_WAVE - 1) / MR_WAVE;       \
+        switch (nv_) {                                           \
+            case 1: { constexpr int NV = 1; CALL; } break;       \
+            case 2: { constexpr int NV = 2; CALL; } break;       \
+            case 3: { constexpr int NV = 3; CALL; } break;       \
+            case 4: { constexpr int NV = 4; CALL; } break;       \
+            case 5: case 6: case 7: case 8: { constexpr int NV = 8; CALL; } break; \
+            default: return MR_EUNSUPPORTED;                     \
+        }                                                        \
+    } while (0)
+
+}  // namespace
+
+extern "C" int mr_pack_tokens(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
+                              const int64_t* item_position_ids, int B, int L, int pad_id, const int32_t* cu_seqlens,
+                              int32_t* tok_word, int32_t* tok_pos, int32_t* tok_tt, int32_t* tok_ip,
+                              mr_stream_t stream) {
+    if (!input_ids || !attention_mask || !cu_seqlens || !tok_word || !tok_pos || B < 0 || L < 0) return MR_EINVAL;
+    if (B == 0 || L == 0) return MR_OK;
+    hipLaunchKernelGGL(pack_tokens_kernel, dim3(B), dim3(MR_WAVE), 0, (hipStream_t)stream, input_ids, attention_mask,
+                       token_type_ids, item_position_ids, L, pad_id, cu_seqlens, tok_word, tok_pos, tok_tt, tok_ip);
+    return mr::check_launch();
+}
+
+extern "C" int mr_embed_gather_ln_f32(const int32_t* tok_word, const int32_t* tok_pos, const int32_t* tok_tt,
+                                      const int32_t* tok_ip, const float* word, const float* pos, const float* type,
+                                      const float* itempos, int n_word, int n_pos, int n_type, int n_ip,
+                                      const float* gamma, const float* beta, float eps, int T, int d, int mode,
+                                      float* out, mr_stream_t stream) {
+    if (!tok_word || !tok_pos || !word || !pos || !type || !gamma || !beta || !out || T < 0 || d <= 0) return MR_EINVAL;
+    if (mode == MR_EMBED_RECFORMER && (!itempos || !tok_ip || !tok_tt)) return MR_EINVAL;
+    if (mode != MR_EMBED_ROBERTA && mode != MR_EMBED_RECFORMER) return MR_EUNSUPPORTED;
+    if (n_word < 1 || n_pos < 1 || n_type < 1 || (mode == MR_EMBED_RECFORMER && n_ip < 1)) return MR_EINVAL;
+    if ((d & 3) || d > 2048) return MR_EUNSUPPORTED;
+    if (!mr::aligned16(word) || !mr::aligned16(pos) || !mr::aligned16(type) || !mr::aligned16(gamma) ||
+        !mr::aligned16(beta) || !mr::aligned16(out) || (itempos && !mr::aligned16(itempos)))
+        return MR_EALIGN;
+    if (T == 0) return MR_OK;
+    const unsigned blocks = (unsigned)((T + kWavesPerBlock - 1) / kWavesPerBlock);
+    MR_DISPATCH_NV(d, hipLaunchKernelGGL((embed_gather_ln_kernel<NV>), dim3(blocks), dim3(kThreads), 0,
+                                         (hipStream_t)stream, tok_word, tok_pos, tok_tt, tok_ip, word, pos, type, itempos,
+                                         n_word, n_pos, n_type, n_ip, gamma, beta, eps, T, d, mode, out));
+    return mr::check_launch();
+}
+
+extern "C" int mr_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int T,
+                                int d, float* out, int64_t ldo, mr_stream_t stream) {
+    if (!x || !gamma || !beta || !out || T < 0 || d <= 0) return MR_EINVAL;
+    if ((d & 3) || d > 2048) return MR_EUNSUPPORTED;
+    if ((ldx & 3) || (ldo & 3) || !mr::aligned16(x) || !mr::aligned16(out) || !mr::aligned16(gamma) || !mr::aligned16(beta))
+        return MR_EALIGN;
+    if (T == 0) return MR_OK;
+    const unsigned blocks = (unsigned)((T + kWavesPerBlock - 1) / kWavesPerBlock);
+    MR_DISPATCH_NV(d, hipLaunchKernelGGL((layernorm_kernel<NV>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x,
+                                         ldx, gamma, beta, eps, T, d, out, ldo));
+    return mr::check_launch();
+}
+
+extern "C" int mr_cls_pool_normalize_f32(const float* x, int64_t ldx, const int32_t* cu_seqlens, int B, int d,
+                                         int normalize, float* out, mr_stream_t stream) {
+    if (!x || !cu_seqlens || !out || B < 0 || d <= 0) return MR_EINVAL;
+    if ((d & 3) || d > 2048) return MR_EUNSUPPORTED;
+    if ((ldx & 3) || !mr::aligned16(x) || !mr::aligned16(out)) return MR_EALIGN;
+    if (B == 0) return MR_OK;
+    const unsigned blocks = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
+    MR_DISPATCH_NV(d, hipLaunchKernelGGL((cls_pool_kernel<NV>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x,
+                                         ldx, cu_seqlens, B, d, normalize, out));
+    return mr::check_launch();
+}
+
+extern "C" int mr_gather_rows_f32(const float* x, int64_t ldx, const int32_t* row_idx, int n, int d, float* out,
+                                  int64_t ldo, mr_stream_t stream) {
+    if (!x || !row_idx || !out || n < 0 || d <= 0) return MR_EINVAL;
+    if ((d & 3) || (ldx & 3) || (ldo & 3) || !mr::aligned16(x) || !mr::aligned16(out)) return MR_EALIGN;
+    if (n == 0) return MR_OK;
+    const unsigned blocks = (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, row_idx, n, d, out, ldo);
+    return mr::check_launch();
+}

@@ -1,0 +1,180 @@
+// K3 / K5-GEMM: C = act(A W^T + bias) (+ R) in exact fp32 on the matrix cores.
+//
+// v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate (157 TFLOP/s chip peak) and is bit-for-bit an
+// fp32 FMA chain over k, so the product path keeps fp32-reference numerics (logits within 1e-4,
+// ranked indices exact) while staying on MFMA.  Block tile 128x128x16, 4 waves (2x2), each wave a
+// 64x64 patch = 2x2 MFMA tiles (64 accumulator VGPRs).  Both operands are K-contiguous ("NT"), staged
+// global -> registers -> LDS (double-buffered LDS, one barrier per k-tile; next tile's global loads are
+// in flight under the current tile's 32 MFMAs per wave).  LDS rows are split into even-k | odd-k halves
+// so that lane (row, h) fetches its 8 operands for the 8 MFMA steps of a k-tile with two ds_read_b128
+// and every output element accumulates k = 0, 1, 2, ... in ascending order.  Row stride 20 floats makes
+// the b128 reads conflict-free.  fp32 MFMA needs only ~8 B/clk/CU of operand traffic, far below L2/LDS
+// limits: the kernel is MFMA-issue bound by construction.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDS_STRIDE = 20;  // floats per LDS row: 8 even-k | 8 odd-k | 4 pad
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int ACT, bool HAS_R>
+__global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ w0, const float* __restrict__ w1,
+    const float* __restrict__ w2, const float* __restrict__ b0, const float* __restrict__ b1,
+    const float* __restrict__ b2, int M, int seg_n, int K, const float* __restrict__ R, int64_t ldr,
+    float* __restrict__ C, int64_t ldc, int tiles_n_seg, int tiles_n, int nwg) {
+    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_STRIDE];
+
+    const int pid = mr::xcd_remap(blockIdx.x, nwg);
+    const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
+    const int seg = tn / tiles_n_seg;
+    const int n0 = (tn - seg * tiles_n_seg) * BN;  // column inside the segment
+    const int m0 = tm * BM;
+    const float* __restrict__ W = seg == 0 ? w0 : (seg == 1 ? w1 : w2);
+    const float* __restrict__ bias = seg == 0 ? b0 : (seg == 1 ? b1 : b2);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // ---- staging map: thread -> (row r / r+64, k-quad kq)
+    const int sr = tid >> 2, kq = tid & 3;
+    int ar0 = m0 + sr, ar1 = m0 + sr + 64;
+    ar0 = ar0 < M ? ar0 : M - 1;
+    ar1 = ar1 < M ? ar1 : M - 1;
+    int br0 = n0 + sr, br1 = n0 + sr + 64;
+    br0 = br0 < seg_n ? br0 : seg_n - 1;
+    br1 = br1 < seg_n ? br1 : seg_n - 1;
+    const float* ga0 = A + (int64_t)ar0 * lda + kq * 4;
+    const float* ga1 = A + (int64_t)ar1 * lda + kq * 4;
+    const float* gb0 = W + (int64_t)br0 * K + kq * 4;
+    const float* gb1 = W + (int64_t)br1 * K + kq * 4;
+    // LDS write offsets (floats): even half at 2*kq, odd half at 8 + 2*kq
+    const int wa0 = sr * LDS_STRIDE + 2 * kq, wa1 = (sr + 64) * LDS_STRIDE + 2 * kq;
+    const int wb0 = (BM + sr) * LDS_STRIDE + 2 * kq, wb1 = (BM + sr + 64) * LDS_STRIDE + 2 * kq;
+    // LDS read offsets (floats)
+    const int ra = (wm * 64 + lr) * LDS_STRIDE + lh * 8;
+    const int rb = (BM + wn * 64 + lr) * LDS_STRIDE + lh * 8;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 sa0, sa1, sb0, sb1;
+    auto gload = [&](int k0) {
+        sa0 = *reinterpret_cast<const float4*>(ga0 + k0);
+        sa1 = *reinterpret_cast<const float4*>(ga1 + k0);
+        sb0 = *reinterpret_cast<const float4*>(gb0 + k0);
+        sb1 = *reinterpret_cast<const float4*>(gb1 + k0);
+    };
+    auto lstore = [&](float* buf) {
+        *reinterpret_cast<float2*>(buf + wa0) = make_float2(sa0.x, sa0.z);
+        *reinterpret_cast<float2*>(buf + wa0 + 8) = make_float2(sa0.y, sa0.w);
+        *reinterpret_cast<float2*>(buf + wa1) = make_float2(sa1.x, sa1.z);
+        *reinterpret_cast<float2*>(buf + wa1 + 8) = make_float2(sa1.y, sa1.w);
+        *reinterpret_cast<float2*>(buf + wb0) = make_float2(sb0.x, sb0.z);
+        *reinterpret_cast<float2*>(buf + wb0 + 8) = make_float2(sb0.y, sb0.w);
+        *reinterpret_cast<float2*>(buf + wb1) = make_float2(sb1.x, sb1.z);
+        *reinterpret_cast<float2*>(buf + wb1 + 8) = make_float2(sb1.y, sb1.w);
+    };
+
+    const int nk = K / BK;
+    gload(0);
+    lstore(lds[0]);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* buf = lds[kt & 1];
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        float4 a[2][2], b[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[i][0] = *reinterpret_cast<const float4*>(buf + ra + i * 32 * LDS_STRIDE);
+            a[i][1] = *reinterpret_cast<const float4*>(buf + ra + i * 32 * LDS_STRIDE + 4);
+            b[i][0] = *reinterpret_cast<const float4*>(buf + rb + i * 32 * LDS_STRIDE);
+            b[i][1] = *reinterpret_cast<const float4*>(buf + rb + i * 32 * LDS_STRIDE + 4);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 fa = a[i][s >> 2], fb = b[i][s >> 2];
+                av[i] = (s & 3) == 0 ? fa.x : ((s & 3) == 1 ? fa.y : ((s & 3) == 2 ? fa.z : fa.w));
+                bv[i] = (s & 3) == 0 ? fb.x : ((s & 3) == 1 ? fb.y : ((s & 3) == 2 ? fb.z : fb.w));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(lds[(kt + 1) & 1]);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + lr;
+        if (col >= seg_n) continue;
+        const float bz = bias ? bias[col] : 0.f;
+        const int64_t colg = (int64_t)seg * seg_n + col;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < M) {
+                    float v = acc[i][j][r] + bz;
+                    if (ACT == MR_ACT_GELU_ERF) v = gelu_erf(v);
+                    if (HAS_R) v += R[(int64_t)row * ldr + colg];
+                    C[(int64_t)row * ldc + colg] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float* w0, const float* w1, const float* w2,
+                                       const float* b0, const float* b1, const float* b2, int nseg, int M, int seg_n,
+                                       int K, int act, const float* R, int64_t ldr, float* C, int64_t ldc,
+                                       mr_stream_t stream) {
+    if (!A || !w0 || !C || nseg < 1 || nseg > 3 || M < 0 || seg_n < 1 || K < 1) return MR_EINVAL;
+    if ((nseg > 1 && !w1) || (nseg > 2 && !w2)) return MR_EINVAL;
+    if (K % BK) return MR_EUNSUPPORTED;
+    if (nseg > 1 && (seg_n % BN)) return MR_EUNSUPPORTED;
+    if (act != MR_ACT_NONE && act != MR_ACT_GELU_ERF) return MR_EUNSUPPORTED;
+    if ((lda & 3) || (ldc & 3) || (R && (ldr & 3))) return MR_EALIGN;
+    if (!mr::aligned16(A) || !mr::aligned16(w0) || (w1 && !mr::aligned16(w1)) || (w2 && !mr::aligned16(w2)))
+        return MR_EALIGN;
+    if (M == 0) return MR_OK;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_n_seg = (seg_n + BN - 1) / BN;
+    const int tiles_n = tiles_n_seg * nseg;
+    const int64_t nwg64 = (int64_t)tiles_m * tiles_n;
+    if (nwg64 > 0x7fffffff) return MR_EUNSUPPORTED;
+    const int nwg = (int)nwg64;
+    hipStream_t st = (hipStream_t)stream;
+#define MR_GEMM_LAUNCH(ACT_, HASR_)                                                                                   \
+    hipLaunchKernelGGL((gemm_nt_kernel<ACT_, HASR_>), dim3(nwg), dim3(kThreads), 0, st, A, lda, w0, w1, w2, b0, b1, b2, \
+                       M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg)
+    if (act == MR_ACT_GELU_ERF) {
+        if (R) MR_GEMM_LAUNCH(MR_ACT_GELU_ERF, true); else MR_GEMM_LAUNCH(MR_ACT_GELU_ERF, false);
+    } else {
+        if (R) MR_GEMM_LAUNCH(MR_ACT_NONE, true); else MR_GEMM_LAUNCH(MR_ACT_NONE, false);
+    }
+#undef MR_GEMM_LAUNCH
+    return mr::check_launch();
+}

@@ -1,0 +1,207 @@
+// K5: full-catalog scoring epilogue -- exact row-wise top-k in canonical order, plus the per-row
+// log-sum-exp / label logit / label rank the evaluator and the CE loss need.
+//
+// One 256-thread workgroup per score row.  Exact radix select on order-preserving 32-bit keys
+// (4 passes x 8 bits, histograms in LDS) finds the k-th largest key; a collection pass takes
+// everything above it plus the lowest-index ties, and one wavefront bitonic-sorts the <= 64 survivors
+// by (score desc, index asc).  The row (<= ~120 KB) is re-read from L2 on every pass; the kernel's
+// HBM traffic is one read of the score block.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ unsigned ord_key(float f) {
+    unsigned u = __float_as_uint(f);
+    if (f != f) return 0xffffffffu;       // NaN ranks above everything (torch.topk convention)
+    if (u == 0x80000000u) u = 0u;         // -0.0 == +0.0: same key, tie broken by index
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(kThreads) void topk_rows_kernel(const float* __restrict__ scores, int64_t ld, int ncols,
+                                                            int k, float* __restrict__ top_val,
+                                                            int64_t* __restrict__ top_idx,
+                                                            const int64_t* __restrict__ labels, float inv_temp,
+                                                            float* __restrict__ row_lse, float* __restrict__ row_lab,
+                                                            int32_t* __restrict__ label_rank) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_remaining, s_ngt;
+    __shared__ unsigned wave_cnt[kThreads / MR_WAVE];
+    __shared__ unsigned long long cand[64];
+    __shared__ float red[kThreads / MR_WAVE];
+
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ s = scores + (int64_t)row * ld;
+
+    if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)k; s_ngt = 0u; }
+    if (tid < 64) cand[tid] = 0ull;
+    unsigned mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        for (int i = tid; i < ncols; i += kThreads) {
+            const unsigned key = ord_key(s[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned rem = s_remaining, c = 0u;
+            int bkt = 255;
+            for (; bkt > 0; --bkt) {
+                if (c + hist[bkt] >= rem) break;
+                c += hist[bkt];
+            }
+            s_remaining = rem - c;
+            s_prefix = prefix | ((unsigned)bkt << shift);
+        }
+        mask |= 0xffu << shift;
+        __syncthreads();
+    }
+    const unsigned thr = s_prefix;          // key of the k-th largest element
+    const unsigned need_eq = s_remaining;   // how many elements equal to it belong to the top-k
+    const unsigned n_gt = (unsigned)k - need_eq;
+
+    // collection: keys > thr in any order, keys == thr by ascending index (first need_eq of them)
+    unsigned eq_seen = 0u;  // block-uniform running count of == thr elements in earlier chunks
+    for (int base = 0; base < ncols; base += kThreads) {
+        const int i = base + tid;
+        unsigned key = 0u;
+        bool gt = false, eq = false;
+        if (i < ncols) {
+            key = ord_key(s[i]);
+            gt = key > thr;
+            eq = key == thr;
+        }
+        if (gt) {
+            const unsigned slot = atomicAdd(&s_ngt, 1u);
+            if (slot < 64u) cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+        }
+        const unsigned long long beq = __ballot(eq);
+        if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(beq);
+        __syncthreads();
+        unsigned before = eq_seen, total = 0u;
+#pragma unroll
+        for (int w = 0; w < kThreads / MR_WAVE; ++w) {
+            if (w < wave) before += wave_cnt[w];
+            total += wave_cnt[w];
+        }
+        if (eq) {
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const unsigned rank = before + (unsigned)__popcll(beq & lt);
+            if (rank < need_eq)
+                cand[n_gt + rank] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+        }
+        eq_seen += total;
+        __syncthreads();
+        if (eq_seen >= need_eq && base + kThreads < ncols) {
+            // remaining chunks can only contribute keys > thr
+            for (int j = base + kThreads + tid; j < ncols; j += kThreads) {
+                const unsigned kj = ord_key(s[j]);
+                if (kj > thr) {
+                    const unsigned slot = atomicAdd(&s_ngt, 1u);
+                    if (slot < 64u) cand[slot] = ((unsigned long long)kj << 32) | (unsigned long long)(0xffffffffu - (unsigned)j);
+                }
+            }
+            break;
+        }
+    }
+    __syncthreads();
+
+    // bitonic sort (descending) of the 64 candidate slots in wave 0; unused slots are 0 and sink
+    if (wave == 0) {
+        unsigned long long v = cand[lane];
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const unsigned long long o = __shfl_xor(v, stride, 64);
+                const bool up = ((lane & size) == 0);          // descending block
+                const bool lower = ((lane & stride) == 0);
+                const bool take_max = (up == lower);
+                v = take_max ? (v > o ? v : o) : (v < o ? v : o);
+            }
+        }
+        if (lane < k) {
+            unsigned idx = 0xffffffffu - (unsigned)(v & 0xffffffffull);
+            if (idx >= (unsigned)ncols) idx = 0u;  // cannot happen for ncols >= k; never read out of bounds
+            top_idx[(int64_t)row * k + lane] = (int64_t)idx;
+            top_val[(int64_t)row * k + lane] = s[idx];
+        }
+        if (labels) {
+            const int64_t lab = labels[row];
+            const unsigned idx = 0xffffffffu - (unsigned)(v & 0xffffffffull);
+            const unsigned long long hit = __ballot(lane < k && (int64_t)idx == lab);
+            if (lane == 0 && label_rank) label_rank[row] = hit ? (int32_t)__builtin_ctzll(hit) : -1;
+        }
+        cand[lane] = v;
+    }
+    __syncthreads();
+
+    if (labels && row_lse) {
+        // row max = best candidate's score (NaN rows propagate NaN like torch.cross_entropy)
+        unsigned best = 0xffffffffu - (unsigned)(cand[0] & 0xffffffffull);
+        if (best >= (unsigned)ncols) best = 0u;
+        const float mx = s[best] * inv_temp;
+        float acc = 0.f;
+        for (int i = tid; i < ncols; i += kThreads) acc += expf(s[i] * inv_temp - mx);
+        acc = mr::wave_sum(acc);
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+            row_lse[row] = mx + logf(tot);
+            if (row_lab) {
+                const int64_t lab = labels[row];
+                row_lab[row] = (lab >= 0 && lab < ncols) ? s[lab] * inv_temp : NAN;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mr_topk_rows_f32(const float* scores, int64_t ld, int nrows, int ncols, int k, float* top_val,
+                                int64_t* top_idx, const int64_t* labels, float inv_temp, float* row_lse, float* row_lab,
+                                int32_t* label_rank, mr_stream_t stream) {
+    if (!scores || !top_val || !top_idx || nrows < 0 || ncols < 1 || k < 1) return MR_EINVAL;
+    if (k > 64 || k > ncols) return MR_EUNSUPPORTED;
+    if (ld < ncols) return MR_EINVAL;
+    if (nrows == 0) return MR_OK;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(nrows), dim3(kThreads), 0, (hipStream_t)stream, scores, ld, ncols, k, top_val,
+                       top_idx, labels, inv_temp, row_lse, row_lab, label_rank);
+    return mr::check_launch();
+}
+
+extern "C" size_t mr_score_topk_ws_bytes(int64_t nU, int64_t M) {
+    if (nU < 0 || M < 0) return 0;
+    const int64_t ldm = (M + 3) & ~(int64_t)3;
+    return (size_t)nU * (size_t)ldm * sizeof(float) + 256;
+}
+
+extern "C" int mr_score_topk_f32(const float* U, const float* E, int64_t nU, int64_t M, int d, int k, float* top_val,
+                                 int64_t* top_idx, float* scores_out, const int64_t* labels, float inv_temp,
+                                 float* row_lse, float* row_lab, int32_t* label_rank, void* ws, size_t ws_bytes,
+                                 mr_stream_t stream) {
+    if (!U || !E || nU < 0 || M < 1 || d < 1) return MR_EINVAL;
+    if (nU > 0x7fffffff || M > 0x7fffffff) return MR_EUNSUPPORTED;
+    float* sc = scores_out;
+    int64_t ldm = M;
+    if (!sc) {
+        if (!ws) return MR_EINVAL;
+        if (ws_bytes < mr_score_topk_ws_bytes(nU, M)) return MR_EWS;
+        sc = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+        ldm = (M + 3) & ~(int64_t)3;
+    } else if (M & 3) {
+        return MR_EALIGN;  // a caller-provided (nU, M) block needs M % 4 == 0 for the GEMM's ldc rule
+    }
+    if (nU == 0) return MR_OK;
+    int rc = mr_gemm_nt_bias_act_f32(U, d, E, nullptr, nullptr, nullptr, nullptr, nullptr, 1, (int)nU, (int)M, d,
+                                     MR_ACT_NONE, nullptr, 0, sc, ldm, stream);
+    if (rc != MR_OK) return rc;
+    return mr_topk_rows_f32(sc, ldm, (int)nU, (int)M, k, top_val, top_idx, labels, inv_temp, row_lse, row_lab, label_rank,
+                            stream);
+}

@@ -1,0 +1,218 @@
+"""Thin torch-tensor wrappers over the C ABI (include/mergerec_hip.h).
+
+Every function launches hand-written HIP kernels on the current torch stream and returns torch tensors
+that own the output memory.  No function here has a torch/eager fallback: inputs must be CUDA(=HIP)
+tensors and the shared library must be present, otherwise MergeRecHipError / ValueError is raised.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import MergeRecHipError, check, ptr
+
+ACT_NONE, ACT_GELU = 0, 1
+EMBED_ROBERTA, EMBED_RECFORMER = 0, 1
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor (the HIP path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+# ------------------------------------------------------------------------------------------ merger
+def task_vector(theta: torch.Tensor, base: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(theta, "theta", torch.float32), _dev(base, "base", torch.float32)
+    if theta.numel() != base.numel():
+        raise ValueError("theta/base size mismatch")
+    out = torch.empty_like(base) if out is None else _dev(out, "out", torch.float32)
+    check(_lib.load().mr_task_vector_f32(ptr(theta), ptr(base), base.numel(), ptr(out), _stream(base)), "mr_task_vector_f32")
+    return out
+
+
+def merge_nway(
+    base: torch.Tensor, tv: torch.Tensor, alpha: torch.Tensor, seg_off: Optional[torch.Tensor] = None,
+    out: Optional[torch.Tensor] = None, p_begin: int = 0, p_count: Optional[int] = None,
+) -> torch.Tensor:
+    """out[p] = base[p] + sum_i alpha[s(p), i] * tv[i, p] for p in [p_begin, p_begin + p_count)."""
+    _dev(base, "base", torch.float32), _dev(tv, "tv", torch.float32), _dev(alpha, "alpha", torch.float32)
+    if tv.dim() != 2 or tv.shape[1] != base.numel():
+        raise ValueError("tv must be (N, P)")
+    N, P = tv.shape
+    S = 1 if seg_off is None else seg_off.numel() - 1
+    if alpha.numel() != S * N:
+        raise ValueError(f"alpha must hold S*N = {S * N} floats, got {alpha.numel()}")
+    if seg_off is not None:
+        _dev(seg_off, "seg_off", torch.int64)
+    out = torch.empty_like(base) if out is None else _dev(out, "out", torch.float32)
+    p_count = P - p_begin if p_count is None else p_count
+    if p_begin < 0 or p_count < 0 or p_begin + p_count > P:
+        raise ValueError("slice out of range")
+    check(
+        _lib.load().mr_merge_nway_f32(ptr(base), ptr(tv), tv.stride(0), ptr(alpha), ptr(seg_off), N, S, p_begin, p_count, ptr(out), _stream(base)),
+        "mr_merge_nway_f32",
+    )
+    return out
+
+
+def merge_bwd_alpha(tv: torch.Tensor, g: torch.Tensor, seg_off: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(tv, "tv", torch.float32), _dev(g, "g", torch.float32)
+    N, P = tv.shape
+    S = 1 if seg_off is None else seg_off.numel() - 1
+    lib = _lib.load()
+    nbytes = lib.mr_merge_bwd_alpha_ws_bytes(N, S, P)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=tv.device)
+    out = torch.empty(S, N, dtype=torch.float32, device=tv.device)
+    check(lib.mr_merge_bwd_alpha_f32(ptr(tv), tv.stride(0), ptr(g), ptr(seg_off), N, S, P, ptr(out), ptr(ws), nbytes, _stream(tv)), "mr_merge_bwd_alpha_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ encoder
+def pack_tokens(input_ids, attention_mask, cu_seqlens, T: int, pad_id: int, token_type_ids=None, item_position_ids=None):
+    _dev(input_ids, "input_ids", torch.int64), _dev(attention_mask, "attention_mask", torch.int64)
+    _dev(cu_seqlens, "cu_seqlens", torch.int32)
+    B, L = input_ids.shape
+    dev = input_ids.device
+    tok_word = torch.empty(T, dtype=torch.int32, device=dev)
+    tok_pos = torch.empty(T, dtype=torch.int32, device=dev)
+    tok_tt = torch.empty(T, dtype=torch.int32, device=dev) if token_type_ids is not None else None
+    tok_ip = torch.empty(T, dtype=torch.int32, device=dev) if item_position_ids is not None else None
+    if token_type_ids is not None:
+        _dev(token_type_ids, "token_type_ids", torch.int64)
+    if item_position_ids is not None:
+        _dev(item_position_ids, "item_position_ids", torch.int64)
+    check(
+        _lib.load().mr_pack_tokens(ptr(input_ids), ptr(attention_mask), ptr(token_type_ids), ptr(item_position_ids), B, L, pad_id,
+                                   ptr(cu_seqlens), ptr(tok_word), ptr(tok_pos), ptr(tok_tt), ptr(tok_ip), _stream(input_ids)),
+        "mr_pack_tokens",
+    )
+    return tok_word, tok_pos, tok_tt, tok_ip
+
+
+def embed_gather_ln(tok_word, tok_pos, tok_tt, tok_ip, word, pos, type_, itempos, gamma, beta, eps: float, mode: int, out=None):
+    T, d = tok_word.numel(), word.shape[1]
+    out = torch.empty(T, d, dtype=torch.float32, device=word.device) if out is None else out
+    check(
+        _lib.load().mr_embed_gather_ln_f32(
+            ptr(tok_word), ptr(tok_pos), ptr(tok_tt), ptr(tok_ip), ptr(word), ptr(pos), ptr(type_), ptr(itempos),
+            word.shape[0], pos.shape[0], type_.shape[0], 0 if itempos is None else itempos.shape[0],
+            ptr(gamma), ptr(beta), eps, T, d, mode, ptr(out), _stream(word)),
+        "mr_embed_gather_ln_f32",
+    )
+    return out
+
+
+def gemm_nt(A: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]] = (None,),
+            act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[:, s*n:(s+1)*n] = act(A @ weights[s].T + biases[s]) (+ residual); 1..3 equally-shaped weight segments."""
+    if A.dim() != 2 or A.stride(1) != 1:
+        raise ValueError("A must be 2-D with unit inner stride")
+    nseg = len(weights)
+    seg_n, K = weights[0].shape
+    if A.shape[1] != K:
+        raise ValueError("K mismatch")
+    biases = list(biases) + [None] * (3 - len(biases))
+    ws = list(weights) + [None] * (3 - nseg)
+    M = A.shape[0]
+    out = torch.empty(M, nseg * seg_n, dtype=torch.float32, device=A.device) if out is None else out
+    check(
+        _lib.load().mr_gemm_nt_bias_act_f32(
+            ptr(A), A.stride(0), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(biases[0]), ptr(biases[1]), ptr(biases[2]), nseg, M, seg_n, K,
+            act, ptr(residual), 0 if residual is None else residual.stride(0), ptr(out), out.stride(0), _stream(A)),
+        "mr_gemm_nt_bias_act_f32",
+    )
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma, beta, eps: float, out=None) -> torch.Tensor:
+    T, d = x.shape
+    out = torch.empty(T, d, dtype=torch.float32, device=x.device) if out is None else out
+    check(_lib.load().mr_layernorm_f32(ptr(x), x.stride(0), ptr(gamma), ptr(beta), eps, T, d, ptr(out), out.stride(0), _stream(x)), "mr_layernorm_f32")
+    return out
+
+
+def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, window: int = -1, out=None) -> torch.Tensor:
+    T = qkv.shape[0]
+    dh = qkv.shape[1] // (3 * H)
+    out = torch.empty(T, H * dh, dtype=torch.float32, device=qkv.device) if out is None else out
+    check(_lib.load().mr_attn_f32(ptr(qkv), ptr(cu_seqlens), B, H, dh, max_len, dh ** -0.5, window, ptr(out), _stream(qkv)), "mr_attn_f32")
+    return out
+
+
+def attention_global_row(qg: torch.Tensor, kvg: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, ctx: torch.Tensor):
+    dh = qg.shape[1] // H
+    check(_lib.load().mr_attn_global_row_f32(ptr(qg), ptr(kvg), ptr(cu_seqlens), B, H, dh, max_len, dh ** -0.5, ptr(ctx), _stream(qg)), "mr_attn_global_row_f32")
+    return ctx
+
+
+def cls_pool_normalize(x: torch.Tensor, cu_seqlens: torch.Tensor, B: int, normalize: bool, out=None) -> torch.Tensor:
+    d = x.shape[1]
+    out = torch.empty(B, d, dtype=torch.float32, device=x.device) if out is None else out
+    check(_lib.load().mr_cls_pool_normalize_f32(ptr(x), x.stride(0), ptr(cu_seqlens), B, d, int(normalize), ptr(out), _stream(x)), "mr_cls_pool_normalize_f32")
+    return out
+
+
+def gather_rows(x: torch.Tensor, row_idx: torch.Tensor, out=None) -> torch.Tensor:
+    n, d = row_idx.numel(), x.shape[1]
+    out = torch.empty(n, d, dtype=torch.float32, device=x.device) if out is None else out
+    check(_lib.load().mr_gather_rows_f32(ptr(x), x.stride(0), ptr(row_idx), n, d, ptr(out), out.stride(0), _stream(x)), "mr_gather_rows_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ scoring
+def topk_rows(scores: torch.Tensor, k: int, labels: Optional[torch.Tensor] = None, inv_temp: float = 1.0):
+    _dev(scores, "scores", torch.float32)
+    R, C = scores.shape
+    dev = scores.device
+    val = torch.empty(R, k, dtype=torch.float32, device=dev)
+    idx = torch.empty(R, k, dtype=torch.int64, device=dev)
+    lse = lab = rank = None
+    if labels is not None:
+        _dev(labels, "labels", torch.int64)
+        lse = torch.empty(R, dtype=torch.float32, device=dev)
+        lab = torch.empty(R, dtype=torch.float32, device=dev)
+        rank = torch.empty(R, dtype=torch.int32, device=dev)
+    check(_lib.load().mr_topk_rows_f32(ptr(scores), scores.stride(0), R, C, k, ptr(val), ptr(idx), ptr(labels), inv_temp, ptr(lse), ptr(lab), ptr(rank), _stream(scores)), "mr_topk_rows_f32")
+    return val, idx, lse, lab, rank
+
+
+def score_topk(U: torch.Tensor, E: torch.Tensor, k: int, labels: Optional[torch.Tensor] = None, inv_temp: float = 1.0,
+               return_scores: bool = False):
+    """scores = U @ E.T -> canonical top-k (+ lse / label logit / label rank when labels are given)."""
+    _dev(U, "U", torch.float32), _dev(E, "E", torch.float32)
+    nU, d = U.shape
+    M = E.shape[0]
+    dev = U.device
+    lib = _lib.load()
+    val = torch.empty(nU, k, dtype=torch.float32, device=dev)
+    idx = torch.empty(nU, k, dtype=torch.int64, device=dev)
+    lse = lab = rank = None
+    if labels is not None:
+        lse = torch.empty(nU, dtype=torch.float32, device=dev)
+        lab = torch.empty(nU, dtype=torch.float32, device=dev)
+        rank = torch.empty(nU, dtype=torch.int32, device=dev)
+    scores = ws = None
+    nbytes = 0
+    if return_scores and M % 4 == 0:
+        scores = torch.empty(nU, M, dtype=torch.float32, device=dev)
+    else:
+        nbytes = lib.mr_score_topk_ws_bytes(nU, M)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib.mr_score_topk_f32(ptr(U), ptr(E), nU, M, d, k, ptr(val), ptr(idx), ptr(scores), ptr(labels), inv_temp, ptr(lse), ptr(lab), ptr(rank), ptr(ws), nbytes, _stream(U)), "mr_score_topk_f32")
+    if return_scores and scores is None:
+        # M % 4 != 0: the block lives in the workspace with a padded leading dimension; expose a view
+        ldm = (M + 3) & ~3
+        off = (-ws.data_ptr()) % 256
+        scores = ws[off : off + nU * ldm * 4].view(torch.float32).view(nU, ldm)[:, :M]
+    return val, idx, lse, lab, rank, scores

@@ -1,0 +1,41 @@
+"""CPU-side checks of the C-ABI boundary: the library loads and exports every symbol the header declares."""
+import ctypes
+import re
+
+from mergerec_amd import _lib
+
+
+def test_library_exports_every_header_symbol():
+    lib = _lib.load()
+    names = _lib.header_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mergerec_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
+
+
+def test_version_and_strerror():
+    lib = _lib.load()
+    assert lib.mr_version() >= 100
+    assert lib.mr_strerror(0) == b"ok"
+    assert b"invalid" in lib.mr_strerror(-1)
+
+
+def test_argument_validation_without_gpu():
+    """Validation happens before any HIP call, so it can be exercised without a device."""
+    lib = _lib.load()
+    assert lib.mr_merge_nway_f32(None, None, 0, None, None, 2, 1, 0, 16, None, None) == -1
+    assert lib.mr_gemm_nt_bias_act_f32(None, 0, None, None, None, None, None, None, 1, 4, 4, 16, 0, None, 0, None, 0, None) == -1
+    assert lib.mr_topk_rows_f32(None, 0, 1, 10, 5, None, None, None, 1.0, None, None, None, None) == -1
+    assert lib.mr_merge_bwd_alpha_ws_bytes(8, 13, 1 << 20) > 0
+    assert lib.mr_score_topk_ws_bytes(32, 1001) >= 32 * 1004 * 4
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+
+    from mergerec_amd import ops
+
+    with pytest.raises(ValueError):
+        ops.merge_nway(torch.zeros(8), torch.zeros(2, 8), torch.zeros(2))

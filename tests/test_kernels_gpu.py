@@ -1,0 +1,284 @@
+"""GPU parity: every HIP kernel, called through the C ABI, against the CPU oracle on seeded inputs."""
+import math
+
+import pytest
+import torch
+
+from oracle import c_oracle as CO
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mergerec_amd import ops as _ops
+
+    return _ops
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------ K1 / K1b / a3
+@pytest.mark.parametrize("N", [1, 2, 3, 8, 11])
+def test_merge_taskwise_bitexact(ops, N):
+    P = 64 * 1531  # multiple of 64 (arena granule), not of the chunk size
+    g = _g(N)
+    base = torch.randn(P, generator=g) * 0.02
+    tv = torch.randn(N, P, generator=g) * 1e-3
+    alpha = torch.rand(N, generator=g) * 0.6 - 0.1
+    want = O.merge_task_wise(base, tv, alpha)
+    got = ops.merge_nway(base.to(DEV), tv.to(DEV), alpha.to(DEV)).cpu()
+    assert torch.equal(got, want)
+    assert torch.equal(CO.merge_nway(base, tv, alpha), want)
+
+
+def test_merge_layerwise_segments_and_slices_bitexact(ops):
+    g = _g(7)
+    seg_len = [64 * 3, 64 * 40, 64 * 1, 64 * 129, 64 * 17, 64 * 64]
+    seg_off = torch.tensor([0] + list(torch.tensor(seg_len).cumsum(0)), dtype=torch.int64)
+    P, N, S = int(seg_off[-1]), 3, len(seg_len)
+    base = torch.randn(P, generator=g)
+    tv = torch.randn(N, P, generator=g)
+    alpha = torch.rand(S, N, generator=g)
+    want = torch.empty(P)
+    for s in range(S):
+        a, b = int(seg_off[s]), int(seg_off[s + 1])
+        want[a:b] = O.merge_task_wise(base[a:b], tv[:, a:b], alpha[s])
+    got = ops.merge_nway(base.to(DEV), tv.to(DEV), alpha.to(DEV), seg_off.to(DEV)).cpu()
+    assert torch.equal(got, want)
+    # rank-slice form: two ranks each merge half of the arena into the same output buffer
+    out = torch.full((P,), float("nan"), device=DEV)
+    half = (P // 2) // 64 * 64
+    ops.merge_nway(base.to(DEV), tv.to(DEV), alpha.to(DEV), seg_off.to(DEV), out=out, p_begin=0, p_count=half)
+    ops.merge_nway(base.to(DEV), tv.to(DEV), alpha.to(DEV), seg_off.to(DEV), out=out, p_begin=half, p_count=P - half)
+    assert torch.equal(out.cpu(), want)
+
+
+def test_task_vector_bitexact(ops):
+    g = _g(3)
+    a, b = torch.randn(64 * 77 + 3, generator=g), torch.randn(64 * 77 + 3, generator=g)
+    assert torch.equal(ops.task_vector(a.to(DEV), b.to(DEV)).cpu(), a - b)
+
+
+def test_merge_bwd_alpha(ops):
+    g = _g(5)
+    seg_len = [64 * 300, 64 * 7, 64 * 1000]
+    seg_off = torch.tensor([0] + list(torch.tensor(seg_len).cumsum(0)), dtype=torch.int64)
+    P, N = int(seg_off[-1]), 4
+    tv, gr = torch.randn(N, P, generator=g), torch.randn(P, generator=g)
+    got = ops.merge_bwd_alpha(tv.to(DEV), gr.to(DEV), seg_off.to(DEV)).cpu()
+    got2 = ops.merge_bwd_alpha(tv.to(DEV), gr.to(DEV), seg_off.to(DEV)).cpu()
+    assert torch.equal(got, got2), "two-stage reduction must be bitwise reproducible"
+    for s in range(3):
+        a, b = int(seg_off[s]), int(seg_off[s + 1])
+        want = O.merge_bwd_alpha(tv[:, a:b], gr[a:b])
+        assert torch.allclose(got[s], want, rtol=1e-4, atol=1e-2 * math.sqrt((b - a) / 1e6)), (got[s], want)
+    one = ops.merge_bwd_alpha(tv.to(DEV), gr.to(DEV)).cpu()
+    assert torch.allclose(one[0], O.merge_bwd_alpha(tv, gr), rtol=1e-4, atol=2e-2)
+
+
+# ------------------------------------------------------------------ K3 GEMM (bit-exact vs k-ordered fmaf chain)
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (130, 768, 768), (257, 200, 3072), (64, 333, 16)])
+def test_gemm_bitexact_vs_fma_chain(ops, M, N, K):
+    g = _g(M + N + K)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    got = ops.gemm_nt(A.to(DEV), [W.to(DEV)], [b.to(DEV)]).cpu()
+    want = CO.gemm_nt(A, W, b)
+    assert torch.equal(got, want), (got - want).abs().max()
+    assert torch.allclose(got, A @ W.T + b, atol=1e-4, rtol=1e-5)  # the reference's own arithmetic (torch GEMM)
+
+
+def test_gemm_segments_gelu_residual(ops):
+    g = _g(11)
+    M, K, n = 200, 128, 128
+    A = torch.randn(M, K, generator=g)
+    Ws = [torch.randn(n, K, generator=g) * 0.1 for _ in range(3)]
+    bs = [torch.randn(n, generator=g) for _ in range(3)]
+    got = ops.gemm_nt(A.to(DEV), [w.to(DEV) for w in Ws], [b.to(DEV) for b in bs]).cpu()
+    want = torch.cat([CO.gemm_nt(A, w, b) for w, b in zip(Ws, bs)], dim=1)
+    assert torch.equal(got, want)
+    R = torch.randn(M, n, generator=g)
+    got = ops.gemm_nt(A.to(DEV), [Ws[0].to(DEV)], [bs[0].to(DEV)], act=ops.ACT_GELU, residual=R.to(DEV)).cpu()
+    want = torch.nn.functional.gelu(CO.gemm_nt(A, Ws[0], bs[0])) + R
+    assert torch.allclose(got, want, atol=2e-6, rtol=1e-6)
+
+
+# ------------------------------------------------------------------ K2 / LN / pooling
+def _ragged_batch(B, L, vocab, g, pad=1):
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0] = L
+    ids = torch.randint(3, vocab, (B, L), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    ids[:, 0] = 0
+    ids = torch.where(mask.bool(), ids, torch.full_like(ids, pad))
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = lens.cumsum(0)
+    return ids, mask, lens, cu
+
+
+def test_pack_and_embed_roberta(ops):
+    g = _g(21)
+    cfg = O.EncoderConfig(hidden=768, vocab=500, max_pos=140, layers=0)
+    sd = O.random_state_dict(O.roberta_param_shapes(cfg, pooler=False), seed=5)
+    ids, mask, lens, cu = _ragged_batch(9, 130, cfg.vocab, g)
+    ids[3, 2] = cfg.pad_id  # a pad id inside a sequence: position ids must follow the cumsum rule
+    T = int(cu[-1])
+    tw, tp, _, _ = ops.pack_tokens(ids.to(DEV), mask.to(DEV), cu.to(DEV), T, cfg.pad_id)
+    want_pos = O.position_ids_from_input_ids(ids, cfg.pad_id)[mask.bool()]
+    assert torch.equal(tw.cpu().long(), ids[mask.bool()])
+    assert torch.equal(tp.cpu().long(), want_pos)
+    d = {k: v.to(DEV) for k, v in sd.items()}
+    e = "model.embeddings."
+    got = ops.embed_gather_ln(tw, tp, None, None, d[e + "word_embeddings.weight"], d[e + "position_embeddings.weight"],
+                              d[e + "token_type_embeddings.weight"], None, d[e + "LayerNorm.weight"], d[e + "LayerNorm.bias"],
+                              cfg.ln_eps, ops.EMBED_ROBERTA).cpu()
+    want = O.roberta_embeddings(sd, ids, cfg, "model.")[mask.bool()]
+    assert torch.allclose(got, want, atol=2e-6, rtol=1e-6), (got - want).abs().max()
+
+
+def test_pack_and_embed_recformer(ops):
+    g = _g(22)
+    cfg = O.EncoderConfig(hidden=64, vocab=300, max_pos=200, layers=0, token_type_size=4, max_item_embeddings=51)
+    sd = O.random_state_dict(O.recformer_param_shapes(cfg), seed=6, std=0.2)
+    ids, mask, lens, cu = _ragged_batch(6, 77, cfg.vocab, g)
+    tt = torch.randint(0, 4, ids.shape, generator=g)
+    ip = torch.randint(0, 51, ids.shape, generator=g)
+    T = int(cu[-1])
+    tw, tp, ttp, tip = ops.pack_tokens(ids.to(DEV), mask.to(DEV), cu.to(DEV), T, cfg.pad_id, tt.to(DEV), ip.to(DEV))
+    d = {k: v.to(DEV) for k, v in sd.items() if v.is_floating_point()}
+    e = "model.embeddings."
+    got = ops.embed_gather_ln(tw, tp, ttp, tip, d[e + "word_embeddings.weight"], d[e + "position_embeddings.weight"],
+                              d[e + "token_type_embeddings.weight"], d[e + "item_position_embeddings.weight"],
+                              d[e + "LayerNorm.weight"], d[e + "LayerNorm.bias"], cfg.ln_eps, ops.EMBED_RECFORMER).cpu()
+    want = O.recformer_embeddings(sd, ids, tt, ip, cfg, "model.")[mask.bool()]
+    assert torch.allclose(got, want, atol=5e-6, rtol=1e-6), (got - want).abs().max()
+
+
+@pytest.mark.parametrize("d", [64, 768, 1024])
+def test_layernorm_and_cls_pool(ops, d):
+    g = _g(d)
+    T = 301
+    x, w, b = torch.randn(T, d, generator=g) * 3 + 1, torch.randn(d, generator=g), torch.randn(d, generator=g)
+    got = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5).cpu()
+    assert torch.allclose(got, torch.nn.functional.layer_norm(x, (d,), w, b, 1e-5), atol=5e-6, rtol=1e-6)
+    cu = torch.tensor([0, 5, 6, 100, 301], dtype=torch.int32)
+    got = ops.cls_pool_normalize(x.to(DEV), cu.to(DEV), 4, True).cpu()
+    assert torch.allclose(got, O.maybe_normalize(x[cu[:-1].long()]), atol=1e-6)
+    got = ops.cls_pool_normalize(x.to(DEV), cu.to(DEV), 4, False).cpu()
+    assert torch.equal(got, x[cu[:-1].long()])
+    idx = torch.tensor([300, 0, 17], dtype=torch.int32)
+    assert torch.equal(ops.gather_rows(x.to(DEV), idx.to(DEV)).cpu(), x[idx.long()])
+
+
+# ------------------------------------------------------------------ K4 attention
+def _attn_ref(qkv, cu, H, window=-1):
+    T, d3 = qkv.shape
+    d = d3 // 3
+    dh = d // H
+    out = torch.zeros(T, d)
+    for b in range(len(cu) - 1):
+        a, e = int(cu[b]), int(cu[b + 1])
+        L = e - a
+        q, k, v = (qkv[a:e, i * d:(i + 1) * d].view(L, H, dh).transpose(0, 1) for i in range(3))
+        s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+        if window >= 0:
+            i = torch.arange(L)
+            ok = ((i[:, None] - i[None, :]).abs() <= window) | (i[None, :] == 0)
+            s = s.masked_fill(~ok[None], float("-inf"))
+        out[a:e] = (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(L, d)
+    return out
+
+
+@pytest.mark.parametrize("H,lens", [(12, [512, 1, 33, 40, 257]), (4, [5, 64, 31, 32, 96])])
+def test_attention_full(ops, H, lens):
+    g = _g(H)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    T = int(cu[-1])
+    qkv = torch.randn(T, 3 * H * 64, generator=g)
+    got = ops.attention(qkv.to(DEV), cu.to(DEV), len(lens), H, max(lens)).cpu()
+    want = _attn_ref(qkv, cu, H)
+    assert torch.allclose(got, want, atol=3e-6, rtol=1e-5), (got - want).abs().max()
+
+
+@pytest.mark.parametrize("window", [4, 32])
+def test_attention_band_global(ops, window):
+    g = _g(window)
+    H, lens = 4, [300, 1, 2, 70, 33, 129]
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    T = int(cu[-1])
+    qkv = torch.randn(T, 3 * H * 64, generator=g)
+    sentinel = 1234.5
+    ctx = torch.full((T, H * 64), sentinel, device=DEV)
+    ops.attention(qkv.to(DEV), cu.to(DEV), len(lens), H, max(lens), window=window, out=ctx)
+    got = ctx.cpu()
+    want = _attn_ref(qkv, cu, H, window)
+    first = torch.zeros(T, dtype=torch.bool)
+    first[cu[:-1].long()] = True
+    assert torch.allclose(got[~first], want[~first], atol=3e-6, rtol=1e-5), (got[~first] - want[~first]).abs().max()
+    assert bool((got[first] == sentinel).all()), "row 0 of each sequence belongs to the global-row kernel"
+    # global row
+    qg = torch.randn(len(lens), H * 64, generator=g)
+    kvg = torch.randn(T, 2 * H * 64, generator=g)
+    ops.attention_global_row(qg.to(DEV), kvg.to(DEV), cu.to(DEV), len(lens), H, max(lens), ctx)
+    got = ctx.cpu()
+    for b in range(len(lens)):
+        a, e = int(cu[b]), int(cu[b + 1])
+        q = qg[b].view(H, 1, 64)
+        k = kvg[a:e, : H * 64].view(-1, H, 64).transpose(0, 1)
+        v = kvg[a:e, H * 64:].view(-1, H, 64).transpose(0, 1)
+        w = (torch.softmax((q @ k.transpose(-1, -2)) * 0.125, -1) @ v).reshape(-1)
+        assert torch.allclose(got[a], w, atol=3e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ K5 scoring + top-k
+def test_topk_rows_canonical_with_ties(ops):
+    g = _g(31)
+    R, C, k = 70, 4968, 50
+    s = torch.randn(R, C, generator=g)
+    s[0, torch.randperm(C, generator=g)[:200]] = float(s[0].max()) + 1.0   # > k equal maxima
+    s[1, :] = 0.25                                                          # constant row
+    s[2, 5] = float("nan"); s[2, 4000] = float("nan")
+    s[3, 100:130] = float(s[3].topk(50).values[-1])                         # ties straddling the k-th value
+    s[4, 7] = float("inf"); s[4, 9] = float("-inf")
+    s[5, 10] = 0.0; s[5, 11] = -0.0; s[5, 12:] = -1.0; s[5, :10] = -2.0    # +0 == -0 tie by index
+    labels = torch.randint(0, C, (R,), generator=g)
+    labels[0] = int(torch.nonzero(s[0] == s[0].max())[3])
+    val, idx, lse, lab, rank = ops.topk_rows(s.to(DEV), k, labels.to(DEV), 20.0)
+    wv, wi = CO.topk_rows(s, k)
+    assert torch.equal(idx.cpu(), wi)
+    assert torch.equal(val.cpu().nan_to_num(7.0), wv.nan_to_num(7.0))
+    ov, oi = O.topk_canonical(s, k)
+    assert torch.equal(wi, oi)
+    want_rank = torch.tensor([(wi[r] == labels[r]).nonzero()[0, 0].item() if (wi[r] == labels[r]).any() else -1 for r in range(R)], dtype=torch.int32)
+    assert torch.equal(rank.cpu(), want_rank)
+    ok = ~torch.isnan(s).any(1) & ~torch.isinf(s).any(1)
+    want_lse = torch.logsumexp(s * 20.0, dim=1)
+    assert torch.allclose(lse.cpu()[ok], want_lse[ok], atol=1e-4, rtol=1e-5)
+    assert torch.allclose(lab.cpu()[ok], (s[torch.arange(R), labels] * 20.0)[ok], atol=1e-6)
+
+
+@pytest.mark.parametrize("nU,M", [(33, 4968), (128, 18357), (5, 50)])
+def test_score_topk_full_catalog(ops, nU, M):
+    g = _g(M)
+    d, k = 768, 50
+    U = O.maybe_normalize(torch.randn(nU, d, generator=g))
+    E = O.maybe_normalize(torch.randn(M, d, generator=g))
+    E[M // 2] = E[3]  # duplicated catalog text -> identical embedding -> exact score tie
+    labels = torch.randint(0, M, (nU,), generator=g)
+    val, idx, lse, lab, rank, scores = ops.score_topk(U.to(DEV), E.to(DEV), k, labels.to(DEV), 20.0, return_scores=True)
+    ref = O.score(U, E)                       # the reference's arithmetic: torch GEMM
+    assert torch.allclose(scores.cpu(), ref, atol=1e-4, rtol=0), (scores.cpu() - ref).abs().max()   # north_star: logits within 1e-4
+    chain = CO.gemm_nt(U, E)                  # same k-ordered fp32 FMA chain the MFMA path computes
+    assert torch.equal(scores.cpu(), chain)
+    wv, wi = CO.topk_rows(chain, k)
+    assert torch.equal(idx.cpu(), wi), "ranked item indices must be bit-exact"
+    assert torch.equal(val.cpu(), wv)
+    _, oi = O.topk_canonical(ref, k)
+    assert O.ranks_equal_up_to_ties(ref, idx.cpu(), oi, atol=2e-6)
+    loss = float((lse - lab).mean())
+    assert abs(loss - O.ce_loss(ref, labels, 0.05)) < 1e-3
