@@ -110,7 +110,7 @@ int mr_embed_gather_ln_f32(const int32_t* tok_word, const int32_t* tok_pos, cons
  * (seg_n, K) row-major contiguous (torch nn.Linear layout), bias_s may be NULL.  The k-sum of each
  * output element is ONE fp32 fused-multiply-add chain in ascending k starting from 0 (exactly what
  * v_mfma_f32_32x32x2_f32 computes), so results are bit-identical to oracle/oracle_c.c gemm_nt_ref.
- * K % 16 == 0; lda, ldc, ldr % 4 == 0; nseg > 1 requires seg_n % 128 == 0.
+ * K % 16 == 0; lda % 4 == 0 (ldc, ldr unrestricted); nseg > 1 requires seg_n % 128 == 0.
  * replaces: torch.nn.functional.linear inside transformers RobertaSelfAttention / RobertaSelfOutput /
  *           RobertaIntermediate / RobertaOutput and the Longformer equivalents (reached from
  *           module/models/encoder/_base.py:37 and recformer/models.py:340-348); with bias == NULL it is

@@ -156,7 +156,7 @@ extern "C" int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float*
     if (K % BK) return MR_EUNSUPPORTED;
     if (nseg > 1 && (seg_n % BN)) return MR_EUNSUPPORTED;
     if (act != MR_ACT_NONE && act != MR_ACT_GELU_ERF) return MR_EUNSUPPORTED;
-    if ((lda & 3) || (ldc & 3) || (R && (ldr & 3))) return MR_EALIGN;
+    if (lda & 3) return MR_EALIGN;  // A and W rows are read as float4; C and R are accessed per element
     if (!mr::aligned16(A) || !mr::aligned16(w0) || (w1 && !mr::aligned16(w1)) || (w2 && !mr::aligned16(w2)))
         return MR_EALIGN;
     if (M == 0) return MR_OK;

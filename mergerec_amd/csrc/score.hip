@@ -195,8 +195,6 @@ extern "C" int mr_score_topk_f32(const float* U, const float* E, int64_t nU, int
         if (ws_bytes < mr_score_topk_ws_bytes(nU, M)) return MR_EWS;
         sc = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
         ldm = (M + 3) & ~(int64_t)3;
-    } else if (M & 3) {
-        return MR_EALIGN;  // a caller-provided (nU, M) block needs M % 4 == 0 for the GEMM's ldc rule
     }
     if (nU == 0) return MR_OK;
     int rc = mr_gemm_nt_bias_act_f32(U, d, E, nullptr, nullptr, nullptr, nullptr, nullptr, 1, (int)nU, (int)M, d,

@@ -1,0 +1,323 @@
+"""Device-side engine for the merged-model inference path: the parameter arena and the encoder runner.
+
+Data layout in HBM
+  * ParamArena: ONE flat fp32 buffer per model holding every tensor of the reference's state_dict in
+    the reference's key order (merger/weight_learning/module/_factory.py:55-66), each tensor starting
+    on a 64-float (256 B) boundary so every weight/bias/table row is 16-byte aligned for the kernels
+    (Recformer's 4098-element ``position_ids`` buffer would otherwise shift everything by 8 bytes).
+    Base model, the N task vectors ((N, P_pad) row-major) and the merged model share the layout, so
+    the merge is one streaming pass and the encoder reads the merged weights in place (no
+    ``load_state_dict`` copy as in merge_test.py:80).
+  * Activations: packed tokens, (T, d) fp32 row-major, T = number of non-masked tokens in the batch
+    (padding never reaches the GPU kernels), ``cu_seqlens`` int32 (B+1).
+
+The runner issues the HIP kernels of include/mergerec_hip.h on the current stream; it holds no
+compute of its own.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+ARENA_ALIGN = 64  # floats
+
+
+@dataclass
+class EncoderSpec:
+    """Architecture of one encoder family (dims of BLaIR = RoBERTa, Recformer = Longformer)."""
+
+    kind: str = "roberta"  # "roberta" | "recformer"
+    hidden: int = 768
+    heads: int = 12
+    layers: int = 12
+    intermediate: int = 3072
+    vocab: int = 50265
+    max_pos: int = 514
+    pad_id: int = 1
+    ln_eps: float = 1e-5
+    token_type_size: int = 1
+    max_item_embeddings: int = 0
+    one_sided_window: int = -1  # recformer: attention_window 64 -> 32 (interface.py:23)
+    pooler: bool = True  # RobertaModel carries an (unused) pooler
+
+    @staticmethod
+    def blair_base():
+        return EncoderSpec()
+
+    @staticmethod
+    def blair_large():
+        return EncoderSpec(hidden=1024, heads=16, layers=24, intermediate=4096)
+
+    @staticmethod
+    def recformer_base():
+        return EncoderSpec(kind="recformer", max_pos=4098, token_type_size=4, max_item_embeddings=51, one_sided_window=32, pooler=False)
+
+    @staticmethod
+    def recformer_large():
+        return EncoderSpec(kind="recformer", hidden=1024, heads=16, layers=24, intermediate=4096, max_pos=4098,
+                           token_type_size=4, max_item_embeddings=51, one_sided_window=32, pooler=False)
+
+    def param_shapes(self, prefix: str = "model.") -> "OrderedDict[str, Tuple[int, ...]]":
+        """state_dict key order of the reference wrapper (transformers 4.51.3 module order)."""
+        d, i = self.hidden, self.intermediate
+        sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+        e = prefix + "embeddings."
+        if self.kind == "recformer":
+            sh[e + "position_ids"] = (1, self.max_pos)  # persistent int64 buffer (recformer/models.py:96)
+        sh[e + "word_embeddings.weight"] = (self.vocab, d)
+        sh[e + "position_embeddings.weight"] = (self.max_pos, d)
+        sh[e + "token_type_embeddings.weight"] = (self.token_type_size, d)
+        if self.kind == "recformer":
+            sh[e + "item_position_embeddings.weight"] = (self.max_item_embeddings, d)
+        sh[e + "LayerNorm.weight"] = (d,)
+        sh[e + "LayerNorm.bias"] = (d,)
+        projs = ("query", "key", "value") + (("query_global", "key_global", "value_global") if self.kind == "recformer" else ())
+        for l in range(self.layers):
+            lp = f"{prefix}encoder.layer.{l}."
+            for n in projs:
+                sh[lp + f"attention.self.{n}.weight"] = (d, d)
+                sh[lp + f"attention.self.{n}.bias"] = (d,)
+            sh[lp + "attention.output.dense.weight"] = (d, d)
+            sh[lp + "attention.output.dense.bias"] = (d,)
+            sh[lp + "attention.output.LayerNorm.weight"] = (d,)
+            sh[lp + "attention.output.LayerNorm.bias"] = (d,)
+            sh[lp + "intermediate.dense.weight"] = (i, d)
+            sh[lp + "intermediate.dense.bias"] = (i,)
+            sh[lp + "output.dense.weight"] = (d, i)
+            sh[lp + "output.dense.bias"] = (d,)
+            sh[lp + "output.LayerNorm.weight"] = (d,)
+            sh[lp + "output.LayerNorm.bias"] = (d,)
+        if self.kind == "roberta" and self.pooler:
+            sh[prefix + "pooler.dense.weight"] = (d, d)
+            sh[prefix + "pooler.dense.bias"] = (d,)
+        return sh
+
+
+class ArenaLayout:
+    """name -> (offset, numel, shape) for one key order; offsets are multiples of 64 floats."""
+
+    def __init__(self, shapes: "OrderedDict[str, Sequence[int]]"):
+        self.shapes: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict((k, tuple(int(x) for x in v)) for k, v in shapes.items())
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for k, shp in self.shapes.items():
+            self.offsets[k] = off
+            n = math.prod(shp)
+            off += (n + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+        self.padded_numel = off
+        self.numel = sum(math.prod(s) for s in self.shapes.values())  # algorithmic P (reference's flat length)
+
+    def keys(self):
+        return list(self.shapes.keys())
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        o, shp = self.offsets[name], self.shapes[name]
+        return flat[o : o + math.prod(shp)].view(shp)
+
+    def views(self, flat: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
+        """a6: named views of a flat arena vector (merger/weight_learning/utils.py:29-40), zero-copy."""
+        return OrderedDict((k, self.view(flat, k)) for k in self.shapes)
+
+    def pack(self, state_dict: Dict[str, torch.Tensor], device, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """a2: flatten a state_dict into arena layout (model_operations.py:47-63 semantics: key order of
+        this layout, int buffers promoted to fp32).  Host packs into one pinned staging buffer, one H2D."""
+        missing = [k for k in self.shapes if k not in state_dict]
+        if missing:
+            raise KeyError(f"state_dict is missing keys: {missing[:3]}{'...' if len(missing) > 3 else ''}")
+        all_dev = all(state_dict[k].is_cuda for k in self.shapes)
+        if out is None:
+            out = torch.zeros(self.padded_numel, dtype=torch.float32, device=device)
+        if all_dev:
+            for k, shp in self.shapes.items():
+                v = state_dict[k]
+                if tuple(v.shape) != shp:
+                    raise ValueError(f"shape mismatch for {k}: {tuple(v.shape)} vs {shp}")
+                self.view(out, k).copy_(v)
+            return out
+        stage = torch.zeros(self.padded_numel, dtype=torch.float32)
+        for k, shp in self.shapes.items():
+            v = state_dict[k]
+            if tuple(v.shape) != shp:
+                raise ValueError(f"shape mismatch for {k}: {tuple(v.shape)} vs {shp}")
+            o = self.offsets[k]
+            stage[o : o + v.numel()].copy_(v.detach().reshape(-1))
+        out.copy_(stage, non_blocking=False)
+        return out
+
+    def compact(self, flat: torch.Tensor) -> torch.Tensor:
+        """The reference's contiguous (P,) flat vector (no pads), for API compatibility."""
+        return torch.cat([self.view(flat, k).reshape(-1) for k in self.shapes])
+
+    def group_segments(self) -> Tuple[List[str], torch.Tensor, List[int]]:
+        """a5: layer-wise groups (layer_wise.py:13-33: ``name.split('.')[3]`` if 'encoder.layer.' in name
+        else 'others'), as maximal runs of adjacent same-group tensors in arena coordinates.
+        Returns (group keys in first-seen order, seg_off int64 (S+1), group index per segment)."""
+        groups: List[str] = []
+        seg_start: List[int] = []
+        seg_gid: List[int] = []
+        for k in self.shapes:
+            key = k.split(".")[3] if "encoder.layer." in k else "others"
+            if key not in groups:
+                groups.append(key)
+            gid = groups.index(key)
+            if not seg_gid or seg_gid[-1] != gid:
+                seg_start.append(self.offsets[k])
+                seg_gid.append(gid)
+        seg_off = torch.tensor(seg_start + [self.padded_numel], dtype=torch.int64)
+        return groups, seg_off, seg_gid
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PackedBatch:
+    """A batch after host-side length analysis; everything the kernels need."""
+
+    B: int
+    T: int
+    max_len: int
+    cu_seqlens: torch.Tensor  # int32 (B+1) device
+    cls_rows: torch.Tensor  # int32 (B) device == cu_seqlens[:-1]
+    tok_word: torch.Tensor
+    tok_pos: torch.Tensor
+    tok_tt: Optional[torch.Tensor] = None
+    tok_ip: Optional[torch.Tensor] = None
+
+
+def _lens_from_mask(attention_mask: torch.Tensor) -> torch.Tensor:
+    # one small D2H sync when the mask lives on the GPU; free when the collator's CPU tensors are passed
+    return attention_mask.ne(0).sum(dim=1).to("cpu", torch.int64)
+
+
+class EncoderRunner:
+    """Runs the BLaIR (RoBERTa) or Recformer (Longformer) forward on packed tokens with HIP kernels.
+
+    ``weights`` is any mapping name -> device tensor (normally ArenaLayout.views(merged_flat))."""
+
+    def __init__(self, spec: EncoderSpec, prefix: str = "model."):
+        if spec.hidden % spec.heads or spec.hidden // spec.heads != 64:
+            raise ValueError("attention kernels are built for head_dim == 64 (BLaIR/Recformer base and large)")
+        self.spec = spec
+        self.prefix = prefix
+        self.fuse_qkv = spec.hidden % 128 == 0
+
+    # ---- batch preparation -----------------------------------------------------------------------
+    def pack(self, batch: Dict[str, torch.Tensor], device, lens: Optional[torch.Tensor] = None, validate: bool = True) -> PackedBatch:
+        ids, mask = batch["input_ids"], batch["attention_mask"]
+        if ids.dim() != 2 or ids.shape != mask.shape:
+            raise ValueError("input_ids / attention_mask must be (B, L) and equal-shaped")
+        B, L = ids.shape
+        if lens is None:
+            lens = _lens_from_mask(mask)
+        lens = lens.to(torch.int64).cpu()
+        if validate and B > 0:
+            if int(lens.min()) < 1:
+                raise ValueError("every sequence needs at least one attended token (CLS)")
+            if bool((mask[:, 0] == 0).any()):
+                raise ValueError("position 0 (CLS) must be attended: CLS pooling reads it (encoder/_base.py:45)")
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= self.spec.vocab:
+                raise ValueError(f"input_ids out of range [0, {self.spec.vocab}): [{lo}, {hi}]")
+            if L + self.spec.pad_id + 1 > self.spec.max_pos:
+                raise ValueError(f"sequence length {L} exceeds the position table ({self.spec.max_pos})")
+        cu = torch.zeros(B + 1, dtype=torch.int32)
+        if B:
+            cu[1:] = lens.cumsum(0).to(torch.int32)
+        T = int(cu[-1])
+        cu_d = cu.to(device, non_blocking=True)
+        tt = ip = None
+        if self.spec.kind == "recformer":
+            for key in ("token_type_ids", "item_position_ids", "global_attention_mask"):
+                if key not in batch:
+                    raise ValueError(f"Missing required key in batch: {key}")  # interface.py:71-74
+            tt, ip = batch["token_type_ids"], batch["item_position_ids"]
+            if validate and B > 0:
+                g = batch["global_attention_mask"]
+                if bool((g[:, 0] != 1).any()) or bool((g[:, 1:] != 0).any()):
+                    raise NotImplementedError("only the Recformer pattern (global attention on token 0 only) is built")
+                if int(tt.min()) < 0 or int(tt.max()) >= self.spec.token_type_size:
+                    raise ValueError("token_type_ids out of range")
+                if int(ip.min()) < 0 or int(ip.max()) >= self.spec.max_item_embeddings:
+                    raise ValueError("item_position_ids out of range")
+        dev = lambda t: None if t is None else t.to(device, torch.int64, non_blocking=True).contiguous()
+        tw, tp, ttp, tip = ops.pack_tokens(dev(ids), dev(mask), cu_d, T, self.spec.pad_id, dev(tt), dev(ip))
+        return PackedBatch(B=B, T=T, max_len=int(lens.max()) if B else 0, cu_seqlens=cu_d, cls_rows=cu_d[:-1].contiguous(),
+                           tok_word=tw, tok_pos=tp, tok_tt=ttp, tok_ip=tip)
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def embed(self, w: Dict[str, torch.Tensor], pb: PackedBatch) -> torch.Tensor:
+        e = self.prefix + "embeddings."
+        rec = self.spec.kind == "recformer"
+        return ops.embed_gather_ln(
+            pb.tok_word, pb.tok_pos, pb.tok_tt, pb.tok_ip, w[e + "word_embeddings.weight"], w[e + "position_embeddings.weight"],
+            w[e + "token_type_embeddings.weight"], w[e + "item_position_embeddings.weight"] if rec else None,
+            w[e + "LayerNorm.weight"], w[e + "LayerNorm.bias"], self.spec.ln_eps, ops.EMBED_RECFORMER if rec else ops.EMBED_ROBERTA)
+
+    def _proj(self, w, lp, names, x):
+        ws = [w[f"{lp}attention.self.{n}.weight"] for n in names]
+        bs = [w[f"{lp}attention.self.{n}.bias"] for n in names]
+        if self.fuse_qkv or len(names) == 1:
+            return ops.gemm_nt(x, ws, bs)
+        out = torch.empty(x.shape[0], len(names) * self.spec.hidden, dtype=torch.float32, device=x.device)
+        for i, (wi, bi) in enumerate(zip(ws, bs)):
+            ops.gemm_nt(x, [wi], [bi], out=out[:, i * self.spec.hidden : (i + 1) * self.spec.hidden])
+        return out
+
+    def layer(self, w: Dict[str, torch.Tensor], l: int, x: torch.Tensor, pb: PackedBatch, cls_only: bool = False) -> torch.Tensor:
+        """One post-LN transformer block.  cls_only: after attention keep only each sequence's first row
+        (a13: the last layer's output is read at [:, 0] only, encoder/_base.py:45)."""
+        sp, lp = self.spec, f"{self.prefix}encoder.layer.{l}."
+        qkv = self._proj(w, lp, ("query", "key", "value"), x)
+        ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=sp.one_sided_window if sp.kind == "recformer" else -1)
+        if sp.kind == "recformer":
+            x_cls = ops.gather_rows(x, pb.cls_rows)
+            qg = self._proj(w, lp, ("query_global",), x_cls)
+            kvg = self._proj(w, lp, ("key_global", "value_global"), x)
+            ops.attention_global_row(qg, kvg, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx)
+        if cls_only:
+            ctx = ops.gather_rows(ctx, pb.cls_rows)
+            x = ops.gather_rows(x, pb.cls_rows)
+        h = ops.gemm_nt(ctx, [w[lp + "attention.output.dense.weight"]], [w[lp + "attention.output.dense.bias"]], residual=x)
+        h = ops.layernorm(h, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps, out=h)
+        i = ops.gemm_nt(h, [w[lp + "intermediate.dense.weight"]], [w[lp + "intermediate.dense.bias"]], act=ops.ACT_GELU)
+        o = ops.gemm_nt(i, [w[lp + "output.dense.weight"]], [w[lp + "output.dense.bias"]], residual=h)
+        return ops.layernorm(o, w[lp + "output.LayerNorm.weight"], w[lp + "output.LayerNorm.bias"], sp.ln_eps, out=o)
+
+    def forward_packed(self, w: Dict[str, torch.Tensor], pb: PackedBatch, normalize: bool, return_hidden: bool = False):
+        """-> (B, d) CLS embeddings (L2-normalised if ``normalize``); optionally every layer's packed hidden."""
+        d = self.spec.hidden
+        if pb.B == 0:
+            empty = torch.empty(0, d, dtype=torch.float32, device=pb.cu_seqlens.device)
+            return (empty, []) if return_hidden else empty
+        x = self.embed(w, pb)
+        hidden = [x] if return_hidden else None
+        L = self.spec.layers
+        for l in range(L):
+            last = l == L - 1
+            x = self.layer(w, l, x, pb, cls_only=last and not return_hidden)
+            if return_hidden:
+                hidden.append(x)
+        if return_hidden or L == 0:
+            out = ops.cls_pool_normalize(x, pb.cu_seqlens, pb.B, normalize)
+            return (out, hidden) if return_hidden else out
+        # x already holds one row per sequence
+        ident = torch.arange(pb.B + 1, dtype=torch.int32, device=x.device)
+        return ops.cls_pool_normalize(x, ident, pb.B, normalize)
+
+    def encode(self, w: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], device, normalize: bool, lens=None, validate: bool = True):
+        return self.forward_packed(w, self.pack(batch, device, lens=lens, validate=validate), normalize)
+
+
+# ------------------------------------------------------------------------------------------------
+def flops_per_sequence(spec: EncoderSpec, L: int, cls_only_last: bool = True) -> float:
+    """Algorithmic FLOPs of one encoder forward: layers * (24 L d^2 + 4 L^2 d) for RoBERTa."""
+    d = spec.hidden
+    per_layer = 24 * L * d * d + 4 * L * L * d
+    if spec.kind == "recformer":
+        per_layer = 28 * L * d * d + 4 * L * 66 * d + 4 * L * d
+    return float(spec.layers * per_layer)

@@ -1,0 +1,223 @@
+"""Host-side mirror of rec_retrieval/merger/weight_learning (the learnable-alpha merge module).
+
+Same names, arguments and error behaviour as the reference; the arithmetic runs in the HIP kernels
+mr_task_vector_f32 / mr_merge_nway_f32 on device-resident arena buffers (mergerec_amd/engine.py).
+
+  load_merging_module            <- weight_learning/module/_factory.py:27-127
+  TaskVectorMergingModuleBase    <- weight_learning/module/_base.py:10-89
+  TaskVectorMergingModuleTaskWise  <- weight_learning/module/task_wise.py:12-62
+  TaskVectorMergingModuleLayerWise <- weight_learning/module/layer_wise.py:37-95
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..engine import ArenaLayout
+from .enums import LearnType, MergeType
+
+StateDict = Dict[str, torch.Tensor]
+
+
+def _check_isinstance_state_dict(t):
+    """_factory.py:17-25."""
+    if not isinstance(t, dict):
+        raise ValueError(f"Expected a state dict, got {type(t)}")
+    for k, v in t.items():
+        if not isinstance(k, str):
+            raise ValueError(f"Expected a string key, got {type(k)}")
+        if not isinstance(v, torch.Tensor):
+            raise ValueError(f"Expected a tensor value, got {type(v)}")
+
+
+class TaskVectorMergingModuleBase(nn.Module):
+    """_base.py:10-89.  ``base_model_tensor`` / ``task_vectors_tensor`` are device buffers in ARENA layout
+    ((P_pad,) / (N, P_pad): each tensor 64-float aligned, pads zero); ``compact_*`` give the reference's
+    contiguous (P,) / (N, P) forms."""
+
+    def __init__(self, base_model_tensor, task_vectors_tensor, model_without_params, layout: ArenaLayout, disable_softmax: bool = False):
+        super().__init__()
+        self.model = model_without_params
+        self.layout = layout
+        self.shape_dict = OrderedDict((k, torch.Size(s)) for k, s in layout.shapes.items())
+        self.disable_softmax = disable_softmax
+        self.base_model_tensor = nn.Parameter(base_model_tensor, requires_grad=False)
+        self.task_vectors_tensor = nn.Parameter(task_vectors_tensor, requires_grad=False)
+        self.global_weights = nn.ParameterDict()
+        self.global_biases = nn.ParameterDict()
+        self.per_weights = nn.ParameterDict()
+        # the parameter arena the (param-less) model reads: merged weights are written here in place (a6)
+        self._merged = torch.zeros_like(base_model_tensor)
+        self._seg_off: Optional[torch.Tensor] = None  # device int64 (S+1) or None for one segment
+        self._seg_gid: List[int] = [0]
+        self._groups: List[str] = ["all"]
+        if hasattr(self.model, "bind_arena"):
+            self.model.bind_arena(layout, self._merged)
+
+    # -- reference API ---------------------------------------------------------------------------
+    def trainable_parameters(self, freeze_global_weight=False, freeze_global_bias=False, freeze_per_weight=False):
+        params = []
+        if not freeze_global_weight:
+            params.extend(self.global_weights.parameters())
+        if not freeze_global_bias:
+            params.extend(self.global_biases.parameters())
+        if not freeze_per_weight:
+            params.extend(self.per_weights.parameters())
+        return params
+
+    def serialize_weights(self):
+        return {
+            "global_weights": {k: v.tolist() for k, v in self.global_weights.items()},
+            "global_biases": {k: v.tolist() for k, v in self.global_biases.items()},
+            "per_weights": {k: v.tolist() for k, v in self.per_weights.items()},
+        }
+
+    @torch.no_grad()
+    def load_weights_from_dict(self, weights: Dict[str, Dict[str, List[float]]]):
+        dev = self.base_model_tensor.device
+        for name, table, truncate in (("global_weights", self.global_weights, False), ("global_biases", self.global_biases, False),
+                                      ("per_weights", self.per_weights, True)):
+            for k, v in weights[name].items():
+                assert k in table, f"Key '{k}' not found in {name}."
+                v = torch.tensor(v)
+                if truncate:
+                    v = v[: table[k].numel()]  # _base.py:72
+                assert v.shape == table[k].shape, f"Shape mismatch for key '{k}', ({v.shape} != {table[k].shape})"
+                table[k].data = v.to(dev)
+
+    def forward(self, batch):
+        self.load_weights()
+        return self.model(batch)
+
+    # -- merge -----------------------------------------------------------------------------------
+    def effective_alpha(self) -> torch.Tensor:
+        """(S, N) device table: alpha = gw * (softmax?)(per) + gb per group (task_wise.py:37-42,
+        layer_wise.py:67-73), expanded to the arena's segments.  Two tiny torch ops (mul, add), each
+        rounded separately like the reference."""
+        rows = {}
+        for key in self._groups:
+            per = self.per_weights[key]
+            if not self.disable_softmax:
+                per = torch.softmax(per, dim=0)
+            rows[key] = self.global_weights[key] * per + self.global_biases[key]
+        return torch.stack([rows[self._groups[g]] for g in self._seg_gid]).contiguous()
+
+    @torch.no_grad()
+    def _merge_task_vectors(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = self._merged if out is None else out
+        return ops.merge_nway(self.base_model_tensor.data, self.task_vectors_tensor.data, self.effective_alpha().detach(),
+                              self._seg_off, out=out)
+
+    def load_weights(self):
+        self._merge_task_vectors()
+        return self.model
+
+    def get_state_dict(self) -> StateDict:
+        """Named views of a freshly merged flat vector (utils.py:29-40); independent of later merges."""
+        merged = self._merge_task_vectors(out=torch.empty_like(self._merged))
+        return self.layout.views(merged)
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def compact_base(self) -> torch.Tensor:
+        return self.layout.compact(self.base_model_tensor.data)
+
+    def compact_task_vectors(self) -> torch.Tensor:
+        return torch.stack([self.layout.compact(t) for t in self.task_vectors_tensor.data])
+
+
+class TaskVectorMergingModuleTaskWise(TaskVectorMergingModuleBase):
+    def __init__(self, base_model_tensor, task_vectors_tensor, model_without_params, layout, initial_global_weight=1.0,
+                 initial_global_bias=0.0, initial_per_weight=0.2, disable_softmax=True):
+        super().__init__(base_model_tensor, task_vectors_tensor, model_without_params, layout, disable_softmax)
+        dev = base_model_tensor.device
+        n = task_vectors_tensor.size(0)
+        self.global_weights["all"] = nn.Parameter(torch.full((1,), float(initial_global_weight), device=dev))
+        self.global_biases["all"] = nn.Parameter(torch.full((1,), float(initial_global_bias), device=dev))
+        self.per_weights["all"] = nn.Parameter(torch.full((n,), float(initial_per_weight), device=dev))
+
+
+class TaskVectorMergingModuleLayerWise(TaskVectorMergingModuleBase):
+    def __init__(self, base_model_tensor, task_vectors_tensor, model_without_params, layout, initial_global_weight=1.0,
+                 initial_global_bias=0.0, initial_per_weight=0.2, disable_softmax=False):
+        super().__init__(base_model_tensor, task_vectors_tensor, model_without_params, layout, disable_softmax)
+        dev = base_model_tensor.device
+        n = task_vectors_tensor.size(0)
+        groups, seg_off, seg_gid = layout.group_segments()
+        self._groups, self._seg_gid = groups, seg_gid
+        self._seg_off = seg_off.to(dev) if len(seg_gid) > 1 else None
+        self.layer_groups = groups
+        for key in groups:
+            self.global_weights[key] = nn.Parameter(torch.full((1,), float(initial_global_weight), device=dev))
+            self.global_biases[key] = nn.Parameter(torch.full((1,), float(initial_global_bias), device=dev))
+            self.per_weights[key] = nn.Parameter(torch.full((n,), float(initial_per_weight), device=dev))
+
+
+def load_merging_module(
+    merge_type: MergeType,
+    learn_type: LearnType,
+    model: torch.nn.Module,
+    pretrain_state_dict: StateDict,
+    finetune_state_dicts: List[StateDict],
+    ignore_keys: set,
+    ties_density: Optional[float] = None,
+    initial_global_weight: float = 1.0,
+    initial_global_bias: float = 0.0,
+    initial_per_weight: float = 0.2,
+    disable_softmax: bool = False,
+    device: Optional[torch.device] = None,
+) -> TaskVectorMergingModuleBase:
+    """_factory.py:27-127.  Key order = the pretrained dict's insertion order restricted to keys also in
+    ``finetune_state_dicts[0]``.  Like the reference (make_functional, :70) this takes the passed model
+    over: afterwards the model computes with the merged arena owned by the returned module."""
+    assert isinstance(merge_type, MergeType), f"Invalid merge type: {merge_type}"
+    assert isinstance(learn_type, LearnType), f"Invalid learn type: {learn_type}"
+    _check_isinstance_state_dict(pretrain_state_dict)
+    for ckpt in finetune_state_dicts:
+        _check_isinstance_state_dict(ckpt)
+
+    keys_to_keep = set(pretrain_state_dict.keys() & finetune_state_dicts[0].keys()) - set(ignore_keys)
+    pre = OrderedDict((k, v) for k, v in pretrain_state_dict.items() if k in keys_to_keep)
+    for ckpt in finetune_state_dicts:  # check_model_shape (model_operations.py:15-44)
+        kept = {k for k in ckpt if k in keys_to_keep}
+        assert kept == set(pre.keys()), "Models have different architectures."
+        for k in pre:
+            assert ckpt[k].shape == pre[k].shape, "Models have different shapes."
+
+    if device is None:
+        device = getattr(model, "device", None) or torch.device("cuda", torch.cuda.current_device())
+    layout = ArenaLayout(OrderedDict((k, tuple(v.shape)) for k, v in pre.items()))
+
+    print("Converting model to functional form...")
+    print("Calculating task vectors...")
+    base = layout.pack(pre, device)
+    n = len(finetune_state_dicts)
+    tv = torch.empty(n, layout.padded_numel, dtype=torch.float32, device=device)
+    if merge_type is MergeType.TASK_VECTOR:
+        stage = torch.empty(layout.padded_numel, dtype=torch.float32, device=device)
+        for i, ckpt in enumerate(finetune_state_dicts):
+            layout.pack(ckpt, device, out=stage)
+            ops.task_vector(stage, base, out=tv[i])  # algorithms/task_vector.py:8-10
+        del stage
+    elif merge_type in (MergeType.TIES, MergeType.PCB, MergeType.LOCALIZE_AND_STITCH):
+        if merge_type is MergeType.TIES:
+            assert ties_density is not None, "Density should be provided for ties merging."
+        raise NotImplementedError(
+            f"{merge_type.name} task-vector pre-processing (one-shot, at init) is the next row of the hot-path scope "
+            "(SURVEY 8(f).1); only MergeType.TASK_VECTOR is built"
+        )
+    else:
+        raise ValueError(f"Invalid merge type: {merge_type}")
+
+    print("Creating merging module...")
+    if learn_type is LearnType.TASK_WISE:
+        cls = TaskVectorMergingModuleTaskWise
+    elif learn_type is LearnType.LAYER_WISE:
+        cls = TaskVectorMergingModuleLayerWise
+    else:
+        raise ValueError(f"Invalid learn type: {learn_type}")
+    return cls(base, tv, model, layout, initial_global_weight=initial_global_weight, initial_global_bias=initial_global_bias,
+               initial_per_weight=initial_per_weight, disable_softmax=disable_softmax)

@@ -1,0 +1,189 @@
+"""Mirror of rec_retrieval/module/models (enums.py:12-24, _base.py:16-70, encoder/_base.py:32-49,
+encoder/blair.py, encoder/recformer/interface.py): ``ModelType[NAME].value(...)`` builds a wrapper whose
+``forward(batch) -> (B, d)`` is the CLS-pooled encoder output and whose ``state_dict()`` keys are
+``'model.<hf-key>'``.  The arithmetic of transformers' RobertaModel / the reference's RecformerModel is
+re-implemented as HIP kernels (mergerec_amd/engine.py); weights live in one device arena.
+
+No network: pretrained weights come from a LOCAL file (``model_name_or_path`` = a torch-saved state_dict,
+with or without the 'model.' prefix) or are randomly initialised when ``model_kwargs['init_seed']`` is
+given (synthetic benchmarks).  Hub names fail loudly.
+"""
+from __future__ import annotations
+
+import math
+import os
+from collections import OrderedDict
+from enum import Enum
+from typing import Dict, Mapping, Optional
+
+import torch
+from torch import nn
+
+from ..engine import ArenaLayout, EncoderRunner, EncoderSpec
+
+
+def _resolve_device(model_kwargs) -> torch.device:
+    dev = model_kwargs.pop("device", None)
+    if dev is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("mergerec_amd models need an MI355X (no CPU fallback for the HIP path)")
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return torch.device(dev)
+
+
+class BaseEncoderModel(nn.Module):
+    SPEC = staticmethod(EncoderSpec.blair_base)
+    DEFAULT_MODEL_PATH: Optional[str] = None
+
+    def __init__(self, model_name_or_path=None, tokenizer_name_or_path=None, model_kwargs=None, tokenizer_kwargs=None,
+                 lora_config=None, pooling_method: str = "cls"):
+        super().__init__()
+        model_kwargs = dict(model_kwargs or {})
+        if lora_config is not None:
+            raise ValueError("LoRA wrappers are outside the merged-inference hot path (SURVEY section 2, row 4)")
+        if pooling_method != "cls":
+            raise NotImplementedError("only pooling_method='cls' is on the hot path (encoder/_base.py:44-45)")
+        if model_name_or_path is None and tokenizer_name_or_path is None:
+            model_name_or_path = tokenizer_name_or_path = self.DEFAULT_MODEL_PATH
+        self.model_name_or_path = model_name_or_path
+        self.pooling_method = pooling_method
+        spec = self.SPEC()
+        for k, v in dict(model_kwargs.pop("spec_overrides", {})).items():
+            setattr(spec, k, v)
+        self.spec = spec
+        self.device = _resolve_device(model_kwargs)
+        self.runner = EncoderRunner(spec, prefix="model.")
+        self.layout = ArenaLayout(spec.param_shapes("model."))
+        self._flat = torch.zeros(self.layout.padded_numel, dtype=torch.float32, device=self.device)
+        self._views: Dict[str, torch.Tensor] = self.layout.views(self._flat)
+        self.tokenizer = self._load_tokenizer(tokenizer_name_or_path, tokenizer_kwargs or {})
+        ckpt_path = model_kwargs.pop("ckpt_path", None)  # Recformer (interface.py:38-41)
+        init_seed = model_kwargs.pop("init_seed", None)
+        src = ckpt_path or model_name_or_path
+        if src is not None and os.path.isfile(str(src)):
+            sd = torch.load(str(src), map_location="cpu")
+            sd = {(k if k.startswith("model.") else "model." + k): v for k, v in sd.items()}
+            self.load_state_dict(sd, strict=ckpt_path is None)
+        elif init_seed is not None:
+            self.load_state_dict(random_init_state_dict(spec, int(init_seed)))
+        else:
+            raise FileNotFoundError(
+                f"pretrained weights '{src}' are not a local file and the container is offline; pass a local state_dict "
+                "path or model_kwargs={'init_seed': <int>} for synthetic weights"
+            )
+
+    @staticmethod
+    def _load_tokenizer(path, kwargs):
+        if path is not None and os.path.isdir(str(path)):
+            from transformers import AutoTokenizer  # only when a local tokenizer directory is supplied
+
+            return AutoTokenizer.from_pretrained(str(path), **kwargs)
+        return None
+
+    # -- parameter access (reference: nn.Module.state_dict / load_state_dict on the HF model) ------
+    def state_dict(self, *args, **kwargs) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((k, v.detach()) for k, v in self._views.items())
+
+    def load_state_dict(self, state_dict: Mapping[str, torch.Tensor], strict: bool = True):
+        sd = dict(state_dict)
+        unexpected = [k for k in sd if k not in self.layout.shapes]
+        missing = [k for k in self.layout.shapes if k not in sd]
+        if strict and (unexpected or missing):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:3]}, unexpected {unexpected[:3]}")
+        for k in self.layout.shapes:
+            if k in sd:
+                if tuple(sd[k].shape) != self.layout.shapes[k]:
+                    raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {self.layout.shapes[k]}")
+                self._views[k].copy_(sd[k].to(self._views[k].device, torch.float32))
+        return missing, unexpected
+
+    def bind_arena(self, layout: ArenaLayout, flat: torch.Tensor):
+        """Compute with an externally owned arena (the merging module's merged buffer) -- the build's
+        equivalent of make_functional + load_weights (weight_learning/utils.py:18-26,43-51)."""
+        need = [k for k in self.layout.shapes if k not in layout.shapes and not k.startswith("model.pooler") and not k.endswith("position_ids")]
+        if need:
+            raise KeyError(f"arena lacks tensors the encoder reads: {need[:3]}")
+        self._flat = flat
+        self._views = layout.views(flat)
+
+    # -- forward ---------------------------------------------------------------------------------
+    def forward(self, batch) -> torch.Tensor:
+        if not isinstance(batch, Mapping) and not hasattr(batch, "keys"):
+            raise TypeError("Input must be a BatchEncoding object.")  # encoder/_base.py:34-35
+        return self.runner.encode(self._views, batch, self.device, normalize=False)
+
+    def encode_normalized(self, batch, normalize: bool, lens=None, validate: bool = True) -> torch.Tensor:
+        """forward + F.normalize fused into the pooling kernel (module/recommender/module.py:74-77)."""
+        return self.runner.encode(self._views, batch, self.device, normalize=normalize, lens=lens, validate=validate)
+
+
+def random_init_state_dict(spec: EncoderSpec, seed: int, std: float = 0.02) -> "OrderedDict[str, torch.Tensor]":
+    """HF-style init for synthetic runs: N(0, std^2) matrices/biases, LayerNorm gamma ~ 1, position_ids = arange."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for k, shp in spec.param_shapes("model.").items():
+        if k.endswith("position_ids"):
+            sd[k] = torch.arange(shp[-1], dtype=torch.float32).expand(shp).clone()
+        elif "LayerNorm.weight" in k:
+            sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        else:
+            sd[k] = std * torch.randn(shp, generator=g)
+    return sd
+
+
+class BLaIR(BaseEncoderModel):
+    DEFAULT_MODEL_PATH = "hyp1231/blair-roberta-base"
+
+
+class BLaIRBase(BaseEncoderModel):
+    DEFAULT_MODEL_PATH = "hyp1231/blair-roberta-base"
+
+
+class BLaIRLarge(BaseEncoderModel):
+    SPEC = staticmethod(EncoderSpec.blair_large)
+    DEFAULT_MODEL_PATH = "hyp1231/blair-roberta-large"
+
+
+class BaseRecformerModel(BaseEncoderModel):
+    SPEC = staticmethod(EncoderSpec.recformer_base)
+
+    def __init__(self, model_name_or_path=None, tokenizer_name_or_path=None, model_kwargs=None, tokenizer_kwargs=None,
+                 lora_config=None, pooling_method: str = "cls"):
+        if lora_config is not None:
+            raise ValueError(f"LoRA is not supported for {self.__class__.__name__}. Please set lora_config.enable=False.")
+        if not isinstance(model_kwargs, dict) or ("ckpt_path" not in model_kwargs and "init_seed" not in model_kwargs):
+            raise ValueError(f"{self.__class__.__name__} requires a 'ckpt_path' in model_kwargs.")  # interface.py:38-39
+        super().__init__(model_name_or_path, tokenizer_name_or_path, model_kwargs, tokenizer_kwargs, None, pooling_method)
+
+    def forward(self, batch) -> torch.Tensor:
+        if not isinstance(batch, Mapping) and not hasattr(batch, "keys"):
+            raise TypeError("Input must be a BatchEncoding object.")
+        for key in ("input_ids", "attention_mask", "token_type_ids", "item_position_ids"):
+            if key not in batch:
+                raise ValueError(f"Missing required key in batch: {key}")
+        return super().forward(batch)
+
+
+class RecformerBase(BaseRecformerModel):
+    DEFAULT_MODEL_PATH = "allenai/longformer-base-4096"
+
+
+class Recformer(RecformerBase):
+    pass
+
+
+class RecformerLarge(BaseRecformerModel):
+    SPEC = staticmethod(EncoderSpec.recformer_large)
+    DEFAULT_MODEL_PATH = "allenai/longformer-large-4096"
+
+
+class ModelType(Enum):
+    """models/enums.py:12-24, restricted to the families on the hot path (BERT/RoBERTa/Longformer/LLaMA/
+    Mistral wrappers are out of scope: no script on the path uses them)."""
+
+    BLAIR = BLaIR
+    BLAIR_BASE = BLaIRBase
+    BLAIR_LARGE = BLaIRLarge
+    RECFORMER = Recformer
+    RECFORMER_BASE = RecformerBase
+    RECFORMER_LARGE = RecformerLarge

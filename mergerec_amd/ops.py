@@ -204,15 +204,10 @@ def score_topk(U: torch.Tensor, E: torch.Tensor, k: int, labels: Optional[torch.
         rank = torch.empty(nU, dtype=torch.int32, device=dev)
     scores = ws = None
     nbytes = 0
-    if return_scores and M % 4 == 0:
+    if return_scores:
         scores = torch.empty(nU, M, dtype=torch.float32, device=dev)
     else:
         nbytes = lib.mr_score_topk_ws_bytes(nU, M)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     check(lib.mr_score_topk_f32(ptr(U), ptr(E), nU, M, d, k, ptr(val), ptr(idx), ptr(scores), ptr(labels), inv_temp, ptr(lse), ptr(lab), ptr(rank), ptr(ws), nbytes, _stream(U)), "mr_score_topk_f32")
-    if return_scores and scores is None:
-        # M % 4 != 0: the block lives in the workspace with a padded leading dimension; expose a view
-        ldm = (M + 3) & ~3
-        off = (-ws.data_ptr()) % 256
-        scores = ws[off : off + nU * ldm * 4].view(torch.float32).view(nU, ldm)[:, :M]
     return val, idx, lse, lab, rank, scores

@@ -1,0 +1,34 @@
+"""Mirror of rec_retrieval/types/model_batch.py:19-45 (the hot path's input dataclasses)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, fields, replace
+from typing import Any, Mapping
+
+import torch
+
+
+class ToDeviceMixin:
+    def to(self, device):
+        def _move(obj):
+            if isinstance(obj, torch.Tensor):
+                return obj.to(device)
+            if hasattr(obj, "to") and not isinstance(obj, (dict, list, tuple)):
+                return obj.to(device)  # transformers.BatchEncoding
+            if isinstance(obj, Mapping):
+                return {k: _move(v) for k, v in obj.items()}
+            if isinstance(obj, (list, tuple)):
+                return type(obj)(_move(v) for v in obj)
+            return obj
+
+        return replace(self, **{f.name: _move(getattr(self, f.name)) for f in fields(self)})
+
+
+@dataclass
+class BatchItem(ToDeviceMixin):
+    items: Any  # BatchEncoding / mapping of int64 (B, L) tensors
+
+
+@dataclass
+class BatchSequence(ToDeviceMixin):
+    sequence: Any
+    labels: torch.Tensor

@@ -1,0 +1,100 @@
+"""Mirror of the reference's top-level utils.py (remove_duplicate_prefix :17-29, test_model :32-134,
+save_predictions :178-214) plus the minimal Trainer the test loop needs when lightning is absent."""
+from __future__ import annotations
+
+import ast
+import csv
+from pathlib import Path
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+
+from .module.callbacks import ItemEncodingCallback
+from .module.recommender import RecModule
+
+
+def remove_duplicate_prefix(state_dict):
+    new = {}
+    for k, v in state_dict.items():
+        if k.startswith("model."):
+            new[k.replace("model.", "", 1)] = v
+        else:
+            print(f"Keeping key {k} without model. prefix")
+            new[k] = v
+    return new
+
+
+def load_alpha_file(path: Path, line: int) -> dict:
+    """merge_test.py:67-68 parses each line with eval(); literal_eval accepts the same dict reprs safely."""
+    rows = [ast.literal_eval(l) for l in Path(path).read_text().strip().splitlines()]
+    return rows[line]["weights"]
+
+
+class Trainer:
+    """``lightning.Trainer(...).test(module, dataloader)`` hook order: callbacks' on_test_epoch_start,
+    module.on_test_epoch_start, test_step per batch (moved to the module's device), on_test_epoch_end."""
+
+    def __init__(self, precision: str = "32-true", callbacks: Sequence = (), **_):
+        if precision not in ("32-true", "32", 32):
+            raise NotImplementedError("the HIP path computes in fp32 (parity configuration); bf16-mixed is not built")
+        self.callbacks = list(callbacks)
+
+    @torch.no_grad()
+    def test(self, module: RecModule, dataloader: Iterable, verbose: bool = False) -> List[Dict[str, float]]:
+        module.trainer = self
+        module.eval()
+        for cb in self.callbacks:
+            if hasattr(cb, "on_test_epoch_start"):
+                cb.on_test_epoch_start(self, module)
+        module.on_test_epoch_start()
+        for i, batch in enumerate(dataloader):
+            module.test_step(batch.to(module.device), i)
+        metrics = module.on_test_epoch_end()
+        return [dict(metrics)]
+
+
+def test_model(module: RecModule, item_dataloaders: Sequence[Iterable], sequence_dataloaders: Sequence[Iterable],
+               data_names: Sequence[str], precision: str = "32-true", metrics_path: Optional[Path] = None,
+               predictions_path: Optional[Path] = None, item_embeddings_path: Optional[Path] = None,
+               user_embeddings_path: Optional[Path] = None):
+    """utils.py:32-134 from the point where the per-domain dataloaders exist (the datamodule / tokeniser
+    side is a 'next' row).  Returns (metric_dict, metrics, scores, labels) like the reference; ``scores``
+    entries are None unless predictions are being saved (the fused path does not materialise them)."""
+    cb = ItemEncodingCallback()
+    trainer = Trainer(precision=precision, callbacks=[cb])
+    module.keep_scores = predictions_path is not None
+    metric_dict, metrics, scores, labels, item_embs, user_embs = {}, [], [], [], [], []
+    for i, (item_dl, seq_dl) in enumerate(zip(item_dataloaders, sequence_dataloaders)):
+        cb.item_dataloader = item_dl
+        module.item_embeddings = None  # utils.py:110: catalog re-encoded per domain
+        metric = trainer.test(module, seq_dl, verbose=False)
+        scores.append(None if module.eval_scores is None else module.eval_scores.detach().cpu().clone())
+        labels.append(module.eval_labels.detach().cpu().clone())
+        item_embs.append(module.item_embeddings.detach().cpu().clone())
+        user_embs.append(module.eval_user_embeddings.detach().cpu().clone())
+        metrics.append(metric[0])
+        metric_dict.update({f"test/dataset_{i}/{k}": v for k, v in metric[0].items()})
+    save_predictions(data_names, item_embs, item_embeddings_path, labels, metrics, metrics_path, predictions_path, scores,
+                     user_embs, user_embeddings_path)
+    return metric_dict, metrics, scores, labels
+
+
+def save_predictions(data_names, item_embeddings, item_embeddings_path, labels, metrics, metrics_path, predictions_path,
+                     scores, user_embeddings, user_embeddings_path):
+    if metrics_path is not None:  # utils.py:191-196: CSV indexed by dataset dir name
+        cols = list(metrics[0].keys()) if metrics else []
+        with open(metrics_path, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["dataset"] + cols)
+            for name, m in zip(data_names, metrics):
+                w.writerow([name] + [m[c] for c in cols])
+        print(f"Saved metrics to {metrics_path}")
+    if predictions_path is not None:
+        torch.save({n: {"scores": s, "labels": l} for n, s, l in zip(data_names, scores, labels)}, predictions_path)
+        print(f"Saved predictions to {predictions_path}")
+    if item_embeddings_path is not None:
+        torch.save(item_embeddings, item_embeddings_path)
+        print(f"Saved item embeddings to {item_embeddings_path}")
+    if user_embeddings_path is not None:
+        torch.save(user_embeddings, user_embeddings_path)
+        print(f"Saved user embeddings to {user_embeddings_path}")

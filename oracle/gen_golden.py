@@ -137,7 +137,7 @@ def main():
         missing = m.load_state_dict({k[len("model."):]: v for k, v in sd.items()}, strict=True)
         return m
 
-    tiny = O.EncoderConfig(hidden=64, heads=4, layers=2, intermediate=128, vocab=200, max_pos=66)
+    tiny = O.EncoderConfig(hidden=128, heads=2, layers=2, intermediate=256, vocab=200, max_pos=66)  # head_dim 64 like the real models
     tiny_sd = O.random_state_dict(O.roberta_param_shapes(tiny), seed=1000, std=0.2)
     m = hf_roberta(tiny, tiny_sd)
     # transformers 5.x orders the embedding tensors (word, token_type, LayerNorm, position); 4.51.3 (the
@@ -197,7 +197,7 @@ def main():
             return self.model(**batch).last_hidden_state[:, 0, :]
 
     # a smaller config for the merger fixture (it stores several full flat vectors)
-    tiny2 = O.EncoderConfig(hidden=32, heads=4, layers=2, intermediate=64, vocab=60, max_pos=40)
+    tiny2 = O.EncoderConfig(hidden=64, heads=1, layers=2, intermediate=32, vocab=40, max_pos=40)
     tiny2_sd = O.random_state_dict(O.roberta_param_shapes(tiny2), seed=1002, std=0.2)
     tiny2_sd = OrderedDict(("model." + k, tiny2_sd["model." + k]) for k in hf_roberta(tiny2, tiny2_sd).state_dict().keys())
     tiny, tiny_sd = tiny2, tiny2_sd
@@ -246,10 +246,10 @@ def main():
             learn_type=learn, use_softmax=softmax_on, groups=groups, weights=weights,
             serialized=mm.serialize_weights(), shape_keys=list(mm.shape_dict.keys()),
             shapes=[tuple(s) for s in mm.shape_dict.values()],
-            init_merged_flat=torch.cat([v.reshape(-1) for v in init_sd.values()]),
+            init_merged_flat=torch.cat([v.reshape(-1) for v in init_sd.values()]) if not softmax_on else None,
             merged_flat=torch.cat([v.reshape(-1) for v in merged_sd.values()]), cls=cls,
         ))
-        g2["base_flat"] = mm.base_model_tensor.detach().clone()
+        g2["base_flat_checksum"] = float(mm.base_model_tensor.detach().double().sum())
         g2["tv_flat"] = mm.task_vectors_tensor.detach().clone()
     # fixed-alpha ModelMerger paths (merger.py:46-93): 'task_vector' sequential accumulation and 'linear'
     pre_aligned = OrderedDict((k, v) for k, v in tiny_sd.items())
@@ -296,8 +296,8 @@ def main():
         return emb[:, : emb.shape[1] - padding_len], enc
 
     g4 = dict(cases=[])
-    for ci, (w1, layers, Lr, lens_r) in enumerate([(4, 2, 21, [21, 9, 1, 14]), (32, 1, 150, [150, 70, 33]), (32, 2, 64, [64, 40])]):
-        rc = O.EncoderConfig(hidden=64, heads=4, layers=layers, intermediate=128, vocab=200, max_pos=300,
+    for ci, (w1, layers, Lr, lens_r) in enumerate([(4, 2, 21, [21, 9, 1, 14]), (32, 1, 150, [150, 70, 33]), (32, 2, 100, [100, 40])]):
+        rc = O.EncoderConfig(hidden=128, heads=2, layers=layers, intermediate=128, vocab=100, max_pos=200,
                              token_type_size=4, max_item_embeddings=51, one_sided_window=w1)
         rsd = O.random_state_dict(O.recformer_param_shapes(rc), seed=3000 + ci, std=0.2)
         model = ref_recformer(rc, rsd)

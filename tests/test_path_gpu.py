@@ -1,0 +1,212 @@
+"""GPU parity of the whole path behind the reference's own API surface (merger -> encoder -> scoring ->
+evaluator), against the golden vectors produced by the reference and against the CPU oracle."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from oracle import c_oracle as CO
+from oracle import ref_cpu as O
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _spec(cfgd, kind="roberta"):
+    from mergerec_amd.engine import EncoderSpec
+
+    return EncoderSpec(kind=kind, hidden=cfgd["hidden"], heads=cfgd["heads"], layers=cfgd["layers"], intermediate=cfgd["intermediate"],
+                       vocab=cfgd["vocab"], max_pos=cfgd["max_pos"], pad_id=cfgd["pad_id"], ln_eps=cfgd["ln_eps"],
+                       token_type_size=cfgd["token_type_size"], max_item_embeddings=cfgd["max_item_embeddings"],
+                       one_sided_window=cfgd["one_sided_window"] if kind == "recformer" else -1)
+
+
+def _dev_weights(sd):
+    return {k: v.to(DEV, torch.float32).contiguous() for k, v in sd.items()}
+
+
+def _unpack(hidden_packed, mask):
+    B, L = mask.shape
+    out = torch.zeros(B, L, hidden_packed.shape[1])
+    out[mask.bool()] = hidden_packed.cpu()
+    return out
+
+
+# ------------------------------------------------------------------ encoder vs reference goldens
+def test_roberta_encoder_matches_library_golden():
+    from mergerec_amd.engine import EncoderRunner
+
+    g3 = load_golden("g3_roberta.pt")
+    run = EncoderRunner(_spec(g3["cfg"]))
+    w = _dev_weights(g3["state_dict"])
+    batch = {"input_ids": g3["input_ids"], "attention_mask": g3["attention_mask"]}
+    pb = run.pack(batch, DEV)
+    cls, hidden = run.forward_packed(w, pb, normalize=False, return_hidden=True)
+    m = g3["attention_mask"].bool()
+    for li, (h, ref) in enumerate(zip(hidden, g3["hidden_states"])):
+        got = _unpack(h, g3["attention_mask"])
+        assert torch.allclose(got[m], ref[m], atol=1e-4, rtol=1e-5), (li, (got[m] - ref[m]).abs().max())
+    assert torch.allclose(cls.cpu(), g3["cls"], atol=1e-4, rtol=1e-5)
+    fast = run.forward_packed(w, pb, normalize=False)  # last layer on CLS rows only
+    assert torch.allclose(fast.cpu(), g3["cls"], atol=1e-4, rtol=1e-5)
+    nrm = run.forward_packed(w, pb, normalize=True).cpu()
+    assert torch.allclose(nrm, O.maybe_normalize(g3["cls"]), atol=1e-5)
+
+
+def test_roberta_true_dims_layer_matches_library_golden():
+    from mergerec_amd.engine import EncoderRunner
+
+    big = load_golden("g3_roberta.pt")["big"]
+    cfg = O.EncoderConfig(**big["cfg"])
+    sd = O.random_state_dict(O.roberta_param_shapes(cfg), seed=big["seed"], std=big["std"])
+    run = EncoderRunner(_spec(big["cfg"]))
+    pb = run.pack({"input_ids": big["input_ids"], "attention_mask": big["attention_mask"]}, DEV)
+    _, hidden = run.forward_packed(_dev_weights(sd), pb, normalize=False, return_hidden=True)
+    m = big["attention_mask"].bool()
+    assert torch.allclose(_unpack(hidden[0], big["attention_mask"])[m], big["emb"][m], atol=1e-5)
+    got = _unpack(hidden[-1], big["attention_mask"])[m]
+    assert torch.allclose(got, big["last"][m], atol=1e-4, rtol=1e-5), (got - big["last"][m]).abs().max()
+
+
+def test_recformer_encoder_matches_reference_golden():
+    from mergerec_amd.engine import EncoderRunner
+
+    for case in load_golden("g4_recformer.pt")["cases"]:
+        run = EncoderRunner(_spec(case["cfg"], "recformer"))
+        w = _dev_weights({k: v for k, v in case["state_dict"].items()})
+        b = case["batch"]
+        pb = run.pack(b, DEV)
+        cls, hidden = run.forward_packed(w, pb, normalize=False, return_hidden=True)
+        m = b["attention_mask"].bool()
+        for li, (h, ref) in enumerate(zip(hidden, case["hidden_states"])):
+            got = _unpack(h, b["attention_mask"])
+            assert torch.allclose(got[m], ref[m], atol=1e-4, rtol=1e-5), (li, (got[m] - ref[m]).abs().max())
+        assert torch.allclose(cls.cpu(), case["cls"], atol=1e-4, rtol=1e-5)
+        fast = run.forward_packed(w, pb, normalize=False)
+        assert torch.allclose(fast.cpu(), case["cls"], atol=1e-4, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ merger behind load_merging_module
+def _tiny_model(cfgd, kind="BLAIR_BASE"):
+    from mergerec_amd.module import ModelType
+
+    over = dict(hidden=cfgd["hidden"], heads=cfgd["heads"], layers=cfgd["layers"], intermediate=cfgd["intermediate"], vocab=cfgd["vocab"],
+                max_pos=cfgd["max_pos"])
+    return ModelType[kind].value(model_kwargs={"init_seed": 1, "spec_overrides": over, "device": DEV})
+
+
+def test_load_merging_module_matches_reference_golden():
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+
+    g2 = load_golden("g2_merger.pt")
+    batch = {"input_ids": g2["input_ids"], "attention_mask": g2["attention_mask"]}
+    for case in g2["cases"]:
+        model = _tiny_model(g2["cfg"])
+        mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[case["learn_type"]], model, g2["pretrain"],
+                                 [dict(ft) for ft in g2["finetunes"]], set(), disable_softmax=not case["use_softmax"],
+                                 initial_per_weight=0.3)
+        assert list(mm.shape_dict.keys()) == case["shape_keys"]
+        assert [tuple(s) for s in mm.shape_dict.values()] == case["shapes"]
+        assert list(mm.per_weights.keys()) == case["groups"]
+        assert torch.equal(mm.compact_task_vectors().cpu(), g2["tv_flat"])
+        assert float(mm.compact_base().cpu().double().sum()) == g2["base_flat_checksum"]
+        if case["init_merged_flat"] is not None:
+            init = torch.cat([v.reshape(-1) for v in mm.get_state_dict().values()]).cpu()
+            assert torch.equal(init, case["init_merged_flat"])
+        mm.load_weights_from_dict(case["weights"])
+        ser = mm.serialize_weights()
+        for part in ("global_weights", "global_biases", "per_weights"):
+            for k, v in case["serialized"][part].items():
+                assert ser[part][k] == v
+        sd = mm.get_state_dict()
+        assert list(sd.keys()) == case["shape_keys"]
+        merged = torch.cat([v.reshape(-1) for v in sd.values()]).cpu()
+        if case["use_softmax"]:  # softmax over N alphas runs on the device: allow the last ulp of expf
+            assert torch.allclose(merged, case["merged_flat"], atol=1e-7, rtol=1e-6)
+        else:
+            assert torch.equal(merged, case["merged_flat"]), case["learn_type"]
+        cls = mm.forward(batch)  # re-merge into the arena, then the encoder reads it in place
+        assert torch.allclose(cls.cpu(), case["cls"], atol=1e-4, rtol=1e-5), (cls.cpu() - case["cls"]).abs().max()
+
+
+def test_merging_module_errors_mirror_reference():
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+
+    g2 = load_golden("g2_merger.pt")
+    model = _tiny_model(g2["cfg"])
+    with pytest.raises(AssertionError):
+        load_merging_module("TASK_VECTOR", LearnType.TASK_WISE, model, g2["pretrain"], g2["finetunes"], set())
+    with pytest.raises(ValueError):
+        load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, [1, 2], g2["finetunes"], set())
+    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, g2["pretrain"], [dict(f) for f in g2["finetunes"]], set())
+    with pytest.raises(AssertionError):
+        mm.load_weights_from_dict({"global_weights": {"nope": [1.0]}, "global_biases": {}, "per_weights": {}})
+    with pytest.raises(NotImplementedError):
+        load_merging_module(MergeType.TIES, LearnType.TASK_WISE, model, g2["pretrain"], [dict(f) for f in g2["finetunes"]], set(), ties_density=0.2)
+
+
+# ------------------------------------------------------------------ the whole path vs the oracle
+@pytest.mark.parametrize("kind", ["BLAIR_BASE", "RECFORMER_BASE"])
+def test_end_to_end_merge_encode_score_evaluate(kind):
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.module import ModelType, RecModule
+    from mergerec_amd.synthetic import make_domain
+    from mergerec_amd.utils import test_model
+
+    rec = kind.startswith("RECFORMER")
+    over = dict(hidden=128, heads=2, layers=2, intermediate=256, vocab=300, max_pos=200)
+    mk = {"init_seed": 11, "spec_overrides": over, "device": DEV}
+    model = ModelType[kind].value(model_kwargs=dict(mk))
+    pre = OrderedDict((k, v.cpu().clone()) for k, v in model.state_dict().items())
+    fts = [O.perturbed_state_dict(pre, seed=50 + i, std=0.02) for i in range(3)]
+    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.LAYER_WISE if rec else LearnType.TASK_WISE, model, pre, fts, set(),
+                             disable_softmax=True)
+    groups = list(mm.per_weights.keys())
+    gg = torch.Generator().manual_seed(3)
+    weights = {"global_weights": {k: [1.0] for k in groups}, "global_biases": {k: [0.0] for k in groups},
+               "per_weights": {k: (0.1 + 0.5 * torch.rand(3, generator=gg)).tolist() for k in groups}}
+    mm.load_weights_from_dict(weights)
+    state_dict = {k: v.detach() for k, v in mm.get_state_dict().items()}
+    model2 = ModelType[kind].value(model_kwargs=dict(mk))
+    model2.load_state_dict(state_dict)  # merge_test.py:71-80
+    module = RecModule(model=model2, evaluator=Evaluator(["NDCG", "RECALL"], [1, 5, 10, 50]), similarity="cosine")
+    dom = make_domain("Toy", n_items=333, n_users=150, batch_size=32, vocab=over["vocab"], seed=9,
+                      kind="recformer" if rec else "roberta", max_seq_len=160, item_len_scale=0.3)
+    metric_dict, metrics, scores, labels = test_model(module, [dom.item_batches], [dom.sequence_batches], ["Toy"])
+
+    # ---- oracle: same arithmetic on CPU
+    base, shape_dict = O.flatten_model(pre)
+    tv = O.get_task_vectors(base, [O.flatten_model(OrderedDict((k, ft[k]) for k in pre))[0] for ft in fts])
+    if rec:
+        grp = O.group_parameters_by_layer(shape_dict)
+        alpha = {k: torch.tensor(weights["per_weights"][k]) for k in grp}
+        merged = O.merge_layer_wise(base, tv, grp, alpha)
+    else:
+        merged = O.merge_task_wise(base, tv, torch.tensor(weights["per_weights"]["all"]))
+    got_merged = torch.cat([v.reshape(-1) for v in state_dict.values()]).cpu()
+    assert torch.equal(got_merged, merged), "merged parameters must be bit-exact"
+    sd = O.get_state_dict(merged, shape_dict)
+    cfg = O.EncoderConfig(hidden=128, heads=2, layers=2, intermediate=256, vocab=300, max_pos=200,
+                          token_type_size=4 if rec else 1, max_item_embeddings=51 if rec else 0, one_sided_window=32 if rec else 0)
+
+    def enc(b):
+        if rec:
+            return O.recformer_encode(sd, b["input_ids"], b["attention_mask"], b["global_attention_mask"], b["token_type_ids"],
+                                      b["item_position_ids"], cfg, "model.")
+        return O.roberta_encode(sd, b["input_ids"], b["attention_mask"], cfg, "model.")
+
+    E = O.maybe_normalize(torch.cat([enc(b.items) for b in dom.item_batches]))
+    U = O.maybe_normalize(torch.cat([enc(b.sequence) for b in dom.sequence_batches]))
+    assert torch.allclose(module.item_embeddings.detach().cpu(), E, atol=1e-4)
+    assert torch.allclose(module.eval_user_embeddings, U, atol=1e-4)
+    ref_scores = O.score(U, E)
+    want = O.evaluate(ref_scores, dom.labels, ["NDCG", "RECALL"], [1, 5, 10, 50], "test/")
+    for k, v in want.items():
+        assert abs(metrics[0][k] - v) <= 1e-3, (k, metrics[0][k], v)   # north_star: NDCG@10 within 1e-3
+    assert abs(metrics[0]["test/loss"] - O.ce_loss(ref_scores, dom.labels, 0.05)) < 2e-3
+    _, oi = O.topk_canonical(ref_scores, 50)
+    assert O.ranks_equal_up_to_ties(ref_scores, module.eval_topk_indices, oi, atol=2e-4)
+    assert list(metric_dict.keys())[0].startswith("test/dataset_0/")
+    assert torch.equal(labels[0], dom.labels)
