@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- sequences/sec of MergeRec's merged-model inference path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json metric: "sequences/sec full-catalog scoring, 8-domain merged BLaIR-base"):
+  8 synthetic fine-tuned BLaIR-base checkpoints (theta_pre ~ N(0, 0.02^2), tau_i ~ N(0, 1e-3^2)) merged with
+  fixed alpha = 1/8 ("average", merge_test.py:47-55); catalog of an Arts-sized domain (M = 22,855);
+  Amazon-shaped synthetic sequences; fp32 end to end (the parity configuration).
+A "step" is one pass of the WHOLE hot path over one batch, per rank:
+  (1) N-way alpha-weighted merge of this rank's arena slice (+ all-gather of slices when N > 1),
+  (2) encode `items_per_step` catalog items and refresh those rows of the item-embedding matrix
+      (+ all-gather of the refreshed rows when N > 1) -- users_per_step / items_per_step = 2 matches the
+      measured users:items ratio of the Amazon domains, so U/users_per_step steps re-encode one full catalog,
+  (3) encode `users_per_step` user sequences (CLS pooled, L2-normalised),
+  (4) score them against the FULL catalog and take the canonical top-50 (+ CE terms, label ranks).
+Nothing is cached across steps; inputs are resident in HBM before the timed region.
+value = users_per_step * N * K / max-over-ranks wall time (weak scaling: per-GPU work is fixed).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from collections import OrderedDict
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--domains", type=int, default=8, help="number of fine-tuned checkpoints merged")
+    ap.add_argument("--catalog", type=int, default=22855, help="catalog size M (Arts-sized)")
+    ap.add_argument("--users-per-step", type=int, default=256)
+    ap.add_argument("--items-per-step", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seqs", type=int, default=6)
+    ap.add_argument("--cpu-items", type=int, default=24)
+    ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP-event timing")
+    return ap.parse_args()
+
+
+def synth_arena(layout, padded, n_dom, device, seed=1000):
+    """Seeded synthetic weights generated directly in arena layout on the device (plumbing, untimed)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    base = torch.zeros(padded, dtype=torch.float32, device=device)
+    for k in layout.shapes:
+        v = layout.view(base, k)
+        if "LayerNorm.weight" in k:
+            v.fill_(1.0)
+        elif "LayerNorm.bias" in k:
+            v.zero_()
+        else:
+            v.copy_(torch.randn(v.shape, generator=g, device=device) * 0.02)
+    tv = torch.zeros(n_dom, padded, dtype=torch.float32, device=device)
+    for i in range(n_dom):
+        gi = torch.Generator(device=device).manual_seed(seed + 1 + i)
+        for k in layout.shapes:
+            layout.view(tv[i], k).copy_(torch.randn(layout.shapes[k], generator=gi, device=device) * 1e-3)
+    return base, tv
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mergerec_amd import ops, parallel
+    from mergerec_amd.engine import ArenaLayout, EncoderRunner, EncoderSpec
+    from mergerec_amd.synthetic import blair_item_lengths, blair_sequence_lengths, _ids_from_lengths
+
+    spec = EncoderSpec.blair_base()
+    layout = ArenaLayout(spec.param_shapes("model."))
+    plan = parallel.SlicePlan(layout.padded_numel, world)
+    runner = EncoderRunner(spec)
+    n_dom, M, d = args.domains, args.catalog, spec.hidden
+    U_step, I_step = args.users_per_step, args.items_per_step
+
+    # ---------------- resident state (untimed setup) ----------------
+    base, tv = synth_arena(layout, plan.padded, n_dom, dev)
+    alpha = torch.full((1, n_dom), 1.0 / n_dom, dtype=torch.float32, device=dev)  # "average" weights
+    arena = torch.zeros(plan.padded, dtype=torch.float32, device=dev)
+    W = layout.views(arena)
+    lo, hi = plan.bounds(rank)
+    scratch = torch.empty(hi - lo, dtype=torch.float32, device=dev) if world > 1 else None
+
+    def merge_slice(p_begin, p_count, out_slice):
+        ops.merge_nway(base, tv, alpha, None, out=out_slice, p_begin=p_begin, p_count=p_count, out_is_slice=True)
+
+    n_total = args.steps + args.warmup
+    g = torch.Generator().manual_seed(1234 + rank)
+    user_batches, item_batches, label_batches = [], [], []
+    for s in range(n_total):
+        ul = blair_sequence_lengths(U_step, g)
+        il = blair_item_lengths(I_step, g)
+        ub = _ids_from_lengths(ul, spec.vocab, g)
+        ib = _ids_from_lengths(il, spec.vocab, g)
+        user_batches.append(({k: v.to(dev) for k, v in ub.items()}, ul))
+        item_batches.append(({k: v.to(dev) for k, v in ib.items()}, il))
+        label_batches.append(torch.randint(0, M, (U_step,), generator=g).to(dev))
+    avg_user_tokens = float(torch.cat([l for _, l in user_batches]).float().mean())
+    avg_item_tokens = float(torch.cat([l for _, l in item_batches]).float().mean())
+
+    # full catalog encoded once with the merged model (setup): E (M, d), row == item id
+    parallel.sharded_merge(merge_slice, arena, plan, scratch)
+    E = torch.empty(M, d, dtype=torch.float32, device=dev)
+    gi = torch.Generator().manual_seed(99)
+    for s0 in range(0, M, 512):
+        n = min(512, M - s0)
+        il = blair_item_lengths(n, gi)
+        ib = {k: v.to(dev) for k, v in _ids_from_lengths(il, spec.vocab, gi).items()}
+        E[s0 : s0 + n] = runner.encode(W, ib, dev, normalize=True, lens=il, validate=False)
+    torch.cuda.synchronize()
+
+    item_blocks = [(r * I_step, (r + 1) * I_step) for r in range(world)]
+    state = {"cursor": 0}
+
+    def step(i):
+        # (1) merge (this rank's slice) [+ all-gather]
+        parallel.sharded_merge(merge_slice, arena, plan, scratch)
+        # (2) catalog slice refresh
+        ib, il = item_batches[i]
+        e_new = runner.encode(W, ib, dev, normalize=True, lens=il, validate=False)
+        e_all = parallel.all_gather_rows(e_new, item_blocks) if world > 1 else e_new
+        c = state["cursor"]
+        n = e_all.shape[0]
+        if c + n > M:
+            c = 0
+        E[c : c + n] = e_all
+        state["cursor"] = c + n
+        # (3) users
+        ub, ul = user_batches[i]
+        u = runner.encode(W, ub, dev, normalize=True, lens=ul, validate=False)
+        # (4) full-catalog scoring + canonical top-50 + CE terms
+        return ops.score_topk(u, E, 50, label_batches[i], 1.0 / 0.05)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ops.PROF.enabled = not args.no_profile
+    ops.PROF.records.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.warmup, n_total):
+        last = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.PROF.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    value = U_step * world * args.steps / elapsed
+
+    # ---------------- per-kernel rooflines from HIP events over the timed region ----------------
+    kernels = {}
+    roofline = None
+    if not args.no_profile:
+        for name, r in ops.PROF.summary().items():
+            sec = r["ms"] / 1e3
+            ent = dict(launches=r["launches"], avg_ms=r["ms"] / max(r["launches"], 1), share_of_step=r["ms"] / (elapsed * 1e3))
+            if r["flops"] > 0:
+                ent.update(bound="mfma", achieved=r["flops"] / sec / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
+            else:
+                ent.update(bound="hbm", achieved=r["bytes"] / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+            ent["frac"] = ent["achieved"] / ent["peak"]
+            kernels[name] = ent
+        dom = max(kernels.items(), key=lambda kv: kv[1]["share_of_step"])
+        roofline = dict(kernel=dom[0], bound=dom[1]["bound"], achieved=dom[1]["achieved"], peak=dom[1]["peak"], unit=dom[1]["unit"],
+                        frac=dom[1]["frac"], traffic=None, launches=dom[1]["launches"], avg_launch_ms=dom[1]["avg_ms"])
+
+    # ---------------- CPU baseline (oracle port, rank 0, N == 1 only) ----------------
+    cpu_baseline = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline, parity = run_cpu_baseline(args, spec, layout, base, tv, alpha, W, runner, dev, M, E)
+
+    if rank == 0:
+        out = OrderedDict(
+            metric="sequences/sec full-catalog scoring, 8-domain merged BLaIR-base; NDCG@10 parity",
+            value=value, unit="sequences/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+            data="synthetic",
+            config=dict(
+                workload=f"{n_dom}-domain merged BLaIR-base (alpha=1/{n_dom}), full-catalog scoring, Arts-sized catalog",
+                domains_merged=n_dom, catalog_items=M, users_per_step_per_gpu=U_step, items_per_step_per_gpu=I_step,
+                avg_user_tokens=avg_user_tokens, avg_item_tokens=avg_item_tokens, topk=50, params=layout.numel,
+                parallelism=f"dp{world}: arena-slice merge + all-gather, catalog rows sharded + all-gather, users data-parallel",
+            ),
+            roofline=roofline, cpu_baseline=cpu_baseline, kernels=kernels, parity=parity,
+        )
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(args, spec, layout, base, tv, alpha, W, runner, dev, M, E):
+    """Times the oracle (oracle/ref_cpu.py, fp32 torch on the host cores) on a bounded sample of the same
+    step and scales it to the step's composition.  Also cross-checks the GPU embeddings of the sample."""
+    from oracle import ref_cpu as O
+    from mergerec_amd.synthetic import blair_item_lengths, blair_sequence_lengths, _ids_from_lengths
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n_dom = tv.shape[0]
+    base_c, tv_c, a_c = base.cpu(), tv.cpu(), alpha.cpu().reshape(-1)
+    t0 = time.perf_counter()
+    merged = O.merge_task_wise(base_c, tv_c, a_c)  # the reference's 3-op expression (task_wise.py:43-47)
+    t_merge = time.perf_counter() - t0
+    sd = layout.views(merged)
+    cfg = O.EncoderConfig()
+    g = torch.Generator().manual_seed(4321)
+    ul = blair_sequence_lengths(args.cpu_seqs, g)
+    il = blair_item_lengths(args.cpu_items, g)
+    ub = _ids_from_lengths(ul, spec.vocab, g)
+    ib = _ids_from_lengths(il, spec.vocab, g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        u_c = O.maybe_normalize(O.roberta_encode(sd, ub["input_ids"], ub["attention_mask"], cfg, "model."))
+        t_users = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        e_c = O.maybe_normalize(O.roberta_encode(sd, ib["input_ids"], ib["attention_mask"], cfg, "model."))
+        t_items = time.perf_counter() - t0
+        E_c = E.cpu()
+        nU = 32  # the reference's per-batch scoring shape (module.py:137 at --batch_size 32)
+        Uc = O.maybe_normalize(torch.randn(nU, spec.hidden, generator=g))
+        t0 = time.perf_counter()
+        sc = O.score(Uc, E_c)
+        O.topk_canonical(sc, 50)
+        t_score = time.perf_counter() - t0
+    U_step, I_step = args.users_per_step, args.items_per_step
+    t_step = t_merge + I_step * (t_items / args.cpu_items) + U_step * (t_users / args.cpu_seqs) + (U_step / nU) * t_score
+    # parity of the GPU path on the very same sample
+    u_g = runner.encode(W, {k: v.to(dev) for k, v in ub.items()}, dev, normalize=True).cpu()
+    e_g = runner.encode(W, {k: v.to(dev) for k, v in ib.items()}, dev, normalize=True).cpu()
+    merged_g = torch.cat([v.reshape(-1) for v in W.values()]).cpu()
+    merged_cc = torch.cat([v.reshape(-1) for v in sd.values()])
+    parity = dict(
+        merged_params_bit_exact=bool(torch.equal(merged_g, merged_cc)),
+        user_embedding_max_abs_diff=float((u_g - u_c).abs().max()), item_embedding_max_abs_diff=float((e_g - e_c).abs().max()),
+        logit_max_abs_diff=float((u_g @ e_g.T - u_c @ e_c.T).abs().max()), tolerance=1e-4,
+    )
+    base_out = dict(
+        value=U_step / t_step, unit="sequences/s", cores=cores, kind="port",
+        sample=(f"oracle/ref_cpu.py fp32 torch, {cores} threads: {n_dom}-way merge of all {layout.numel} params ({t_merge:.2f}s), "
+                f"{args.cpu_seqs} user sequences ({t_users:.2f}s), {args.cpu_items} items ({t_items:.2f}s), 32x{M} scoring+top-50 "
+                f"({t_score * 1e3:.1f}ms); scaled to one step = merge + {I_step} items + {U_step} users + scoring"),
+        cpu_s_per_step=t_step,
+    )
+    return base_out, parity
+
+
+if __name__ == "__main__":
+    main()

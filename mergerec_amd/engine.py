@@ -187,6 +187,7 @@ class PackedBatch:
     tok_pos: torch.Tensor
     tok_tt: Optional[torch.Tensor] = None
     tok_ip: Optional[torch.Tensor] = None
+    sum_len_sq: float = 0.0  # sum_b L_b^2 (algorithmic attention work, for the profiler)
 
 
 def _lens_from_mask(attention_mask: torch.Tensor) -> torch.Tensor:
@@ -247,7 +248,7 @@ class EncoderRunner:
         dev = lambda t: None if t is None else t.to(device, torch.int64, non_blocking=True).contiguous()
         tw, tp, ttp, tip = ops.pack_tokens(dev(ids), dev(mask), cu_d, T, self.spec.pad_id, dev(tt), dev(ip))
         return PackedBatch(B=B, T=T, max_len=int(lens.max()) if B else 0, cu_seqlens=cu_d, cls_rows=cu_d[:-1].contiguous(),
-                           tok_word=tw, tok_pos=tp, tok_tt=ttp, tok_ip=tip)
+                           tok_word=tw, tok_pos=tp, tok_tt=ttp, tok_ip=tip, sum_len_sq=float((lens.double() ** 2).sum()) if B else 0.0)
 
     # ---- forward ---------------------------------------------------------------------------------
     def embed(self, w: Dict[str, torch.Tensor], pb: PackedBatch) -> torch.Tensor:
@@ -273,6 +274,9 @@ class EncoderRunner:
         (a13: the last layer's output is read at [:, 0] only, encoder/_base.py:45)."""
         sp, lp = self.spec, f"{self.prefix}encoder.layer.{l}."
         qkv = self._proj(w, lp, ("query", "key", "value"), x)
+        if ops.PROF.enabled:
+            w_ = sp.one_sided_window
+            ops.ATTN_FLOPS_HINT[0] = 4.0 * sp.hidden * (pb.sum_len_sq if sp.kind != "recformer" else pb.T * (2 * w_ + 2))
         ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=sp.one_sided_window if sp.kind == "recformer" else -1)
         if sp.kind == "recformer":
             x_cls = ops.gather_rows(x, pb.cls_rows)

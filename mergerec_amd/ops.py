@@ -17,6 +17,44 @@ ACT_NONE, ACT_GELU = 0, 1
 EMBED_ROBERTA, EMBED_RECFORMER = 0, 1
 
 
+class LaunchProfiler:
+    """Optional per-launch timing with HIP events recorded on the stream the kernel is launched on
+    (torch's current stream).  bench.py turns it on for the timed region; records are
+    (kernel family, algorithmic flops, algorithmic bytes, start event, end event)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def begin(self, dev):
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(dev))
+        return ev
+
+    def end(self, ev0, dev, name, flops=0.0, nbytes=0.0):
+        if ev0 is None:
+            return
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(torch.cuda.current_stream(dev))
+        self.records.append((name, float(flops), float(nbytes), ev0, ev1))
+
+    def summary(self):
+        """name -> dict(launches, ms, flops, bytes); call after a device synchronize."""
+        out = {}
+        for name, fl, nb, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+PROF = LaunchProfiler()
+
+
 def _dev(t: torch.Tensor, name: str, dtype=None):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise ValueError(f"{name} must be a GPU tensor (the HIP path has no CPU fallback)")
@@ -43,9 +81,11 @@ def task_vector(theta: torch.Tensor, base: torch.Tensor, out: Optional[torch.Ten
 
 def merge_nway(
     base: torch.Tensor, tv: torch.Tensor, alpha: torch.Tensor, seg_off: Optional[torch.Tensor] = None,
-    out: Optional[torch.Tensor] = None, p_begin: int = 0, p_count: Optional[int] = None,
+    out: Optional[torch.Tensor] = None, p_begin: int = 0, p_count: Optional[int] = None, out_is_slice: bool = False,
 ) -> torch.Tensor:
-    """out[p] = base[p] + sum_i alpha[s(p), i] * tv[i, p] for p in [p_begin, p_begin + p_count)."""
+    """out[p] = base[p] + sum_i alpha[s(p), i] * tv[i, p] for p in [p_begin, p_begin + p_count).
+    out_is_slice: `out` holds only the slice (p_count floats; out[0] is element p_begin) -- used when a rank
+    merges its arena slice into a send buffer for the all-gather."""
     _dev(base, "base", torch.float32), _dev(tv, "tv", torch.float32), _dev(alpha, "alpha", torch.float32)
     if tv.dim() != 2 or tv.shape[1] != base.numel():
         raise ValueError("tv must be (N, P)")
@@ -59,10 +99,15 @@ def merge_nway(
     p_count = P - p_begin if p_count is None else p_count
     if p_begin < 0 or p_count < 0 or p_begin + p_count > P:
         raise ValueError("slice out of range")
+    if out.numel() < (p_count if out_is_slice else p_begin + p_count):
+        raise ValueError("out is too small for the requested slice")
+    out_ptr = out.data_ptr() - (4 * p_begin if out_is_slice else 0)
+    ev = PROF.begin(base.device)
     check(
-        _lib.load().mr_merge_nway_f32(ptr(base), ptr(tv), tv.stride(0), ptr(alpha), ptr(seg_off), N, S, p_begin, p_count, ptr(out), _stream(base)),
+        _lib.load().mr_merge_nway_f32(ptr(base), ptr(tv), tv.stride(0), ptr(alpha), ptr(seg_off), N, S, p_begin, p_count, out_ptr, _stream(base)),
         "mr_merge_nway_f32",
     )
+    PROF.end(ev, base.device, "merge_nway", nbytes=(N + 2) * p_count * 4)
     return out
 
 
@@ -103,6 +148,7 @@ def pack_tokens(input_ids, attention_mask, cu_seqlens, T: int, pad_id: int, toke
 def embed_gather_ln(tok_word, tok_pos, tok_tt, tok_ip, word, pos, type_, itempos, gamma, beta, eps: float, mode: int, out=None):
     T, d = tok_word.numel(), word.shape[1]
     out = torch.empty(T, d, dtype=torch.float32, device=word.device) if out is None else out
+    ev = PROF.begin(word.device)
     check(
         _lib.load().mr_embed_gather_ln_f32(
             ptr(tok_word), ptr(tok_pos), ptr(tok_tt), ptr(tok_ip), ptr(word), ptr(pos), ptr(type_), ptr(itempos),
@@ -110,6 +156,8 @@ def embed_gather_ln(tok_word, tok_pos, tok_tt, tok_ip, word, pos, type_, itempos
             ptr(gamma), ptr(beta), eps, T, d, mode, ptr(out), _stream(word)),
         "mr_embed_gather_ln_f32",
     )
+    n_id = 2 + (tok_tt is not None) + (tok_ip is not None)
+    PROF.end(ev, word.device, "embed_gather_ln", nbytes=T * (2 * d * 4 + 4 * n_id))
     return out
 
 
@@ -126,27 +174,37 @@ def gemm_nt(A: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[O
     ws = list(weights) + [None] * (3 - nseg)
     M = A.shape[0]
     out = torch.empty(M, nseg * seg_n, dtype=torch.float32, device=A.device) if out is None else out
+    ev = PROF.begin(A.device)
     check(
         _lib.load().mr_gemm_nt_bias_act_f32(
             ptr(A), A.stride(0), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(biases[0]), ptr(biases[1]), ptr(biases[2]), nseg, M, seg_n, K,
             act, ptr(residual), 0 if residual is None else residual.stride(0), ptr(out), out.stride(0), _stream(A)),
         "mr_gemm_nt_bias_act_f32",
     )
+    PROF.end(ev, A.device, "gemm_nt", flops=2.0 * M * nseg * seg_n * K, nbytes=4.0 * (M * K + nseg * seg_n * K + M * nseg * seg_n * (2 if residual is not None else 1)))
     return out
 
 
 def layernorm(x: torch.Tensor, gamma, beta, eps: float, out=None) -> torch.Tensor:
     T, d = x.shape
     out = torch.empty(T, d, dtype=torch.float32, device=x.device) if out is None else out
+    ev = PROF.begin(x.device)
     check(_lib.load().mr_layernorm_f32(ptr(x), x.stride(0), ptr(gamma), ptr(beta), eps, T, d, ptr(out), out.stride(0), _stream(x)), "mr_layernorm_f32")
+    PROF.end(ev, x.device, "layernorm", nbytes=2.0 * T * d * 4)
     return out
+
+
+ATTN_FLOPS_HINT = [0.0]  # algorithmic 4 * sum(L_b^2) * d of the next attention launch (set by the engine)
 
 
 def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, window: int = -1, out=None) -> torch.Tensor:
     T = qkv.shape[0]
     dh = qkv.shape[1] // (3 * H)
     out = torch.empty(T, H * dh, dtype=torch.float32, device=qkv.device) if out is None else out
+    ev = PROF.begin(qkv.device)
     check(_lib.load().mr_attn_f32(ptr(qkv), ptr(cu_seqlens), B, H, dh, max_len, dh ** -0.5, window, ptr(out), _stream(qkv)), "mr_attn_f32")
+    PROF.end(ev, qkv.device, "attention", flops=ATTN_FLOPS_HINT[0], nbytes=4.0 * T * 4 * H * dh)
+    ATTN_FLOPS_HINT[0] = 0.0
     return out
 
 
@@ -209,5 +267,7 @@ def score_topk(U: torch.Tensor, E: torch.Tensor, k: int, labels: Optional[torch.
     else:
         nbytes = lib.mr_score_topk_ws_bytes(nU, M)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ev = PROF.begin(dev)
     check(lib.mr_score_topk_f32(ptr(U), ptr(E), nU, M, d, k, ptr(val), ptr(idx), ptr(scores), ptr(labels), inv_temp, ptr(lse), ptr(lab), ptr(rank), ptr(ws), nbytes, _stream(U)), "mr_score_topk_f32")
+    PROF.end(ev, dev, "score_topk", flops=2.0 * nU * M * d, nbytes=4.0 * (nU + M) * d + nU * k * 12)
     return val, idx, lse, lab, rank, scores

@@ -1,0 +1,109 @@
+"""One-process-per-GPU sharding of the path over the 8 GPUs of a node (RCCL over xGMI via
+torch.distributed backend "nccl").  The reference is single-GPU; this partitioning is new.
+
+  merge      : rank r merges arena elements [lo_r, hi_r) (64-float aligned slices) with the same kernel,
+               then ONE all-gather of the merged slices fills every rank's arena (P_pad/8 * 4 B = 62 MB per
+               rank for BLaIR-base).  No other collective touches parameters.
+  catalog    : item rows are split in contiguous blocks; each rank encodes its block, one all-gather of the
+               (M/world, d) embedding blocks gives every rank the full E (row index == item id is kept).
+  users      : data-parallel over test sequences; scoring is local against the full E.
+  metrics    : label ranks / lse / label logits are all-gathered (a few bytes per user); the metric sums
+               are then evaluated identically on every rank.
+
+The compute callables are passed in, so the partition/collective logic is testable on CPU with gloo."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+ALIGN = 64
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def world() -> Tuple[int, int]:
+    return (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
+
+
+@dataclass(frozen=True)
+class SlicePlan:
+    """Equal 64-aligned slices of a length-`padded` vector; `padded` is a multiple of world * 64."""
+
+    total: int
+    world: int
+
+    @property
+    def slice_len(self) -> int:
+        per = (self.total + self.world - 1) // self.world
+        return (per + ALIGN - 1) // ALIGN * ALIGN
+
+    @property
+    def padded(self) -> int:
+        return self.slice_len * self.world
+
+    def bounds(self, rank: int) -> Tuple[int, int]:
+        lo = rank * self.slice_len
+        return lo, lo + self.slice_len
+
+
+def row_blocks(n_rows: int, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous, near-equal [lo, hi) row blocks (first `rem` ranks get one more row)."""
+    q, r = divmod(n_rows, world_size)
+    out, lo = [], 0
+    for i in range(world_size):
+        hi = lo + q + (1 if i < r else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def sharded_merge(merge_slice: Callable[[int, int, torch.Tensor], None], arena: torch.Tensor, plan: SlicePlan,
+                  scratch: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
+    """merge_slice(p_begin, p_count, out_slice) writes this rank's merged slice; all-gather into `arena`
+    (length plan.padded).  world == 1 degenerates to a plain in-place merge."""
+    rank, ws = world()
+    assert arena.numel() == plan.padded, "arena must be allocated with SlicePlan.padded elements"
+    lo, hi = plan.bounds(rank)
+    if ws == 1:
+        merge_slice(lo, hi - lo, arena[lo:hi])
+        return arena
+    if scratch is None:
+        scratch = torch.empty(hi - lo, dtype=arena.dtype, device=arena.device)
+    merge_slice(lo, hi - lo, scratch)
+    dist.all_gather_into_tensor(arena, scratch, group=group)
+    return arena
+
+
+def all_gather_rows(local: torch.Tensor, blocks: Sequence[Tuple[int, int]], group=None) -> torch.Tensor:
+    """Concatenate per-rank row blocks (possibly unequal) in rank order -> (sum rows, d)."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    d = local.shape[1:]
+    mx = max(hi - lo for lo, hi in blocks)
+    pad = torch.zeros((mx, *d), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((ws * mx, *d), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[i * mx : i * mx + (hi - lo)] for i, (lo, hi) in enumerate(blocks)], dim=0)
+
+
+def all_gather_vector(local: torch.Tensor, group=None) -> torch.Tensor:
+    """Variable-length 1-D gather (per-user ranks / lse), rank order preserved."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    ns = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(ns, n, group=group)
+    sizes = [int(x) for x in ns]
+    blocks, lo = [], 0
+    for s in sizes:
+        blocks.append((lo, lo + s))
+        lo += s
+    return all_gather_rows(local.reshape(-1, 1), blocks, group=group).reshape(-1)
