@@ -227,7 +227,13 @@ def run_cpu_baseline(args, spec, layout, base, tv, alpha, W, runner, dev, M, E):
     from oracle import ref_cpu as O
     from mergerec_amd.synthetic import blair_item_lengths, blair_sequence_lengths, _ids_from_lengths
 
-    cores = os.cpu_count() or 1
+    # threads actually used: this process's CPU share (the GPU box exposes 256 logical CPUs but grants a
+    # 16-CPU share per GPU; 256 torch threads oversubscribe it by 16x)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = min(avail, 16)
     torch.set_num_threads(cores)
     n_dom = tv.shape[0]
     base_c, tv_c, a_c = base.cpu(), tv.cpu(), alpha.cpu().reshape(-1)

@@ -94,7 +94,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
 
     for (int kt = 0; kt < nk; ++kt) {
         const float* buf = lds[kt & 1];
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        // Unconditional prefetch (the last iteration harmlessly re-reads tile 0 into the idle buffer): a
+        // conditional load makes hipcc copy the staged registers and wait vmcnt(0) right behind the loads.
+        gload((kt + 1 < nk) ? (kt + 1) * BK : 0);
+        // Pin the prefetch ahead of the MFMA block: left alone, hipcc sinks these loads behind the MFMAs to
+        // reuse the fragment registers and then waits for them at once (memory latency exposed per k-tile).
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         float4 a[2][2], b[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -118,27 +124,41 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(lds[(kt + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the vmcnt wait + LDS stores behind all 32 MFMAs
+        lstore(lds[(kt + 1) & 1]);
         __syncthreads();
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool interior = (m0 + BM <= M) && (n0 + BN <= seg_n);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + lr;
-        if (col >= seg_n) continue;
-        const float bz = bias ? bias[col] : 0.f;
+        const bool col_ok = interior || col < seg_n;
+        const float bz = (bias && col_ok) ? bias[col] : 0.f;
         const int64_t colg = (int64_t)seg * seg_n + col;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            const int rbase = m0 + wm * 64 + i * 32 + 4 * lh;
+            if (interior) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M) {
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
                     float v = acc[i][j][r] + bz;
                     if (ACT == MR_ACT_GELU_ERF) v = gelu_erf(v);
-                    if (HAS_R) v += R[(int64_t)row * ldr + colg];
-                    C[(int64_t)row * ldc + colg] = v;
+                    if (HAS_R) v += R[row * ldr + colg];
+                    C[row * ldc + colg] = v;
+                }
+            } else if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < M) {
+                        float v = acc[i][j][r] + bz;
+                        if (ACT == MR_ACT_GELU_ERF) v = gelu_erf(v);
+                        if (HAS_R) v += R[row * ldr + colg];
+                        C[row * ldc + colg] = v;
+                    }
                 }
             }
         }

@@ -13,7 +13,7 @@ from torch import nn
 
 from .. import ops
 from ..evaluator import Evaluator
-from ..types import BatchItem, BatchSequence
+from ..model_batch import BatchItem, BatchSequence
 
 try:  # pragma: no cover - lightning is not installed in the build image
     import lightning as L

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from .types import BatchItem, BatchSequence
+from .model_batch import BatchItem, BatchSequence
 
 CATALOG_SIZES = {  # M; Arts/Instruments/Office/Scientific are placeholders (datasets absent)
     "Pantry": 4968, "Beauty": 12101, "Sports": 18357, "Toys": 11924,
