@@ -1,13 +1,12 @@
 // K4 / K4b: fused multi-head self-attention over packed tokens, exact fp32 on the matrix cores.
 //
-// One wavefront owns a 32-query tile of one (sequence, head) and walks the key tiles with an online
+// One wavefront owns a 32-query tile of one (sequence, head); the 4 waves of a workgroup cover 128
+// consecutive queries and share the K/V tiles through LDS.  Each wave walks the key tiles with an online
 // softmax.  Scores are computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x2_f32, 32 steps over
 // dh = 64), so the accumulator layout (column = query on the lane, rows = keys in the 16 registers)
 // is already the B operand of the second product O^T = V^T P^T: P never leaves registers and no LDS
-// or cross-lane traffic is needed except one lane^32 exchange for the row max / row sum.  K, Q and V
-// are read straight from global memory in operand layout (Q/K: 128 contiguous bytes per lane;
-// V: 128-byte segments per half-wave), which L2 serves: fp32 MFMA is slow enough (64 clk per
-// instruction) that operand traffic is ~1 B/clk/CU.  Attention is ~6 % of the encoder's FLOPs.
+// round trip or cross-lane traffic is needed for it except one lane^32 exchange for the row max / row sum.
+// Attention is ~6 % of the encoder's FLOPs.
 #include "common.h"
 #include <math.h>
 
@@ -17,111 +16,155 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kThreads = 256;
 constexpr int kDh = 64;
 
+constexpr int kKS = 68;  // K tile row stride in floats: conflict-free ds_read_b128 of 16 distinct rows
+constexpr int kVS = 64;  // V tile row stride (read with ds_read_b32, lanes along d)
+constexpr int kTileFloats = 32 * kKS + 32 * kVS;
+
+// One workgroup = 4 waves = 128 consecutive queries of one (sequence, head); wave w owns queries
+// [q_base + 32w, +32).  All 256 threads stage each 32-key K and V tile through double-buffered LDS
+// (coalesced 256-B rows; the next tile's global loads are issued before the current tile's 64 MFMAs and
+// stored to the idle buffer after them, one barrier per tile), every wave reads its MFMA operands from LDS.
 template <bool WINDOWED>
 __global__ __launch_bounds__(kThreads) void attn_kernel(const float* __restrict__ qkv,
-                                                       const int32_t* __restrict__ cu, int H, float scale,
+                                                       const int32_t* __restrict__ cu, int H, float scale_log2e,
                                                        int window, float* __restrict__ ctx) {
+    __shared__ __attribute__((aligned(16))) float lds[2][kTileFloats];
     const int b = blockIdx.z, h = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 31, lh = lane >> 5;
     const int t0 = cu[b], len = cu[b + 1] - t0;
-    const int q0 = (blockIdx.x * (kThreads / MR_WAVE) + wave) * 32;
-    if (q0 >= len) return;  // whole wave exits together; no barriers in this kernel
+    const int q_base = blockIdx.x * 128;
+    if (q_base >= len) return;  // the whole workgroup leaves together, before any barrier
     const int64_t ld = (int64_t)3 * H * kDh;
     const float* __restrict__ Qb = qkv + (int64_t)t0 * ld + h * kDh;
     const float* __restrict__ Kb = Qb + H * kDh;
     const float* __restrict__ Vb = Qb + 2 * H * kDh;
 
-    // Q as the B operand of S^T = K Q^T: lane (query lr, half lh) holds Q[q][32*lh + s], s = 0..31
+    const int q0 = q_base + wave * 32;
+    const bool wave_active = q0 < len;  // wave-uniform
     const int qi = q0 + lr;
-    const int qrow = qi < len ? qi : len - 1;
+    // Q as the B operand of S^T = K Q^T: lane (query lr, half lh) holds Q[q][32*lh + s], pre-scaled by
+    // scale * log2(e) so that the softmax runs on exp2
     float qv[32];
     {
+        const int qrow = qi < len ? qi : len - 1;
         const float4* qp = reinterpret_cast<const float4*>(Qb + (int64_t)qrow * ld + 32 * lh);
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             const float4 x = qp[v];
-            qv[4 * v + 0] = x.x * scale;
-            qv[4 * v + 1] = x.y * scale;
-            qv[4 * v + 2] = x.z * scale;
-            qv[4 * v + 3] = x.w * scale;
+            qv[4 * v + 0] = x.x * scale_log2e;
+            qv[4 * v + 1] = x.y * scale_log2e;
+            qv[4 * v + 2] = x.z * scale_log2e;
+            qv[4 * v + 3] = x.w * scale_log2e;
         }
     }
 
+    // key-tile schedule of the workgroup
     int k_lo = 0, k_hi = len;
     if (WINDOWED) {
-        k_lo = q0 - window;
+        k_lo = q_base - window;
         k_lo = k_lo < 0 ? 0 : (k_lo & ~31);
-        k_hi = q0 + 31 + window + 1;
+        k_hi = q_base + 127 + window + 1;
         k_hi = k_hi > len ? len : k_hi;
     }
+    const bool extra0 = WINDOWED && k_lo > 0;  // tile 0 carries the global key when the band does not reach it
+    const int ntiles = (k_hi - k_lo + 31) / 32 + (extra0 ? 1 : 0);
+    auto tile_base = [&](int it) { return extra0 ? (it == 0 ? 0 : k_lo + (it - 1) * 32) : k_lo + it * 32; };
+
+    // staging map: thread -> (row sr / sr + 16, 16-byte column sc)
+    const int sr = tid >> 4, sc = (tid & 15) * 4;
+    float4 kreg0, kreg1, vreg0, vreg1;
+    auto gload = [&](int kb) {
+        int r0 = kb + sr, r1 = kb + sr + 16;
+        r0 = r0 < len ? r0 : len - 1;
+        r1 = r1 < len ? r1 : len - 1;
+        kreg0 = *reinterpret_cast<const float4*>(Kb + (int64_t)r0 * ld + sc);
+        kreg1 = *reinterpret_cast<const float4*>(Kb + (int64_t)r1 * ld + sc);
+        vreg0 = *reinterpret_cast<const float4*>(Vb + (int64_t)r0 * ld + sc);
+        vreg1 = *reinterpret_cast<const float4*>(Vb + (int64_t)r1 * ld + sc);
+    };
+    auto lstore = [&](float* buf) {
+        *reinterpret_cast<float4*>(buf + sr * kKS + sc) = kreg0;
+        *reinterpret_cast<float4*>(buf + (sr + 16) * kKS + sc) = kreg1;
+        *reinterpret_cast<float4*>(buf + 32 * kKS + sr * kVS + sc) = vreg0;
+        *reinterpret_cast<float4*>(buf + 32 * kKS + (sr + 16) * kVS + sc) = vreg1;
+    };
+
     float m = -INFINITY, l = 0.f;
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 
-    // key tiles: tile 0 first when the band does not reach it (the global key column), then the band
-    const bool extra0 = WINDOWED && k_lo > 0;
-    const int ntiles = (k_hi - k_lo + 31) / 32 + (extra0 ? 1 : 0);
+    gload(tile_base(0));
+    lstore(lds[0]);
+    __syncthreads();
+
     for (int it = 0; it < ntiles; ++it) {
-        const int kb = extra0 ? (it == 0 ? 0 : k_lo + (it - 1) * 32) : k_lo + it * 32;
-        // ---- S^T tile: A operand = K[kb + lr][32*lh + s]
-        int krow = kb + lr;
-        krow = krow < len ? krow : len - 1;
-        const float4* kp = reinterpret_cast<const float4*>(Kb + (int64_t)krow * ld + 32 * lh);
-        float4 kx[8];
+        const float* buf = lds[it & 1];
+        const int kb = tile_base(it);
+        gload(tile_base(it + 1 < ntiles ? it + 1 : it));  // unconditional: keeps the loads in flight under the MFMAs
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        bool relevant = wave_active;
+        if (WINDOWED) relevant = relevant && (kb == 0 || (kb + 31 >= q0 - window && kb <= q0 + 31 + window));
+        if (relevant) {
+            // ---- S^T tile = K Q^T: A operand = K[kb + lr][32*lh + s] from LDS
+            const float4* kp = reinterpret_cast<const float4*>(buf + lr * kKS + 32 * lh);
+            f32x16 s;
 #pragma unroll
-        for (int v = 0; v < 8; ++v) kx[v] = kp[v];
-        f32x16 s;
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-        for (int v = 0; v < 8; ++v) {
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kx[v].x, qv[4 * v + 0], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kx[v].y, qv[4 * v + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kx[v].z, qv[4 * v + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kx[v].w, qv[4 * v + 3], s, 0, 0, 0);
-        }
-        // ---- mask + online softmax; s[r] is key kb + (r&3) + 8*(r>>2) + 4*lh for query q0 + lr
-        float mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            bool ok = key < len;
-            if (WINDOWED) {
-                const int dlt = qi - key;
-                ok = ok && (key == 0 || (dlt <= window && dlt >= -window));
+            for (int v = 0; v < 8; ++v) {
+                const float4 kx = kp[v];
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kx.x, qv[4 * v + 0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kx.y, qv[4 * v + 1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kx.z, qv[4 * v + 2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kx.w, qv[4 * v + 3], s, 0, 0, 0);
             }
-            s[r] = ok ? s[r] : -INFINITY;
-            mx = fmaxf(mx, s[r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // nothing visible yet: p = 0, corr = 1
-        const float corr = (m == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : expf(m - m_use);
-        float ps = 0.f;
+            // ---- mask + online softmax (base 2); s[r] is key kb + (r&3) + 8*(r>>2) + 4*lh for query q0 + lr
+            float mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = expf(s[r] - m_use);  // exp(-inf) = 0 for masked keys
-            ps += s[r];
-        }
-        ps += __shfl_xor(ps, 32, 64);
-        l = l * corr + ps;
-        m = m_new;
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                bool ok = key < len;
+                if (WINDOWED) {
+                    const int dlt = qi - key;
+                    ok = ok && (key == 0 || (dlt <= window && dlt >= -window));
+                }
+                s[r] = ok ? s[r] : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // nothing visible yet: p = 0, corr = 1
+            const float corr = (m == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : exp2f(m - m_use);
+            float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
-        // ---- O^T += V^T P^T: A operand = V[kb + kappa(r, lh)][dt*32 + lr], B operand = s[r]
+            for (int r = 0; r < 16; ++r) {
+                s[r] = exp2f(s[r] - m_use);  // exp2(-inf) = 0 for masked keys
+                ps += s[r];
+            }
+            ps += __shfl_xor(ps, 32, 64);
+            l = l * corr + ps;
+            m = m_new;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int vrow = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            vrow = vrow < len ? vrow : len - 1;  // p == 0 there
-            const float* vp = Vb + (int64_t)vrow * ld + lr;
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], s[r], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], s[r], o1, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+            // ---- O^T += V^T P^T: A operand = V[kb + kappa(r, lh)][dt*32 + lr] from LDS, B operand = s[r]
+            const float* vp = buf + 32 * kKS + (4 * lh) * kVS + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* vr = vp + ((r & 3) + 8 * (r >> 2)) * kVS;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], s[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], s[r], o1, 0, 0, 0);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(lds[(it + 1) & 1]);
+        __syncthreads();
     }
 
-    if (qi < len && !(WINDOWED && qi == 0)) {
+    if (wave_active && qi < len && !(WINDOWED && qi == 0)) {
         const float inv = 1.0f / l;
         float* op = ctx + (int64_t)(t0 + qi) * ((int64_t)H * kDh) + h * kDh + 4 * lh;
 #pragma unroll
@@ -187,12 +230,12 @@ extern "C" int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, int B, i
     if (dh != kDh) return MR_EUNSUPPORTED;
     if (!mr::aligned16(qkv) || !mr::aligned16(ctx)) return MR_EALIGN;
     if (B == 0 || max_len == 0) return MR_OK;
-    const int qtiles = (max_len + 31) / 32;
-    const dim3 grid((qtiles + 3) / 4, H, B);
+    const dim3 grid((max_len + 127) / 128, H, B);
+    const float scale_log2e = scale * 1.4426950408889634f;
     if (window >= 0)
-        hipLaunchKernelGGL((attn_kernel<true>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, H, scale, window, ctx);
+        hipLaunchKernelGGL((attn_kernel<true>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, H, scale_log2e, window, ctx);
     else
-        hipLaunchKernelGGL((attn_kernel<false>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, H, scale, window, ctx);
+        hipLaunchKernelGGL((attn_kernel<false>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, H, scale_log2e, window, ctx);
     return mr::check_launch();
 }
 
