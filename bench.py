@@ -47,8 +47,8 @@ def parse():
     ap.add_argument("--users-per-step", type=int, default=256)
     ap.add_argument("--items-per-step", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seqs", type=int, default=6)
-    ap.add_argument("--cpu-items", type=int, default=24)
+    ap.add_argument("--cpu-seqs", type=int, default=64)
+    ap.add_argument("--cpu-items", type=int, default=128)
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP-event timing")
     return ap.parse_args()
 
