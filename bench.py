@@ -193,8 +193,20 @@ def main():
             ent["frac"] = ent["achieved"] / ent["peak"]
             kernels[name] = ent
         dom = max(kernels.items(), key=lambda kv: kv[1]["share_of_step"])
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+        # (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950; tools/pmc_summary.py) -- PMC cannot be
+        # collected from inside the timed run.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if world == 1 and os.path.exists(tpath):
+            t = json.load(open(tpath)).get(dom[0])
+            if t:
+                traffic = t["fetch_bytes_x2_per_launch"] + t["write_bytes_per_launch"]
+                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
         roofline = dict(kernel=dom[0], bound=dom[1]["bound"], achieved=dom[1]["achieved"], peak=dom[1]["peak"], unit=dom[1]["unit"],
-                        frac=dom[1]["frac"], traffic=None, launches=dom[1]["launches"], avg_launch_ms=dom[1]["avg_ms"])
+                        frac=dom[1]["frac"], traffic=traffic, traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
+                        algorithmic_bytes_per_launch=ops.PROF.summary()[dom[0]]["bytes"] / max(dom[1]["launches"], 1),
+                        launches=dom[1]["launches"], avg_launch_ms=dom[1]["avg_ms"])
 
     # ---------------- CPU baseline (oracle port, rank 0, N == 1 only) ----------------
     cpu_baseline = None
