@@ -82,10 +82,19 @@ def main():
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; MERGEREC_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals of the N > 1 path
+    backend = os.environ.get("MERGEREC_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks need {world} GPUs, {ndev} visible")
+    local_dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mergerec_amd import ops, parallel
     from mergerec_amd.engine import ArenaLayout, EncoderRunner, EncoderSpec
@@ -174,7 +183,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.PROF.enabled = False
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     value = U_step * world * args.steps / elapsed

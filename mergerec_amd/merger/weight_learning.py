@@ -23,6 +23,24 @@ from .enums import LearnType, MergeType
 StateDict = Dict[str, torch.Tensor]
 
 
+class _MergeFunction(torch.autograd.Function):
+    """a20: the merge as an autograd node.  forward = mr_merge_nway_f32, backward = mr_merge_bwd_alpha_f32
+    (dalpha[s, i] = <tau_i[segment s], dL/dtheta[segment s]>), i.e. the gradient the reference obtains by
+    differentiating task_wise.py:43-47 / layer_wise.py:75-81 inside merge_train.py's training step."""
+
+    @staticmethod
+    def forward(ctx, alpha, base, tv, seg_off, out):
+        ctx.tv, ctx.seg_off = tv, seg_off
+        ops.merge_nway(base, tv, alpha.detach().contiguous(), seg_off, out=out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = grad_out.contiguous()
+        dalpha = ops.merge_bwd_alpha(ctx.tv, g, ctx.seg_off)
+        return dalpha, None, None, None, None
+
+
 def _check_isinstance_state_dict(t):
     """_factory.py:17-25."""
     if not isinstance(t, dict):
@@ -111,6 +129,12 @@ class TaskVectorMergingModuleBase(nn.Module):
         out = self._merged if out is None else out
         return ops.merge_nway(self.base_model_tensor.data, self.task_vectors_tensor.data, self.effective_alpha().detach(),
                               self._seg_off, out=out)
+
+    def merged_params(self) -> torch.Tensor:
+        """Differentiable merge: returns the merged arena vector with an autograd edge back to
+        global_weights / global_biases / per_weights (the backward runs the HIP alpha-gradient kernel)."""
+        return _MergeFunction.apply(self.effective_alpha(), self.base_model_tensor.data, self.task_vectors_tensor.data,
+                                    self._seg_off, torch.empty_like(self._merged))
 
     def load_weights(self):
         self._merge_task_vectors()

@@ -62,6 +62,17 @@ def row_blocks(n_rows: int, world_size: int) -> List[Tuple[int, int]]:
     return out
 
 
+def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """all_gather_into_tensor; with the gloo backend (CPU rehearsals, or several ranks sharing one GPU in tests)
+    device tensors are staged through host memory.  The production backend is "nccl" (= RCCL over xGMI)."""
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_gather_into_tensor(o, i, group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def sharded_merge(merge_slice: Callable[[int, int, torch.Tensor], None], arena: torch.Tensor, plan: SlicePlan,
                   scratch: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
     """merge_slice(p_begin, p_count, out_slice) writes this rank's merged slice; all-gather into `arena`
@@ -75,7 +86,7 @@ def sharded_merge(merge_slice: Callable[[int, int, torch.Tensor], None], arena: 
     if scratch is None:
         scratch = torch.empty(hi - lo, dtype=arena.dtype, device=arena.device)
     merge_slice(lo, hi - lo, scratch)
-    dist.all_gather_into_tensor(arena, scratch, group=group)
+    _all_gather_into(arena, scratch, group=group)
     return arena
 
 
@@ -89,7 +100,7 @@ def all_gather_rows(local: torch.Tensor, blocks: Sequence[Tuple[int, int]], grou
     pad = torch.zeros((mx, *d), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((ws * mx, *d), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    _all_gather_into(out, pad, group=group)
     return torch.cat([out[i * mx : i * mx + (hi - lo)] for i, (lo, hi) in enumerate(blocks)], dim=0)
 
 
@@ -98,9 +109,14 @@ def all_gather_vector(local: torch.Tensor, group=None) -> torch.Tensor:
     rank, ws = world()
     if ws == 1:
         return local
-    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
-    ns = [torch.zeros_like(n) for _ in range(ws)]
-    dist.all_gather(ns, n, group=group)
+    n = torch.tensor([local.numel()], dtype=torch.int64)
+    ns = torch.zeros(ws, dtype=torch.int64)
+    if dist.get_backend(group) == "gloo":
+        dist.all_gather_into_tensor(ns, n, group=group)
+    else:
+        nd = ns.to(local.device)
+        dist.all_gather_into_tensor(nd, n.to(local.device), group=group)
+        ns = nd.cpu()
     sizes = [int(x) for x in ns]
     blocks, lo = [], 0
     for s in sizes:
