@@ -238,7 +238,7 @@ def test_merge_test_cli_synthetic(tmp_path):
     try:
         metrics = merge_test.main(over)
     finally:
-        models.BLaIRBase.SPEC = old
+        models.BLaIRBase.SPEC = staticmethod(old)
     assert set(metrics[0]) >= {"test/NDCG@10", "test/Recall@50", "test/loss"}
     rows = list(csv.DictReader(open(out)))
     assert rows[0]["dataset"] == "Tiny" and float(rows[0]["test/Recall@50"]) == metrics[0]["test/Recall@50"]
