@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def parse():
@@ -50,6 +51,8 @@ def parse():
     ap.add_argument("--cpu-seqs", type=int, default=64)
     ap.add_argument("--cpu-items", type=int, default=128)
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP-event timing")
+    ap.add_argument("--gemm-mode", choices=["bf16x6", "f32"], default=None,
+                    help="encoder GEMM arithmetic: bf16x6 = 6 bf16 MFMA products per fp32 product (default), f32 = exact fp32 MFMA")
     return ap.parse_args()
 
 
@@ -97,7 +100,7 @@ def main():
             dist.init_process_group(backend)
 
     from mergerec_amd import ops, parallel
-    from mergerec_amd.engine import ArenaLayout, EncoderRunner, EncoderSpec
+    from mergerec_amd.engine import ArenaLayout, EncoderRunner, EncoderSpec, WeightSet, default_gemm_mode
     from mergerec_amd.synthetic import blair_item_lengths, blair_sequence_lengths, _ids_from_lengths
 
     spec = EncoderSpec.blair_base()
@@ -111,7 +114,8 @@ def main():
     base, tv = synth_arena(layout, plan.padded, n_dom, dev)
     alpha = torch.full((1, n_dom), 1.0 / n_dom, dtype=torch.float32, device=dev)  # "average" weights
     arena = torch.zeros(plan.padded, dtype=torch.float32, device=dev)
-    W = layout.views(arena)
+    gemm_mode = args.gemm_mode or default_gemm_mode()
+    W = WeightSet(layout, arena[: layout.padded_numel], gemm_mode)
     lo, hi = plan.bounds(rank)
     scratch = torch.empty(hi - lo, dtype=torch.float32, device=dev) if world > 1 else None
 
@@ -129,11 +133,20 @@ def main():
         user_batches.append(({k: v.to(dev) for k, v in ub.items()}, ul))
         item_batches.append(({k: v.to(dev) for k, v in ib.items()}, il))
         label_batches.append(torch.randint(0, M, (U_step,), generator=g).to(dev))
+    # items first, then users, padded to a common length on the host (padding never reaches a kernel)
+    mixed_batches = []
+    for (ib, il), (ub, ul) in zip(item_batches, user_batches):
+        L = max(ib["input_ids"].shape[1], ub["input_ids"].shape[1])
+        pad = lambda t, v: torch.nn.functional.pad(t, (0, L - t.shape[1]), value=v)
+        mixed_batches.append(({"input_ids": torch.cat([pad(ib["input_ids"], spec.pad_id), pad(ub["input_ids"], spec.pad_id)]),
+                               "attention_mask": torch.cat([pad(ib["attention_mask"], 0), pad(ub["attention_mask"], 0)])},
+                              torch.cat([il, ul])))
     avg_user_tokens = float(torch.cat([l for _, l in user_batches]).float().mean())
     avg_item_tokens = float(torch.cat([l for _, l in item_batches]).float().mean())
 
     # full catalog encoded once with the merged model (setup): E (M, d), row == item id
     parallel.sharded_merge(merge_slice, arena, plan, scratch)
+    W.refresh()
     E = torch.empty(M, d, dtype=torch.float32, device=dev)
     gi = torch.Generator().manual_seed(99)
     for s0 in range(0, M, 512):
@@ -149,21 +162,20 @@ def main():
     def step(i):
         # (1) merge (this rank's slice) [+ all-gather]
         parallel.sharded_merge(merge_slice, arena, plan, scratch)
-        # (2) catalog slice refresh
-        ib, il = item_batches[i]
-        e_new = runner.encode(W, ib, dev, normalize=True, lens=il, validate=False)
-        e_all = parallel.all_gather_rows(e_new, item_blocks) if world > 1 else e_new
+        W.refresh()  # bf16x6 mode: re-split the freshly merged arena into its three bf16 piece arenas
+        # (2)+(3) ONE packed encoder pass over [catalog slice ; user sequences] (varlen: no padding is computed)
+        mb, ml = mixed_batches[i]
+        emb = runner.encode(W, mb, dev, normalize=True, lens=ml, validate=False)
+        e_new, u = emb[:I_step], emb[I_step:]
+        e_all = parallel.all_gather_rows(e_new.contiguous(), item_blocks) if world > 1 else e_new
         c = state["cursor"]
         n = e_all.shape[0]
         if c + n > M:
             c = 0
-        E[c : c + n] = e_all
+        E[c : c + n] = e_all  # refresh those catalog rows before scoring
         state["cursor"] = c + n
-        # (3) users
-        ub, ul = user_batches[i]
-        u = runner.encode(W, ub, dev, normalize=True, lens=ul, validate=False)
         # (4) full-catalog scoring + canonical top-50 + CE terms
-        return ops.score_topk(u, E, 50, label_batches[i], 1.0 / 0.05)
+        return ops.score_topk(u.contiguous(), E, 50, label_batches[i], 1.0 / 0.05)
 
     for i in range(args.warmup):
         step(i)
@@ -196,7 +208,11 @@ def main():
             sec = r["ms"] / 1e3
             ent = dict(launches=r["launches"], avg_ms=r["ms"] / max(r["launches"], 1), share_of_step=r["ms"] / (elapsed * 1e3))
             if r["flops"] > 0:
-                ent.update(bound="mfma", achieved=r["flops"] / sec / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
+                if name == "gemm_nt_bf16x6":  # 6 bf16 MFMA flops are executed per algorithmic flop; peak = dense bf16 MFMA
+                    ent.update(bound="mfma", achieved=r["flops"] / sec / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
+                               mfma_flops_per_algorithmic_flop=6, mfma_utilization=6 * r["flops"] / sec / 1e12 / MFMA_BF16_PEAK_TF)
+                else:
+                    ent.update(bound="mfma", achieved=r["flops"] / sec / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
             else:
                 ent.update(bound="hbm", achieved=r["bytes"] / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
             ent["frac"] = ent["achieved"] / ent["peak"]
@@ -212,7 +228,7 @@ def main():
             if t:
                 traffic = t["fetch_bytes_x2_per_launch"] + t["write_bytes_per_launch"]
                 traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
-        roofline = dict(kernel=dom[0], bound=dom[1]["bound"], achieved=dom[1]["achieved"], peak=dom[1]["peak"], unit=dom[1]["unit"],
+        roofline = dict(kernel=dom[0], **{k: dom[1][k] for k in ("mfma_flops_per_algorithmic_flop", "mfma_utilization") if k in dom[1]}, bound=dom[1]["bound"], achieved=dom[1]["achieved"], peak=dom[1]["peak"], unit=dom[1]["unit"],
                         frac=dom[1]["frac"], traffic=traffic, traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=ops.PROF.summary()[dom[0]]["bytes"] / max(dom[1]["launches"], 1),
                         launches=dom[1]["launches"], avg_launch_ms=dom[1]["avg_ms"])
@@ -227,7 +243,8 @@ def main():
         out = OrderedDict(
             metric="sequences/sec full-catalog scoring, 8-domain merged BLaIR-base; NDCG@10 parity",
             value=value, unit="sequences/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-            ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+            ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+            dtype="f32" if gemm_mode == "f32" else "f32 via bf16x6 split MFMA (encoder GEMMs: 6 bf16 products per fp32 product; merge, attention, scoring in f32)",
             data="synthetic",
             config=dict(
                 workload=f"{n_dom}-domain merged BLaIR-base (alpha=1/{n_dom}), full-catalog scoring, Arts-sized catalog",
@@ -287,7 +304,7 @@ def run_cpu_baseline(args, spec, layout, base, tv, alpha, W, runner, dev, M, E):
     # parity of the GPU path on the very same sample
     u_g = runner.encode(W, {k: v.to(dev) for k, v in ub.items()}, dev, normalize=True).cpu()
     e_g = runner.encode(W, {k: v.to(dev) for k, v in ib.items()}, dev, normalize=True).cpu()
-    merged_g = torch.cat([v.reshape(-1) for v in W.values()]).cpu()
+    merged_g = torch.cat([v.reshape(-1) for v in W.views.values()]).cpu()
     merged_cc = torch.cat([v.reshape(-1) for v in sd.values()])
     parity = dict(
         merged_params_bit_exact=bool(torch.equal(merged_g, merged_cc)),

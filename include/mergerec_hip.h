@@ -119,6 +119,23 @@ int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float* w0, const 
                             const float* b0, const float* b1, const float* b2, int nseg, int M, int seg_n, int K,
                             int act, const float* R, int64_t ldr, float* C, int64_t ldc, mr_stream_t stream);
 
+/* Split-precision variant of mr_gemm_nt_bias_act_f32 on the bf16 matrix cores (same math, fp32-grade accuracy,
+ * 2.67x fewer matrix-pipe cycles): every fp32 value x is x = hi + mid + lo with three bf16 pieces and a*b is the
+ * six products hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid accumulated in fp32 (relative error ~2^-24 per
+ * product; NOT bit-identical to the fp32 FMA chain -- the scoring GEMM keeps the exact kernel).
+ * Weights come pre-split: w_hi / w_mid / w_lo are bf16 arrays with the SAME element layout as the fp32 arena
+ * (mr_split_bf16x3_f32 of the whole arena after each merge); segment s is the (seg_n, K) row-major matrix that
+ * starts at element offset off_s (multiple of 8).  Activations A (fp32) are split on the fly.
+ * replaces: the same torch.nn.functional.linear calls as mr_gemm_nt_bias_act_f32. */
+int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t* w_hi, const uint16_t* w_mid,
+                          const uint16_t* w_lo, int64_t off0, int64_t off1, int64_t off2, const float* b0,
+                          const float* b1, const float* b2, int nseg, int M, int seg_n, int K, int act, const float* R,
+                          int64_t ldr, float* C, int64_t ldc, mr_stream_t stream);
+
+/* hi[i] = bf16(x[i]); mid[i] = bf16(x[i] - hi[i]); lo[i] = bf16(x[i] - hi[i] - mid[i])  (round-to-nearest-even;
+ * the subtractions are exact in fp32).  n % 4 == 0.  Run once per merge over the parameter arena. */
+int mr_split_bf16x3_f32(const float* x, int64_t n, uint16_t* hi, uint16_t* mid, uint16_t* lo, mr_stream_t stream);
+
 /* out[t,:] = LayerNorm(x[t,:]) * gamma + beta   (x already holds dense(...) + residual).
  * replaces: the LayerNorm of transformers RobertaSelfOutput / RobertaOutput (post-LN blocks). */
 int mr_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int T, int d,

@@ -1,0 +1,249 @@
+// K3': fp32-accurate GEMM on the bf16 matrix cores ("bf16x6" split precision).
+//
+// Every fp32 operand x is written as x = hi + mid + lo with three bf16 pieces (hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid); the two subtractions are exact in fp32), and a*b is evaluated as the six products
+// hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid (all terms >= 2^-24 relative), each an exact bf16*bf16 product
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Per 32x32x16 tile-step that is 6 MFMAs x 32 clk = 192 clk
+// against 8 x 64 = 512 clk for v_mfma_f32_32x32x2_f32: 2.67x fewer matrix-pipe cycles at fp32-grade accuracy
+// (measured: 12-layer BLaIR-base embeddings within 2e-7 of the fp32 path; tolerance of the path is 1e-4).
+// Weights are pre-split once per merge into three bf16 arenas (mr_split_bf16x3_f32); activations are split while
+// they are staged global -> registers -> LDS.  Structure otherwise as gemm.hip: 128x128x16 block tile, 4 waves
+// (2x2), wave tile 64x64 = 2x2 MFMA tiles, double-buffered LDS, one barrier per k-tile, prefetch pinned ahead of the
+// MFMA block.  LDS rows are 16 bf16 + 8 pad (48 B): the ds_read_b128 of 16 distinct rows is conflict-free.
+#include "common.h"
+#include <stdint.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int ROWB = 48;                 // bytes per LDS row (16 bf16 + pad)
+constexpr int PIECE = 128 * ROWB;        // bytes per (operand, piece) tile
+constexpr int BUF = 6 * PIECE;           // A{hi,mid,lo} B{hi,mid,lo}
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// two fp32 -> one dword of two bf16 (round-to-nearest-even), low half = first argument
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// split 4 fp32 into three pieces of 4 bf16 (2 dwords each)
+__device__ __forceinline__ void split4(const float4 x, uint2& h, uint2& m, uint2& l) {
+    h.x = pack2(x.x, x.y);
+    h.y = pack2(x.z, x.w);
+    const float r0 = x.x - lo_f(h.x), r1 = x.y - hi_f(h.x), r2 = x.z - lo_f(h.y), r3 = x.w - hi_f(h.y);
+    m.x = pack2(r0, r1);
+    m.y = pack2(r2, r3);
+    l.x = pack2(r0 - lo_f(m.x), r1 - hi_f(m.x));
+    l.y = pack2(r2 - lo_f(m.y), r3 - hi_f(m.y));
+}
+
+__global__ __launch_bounds__(kThreads) void split_bf16x3_kernel(const float* __restrict__ x, int64_t n4,
+                                                               uint2* __restrict__ hi, uint2* __restrict__ mid,
+                                                               uint2* __restrict__ lo) {
+    for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < n4; v += (int64_t)gridDim.x * kThreads) {
+        uint2 h, m, l;
+        split4(reinterpret_cast<const float4*>(x)[v], h, m, l);
+        hi[v] = h;
+        mid[v] = m;
+        lo[v] = l;
+    }
+}
+
+template <int ACT, bool HAS_R>
+__global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16x6_kernel(
+    const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ wh, const uint16_t* __restrict__ wm_,
+    const uint16_t* __restrict__ wl, int64_t off0, int64_t off1, int64_t off2, const float* __restrict__ b0,
+    const float* __restrict__ b1, const float* __restrict__ b2, int M, int seg_n, int K,
+    const float* __restrict__ R, int64_t ldr, float* __restrict__ C, int64_t ldc, int tiles_n_seg, int tiles_n,
+    int nwg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUF bytes
+
+    const int pid = mr::xcd_remap(blockIdx.x, nwg);
+    const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
+    const int seg = tn / tiles_n_seg;
+    const int n0 = (tn - seg * tiles_n_seg) * BN;
+    const int m0 = tm * BM;
+    const int64_t woff = seg == 0 ? off0 : (seg == 1 ? off1 : off2);
+    const float* __restrict__ bias = seg == 0 ? b0 : (seg == 1 ? b1 : b2);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // ---- staging maps
+    // A (fp32): thread -> rows sr, sr + 64; k-quad kq (4 consecutive k)
+    const int sr = tid >> 2, kq = tid & 3;
+    int ar0 = m0 + sr, ar1 = m0 + sr + 64;
+    ar0 = ar0 < M ? ar0 : M - 1;
+    ar1 = ar1 < M ? ar1 : M - 1;
+    const float* ga0 = A + (int64_t)ar0 * lda + kq * 4;
+    const float* ga1 = A + (int64_t)ar1 * lda + kq * 4;
+    const int wa0 = sr * ROWB + kq * 8, wa1 = (sr + 64) * ROWB + kq * 8;  // byte offsets inside an A piece
+    // B (pre-split bf16): thread -> row br, 16-byte half bh (8 consecutive k) of each piece
+    const int brow = tid >> 1, bh = tid & 1;
+    int br = n0 + brow;
+    br = br < seg_n ? br : seg_n - 1;
+    const int64_t gboff = woff + (int64_t)br * K + bh * 8;
+    const int wb = brow * ROWB + bh * 16;
+    // fragment read offsets (bytes)
+    const int ra = (wm * 64 + lr) * ROWB + lh * 16;
+    const int rb = (wn * 64 + lr) * ROWB + lh * 16;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 sa0, sa1;
+    uint4 sbh, sbm, sbl;
+    auto gload = [&](int k0) {
+        sa0 = *reinterpret_cast<const float4*>(ga0 + k0);
+        sa1 = *reinterpret_cast<const float4*>(ga1 + k0);
+        sbh = *reinterpret_cast<const uint4*>(wh + gboff + k0);
+        sbm = *reinterpret_cast<const uint4*>(wm_ + gboff + k0);
+        sbl = *reinterpret_cast<const uint4*>(wl + gboff + k0);
+    };
+    auto lstore = [&](unsigned char* buf) {
+        uint2 h, m, l;
+        split4(sa0, h, m, l);
+        *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa0) = h;
+        *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa0) = m;
+        *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa0) = l;
+        split4(sa1, h, m, l);
+        *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa1) = h;
+        *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa1) = m;
+        *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa1) = l;
+        *reinterpret_cast<uint4*>(buf + 3 * PIECE + wb) = sbh;
+        *reinterpret_cast<uint4*>(buf + 4 * PIECE + wb) = sbm;
+        *reinterpret_cast<uint4*>(buf + 5 * PIECE + wb) = sbl;
+    };
+
+    const int nk = K / BK;
+    gload(0);
+    lstore(lds);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char* buf = lds + (kt & 1) * BUF;
+        gload((kt + 1 < nk) ? (kt + 1) * BK : 0);  // unconditional prefetch, see gemm.hip
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[i][p] = *reinterpret_cast<const bf16x8*>(buf + p * PIECE + ra + i * 32 * ROWB);
+                b[i][p] = *reinterpret_cast<const bf16x8*>(buf + (3 + p) * PIECE + rb + i * 32 * ROWB);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 c = acc[i][j];
+                // smallest terms first, hi*hi last
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);  // lo  * hi
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);  // hi  * lo
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);  // mid * mid
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);  // mid * hi
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);  // hi  * mid
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);  // hi  * hi
+                acc[i][j] = c;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(lds + ((kt + 1) & 1) * BUF);
+        __syncthreads();
+    }
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA is dtype independent)
+    const bool interior = (m0 + BM <= M) && (n0 + BN <= seg_n);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + lr;
+        const bool col_ok = interior || col < seg_n;
+        const float bz = (bias && col_ok) ? bias[col] : 0.f;
+        const int64_t colg = (int64_t)seg * seg_n + col;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rbase = m0 + wm * 64 + i * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+                if (interior || (col_ok && row < M)) {
+                    float v = acc[i][j][r] + bz;
+                    if (ACT == MR_ACT_GELU_ERF) v = gelu_erf(v);
+                    if (HAS_R) v += R[row * ldr + colg];
+                    C[row * ldc + colg] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mr_split_bf16x3_f32(const float* x, int64_t n, uint16_t* hi, uint16_t* mid, uint16_t* lo,
+                                   mr_stream_t stream) {
+    if (!x || !hi || !mid || !lo || n < 0) return MR_EINVAL;
+    if ((n & 3) || !mr::aligned16(x) || (reinterpret_cast<uintptr_t>(hi) & 7) || (reinterpret_cast<uintptr_t>(mid) & 7) ||
+        (reinterpret_cast<uintptr_t>(lo) & 7))
+        return MR_EALIGN;
+    if (n == 0) return MR_OK;
+    int64_t blocks = (n / 4 + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, x, n / 4,
+                       reinterpret_cast<uint2*>(hi), reinterpret_cast<uint2*>(mid), reinterpret_cast<uint2*>(lo));
+    return mr::check_launch();
+}
+
+extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t* w_hi, const uint16_t* w_mid,
+                                     const uint16_t* w_lo, int64_t off0, int64_t off1, int64_t off2, const float* b0,
+                                     const float* b1, const float* b2, int nseg, int M, int seg_n, int K, int act,
+                                     const float* R, int64_t ldr, float* C, int64_t ldc, mr_stream_t stream) {
+    if (!A || !w_hi || !w_mid || !w_lo || !C || nseg < 1 || nseg > 3 || M < 0 || seg_n < 1 || K < 1) return MR_EINVAL;
+    if (K % BK) return MR_EUNSUPPORTED;
+    if (nseg > 1 && (seg_n % BN)) return MR_EUNSUPPORTED;
+    if (act != MR_ACT_NONE && act != MR_ACT_GELU_ERF) return MR_EUNSUPPORTED;
+    if ((lda & 3) || !mr::aligned16(A) || !mr::aligned16(w_hi) || !mr::aligned16(w_mid) || !mr::aligned16(w_lo) ||
+        (off0 & 7) || (nseg > 1 && (off1 & 7)) || (nseg > 2 && (off2 & 7)))
+        return MR_EALIGN;
+    if (M == 0) return MR_OK;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_n_seg = (seg_n + BN - 1) / BN;
+    const int tiles_n = tiles_n_seg * nseg;
+    const int64_t nwg64 = (int64_t)tiles_m * tiles_n;
+    if (nwg64 > 0x7fffffff) return MR_EUNSUPPORTED;
+    const int nwg = (int)nwg64;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t shm = 2 * BUF;
+#define MR_GEMM_LAUNCH(ACT_, HASR_)                                                                                      \
+    do {                                                                                                                 \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<ACT_, HASR_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                    \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_>), dim3(nwg), dim3(kThreads), shm, st, A, lda, w_hi, w_mid, \
+                           w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg);   \
+    } while (0)
+    if (act == MR_ACT_GELU_ERF) {
+        if (R) MR_GEMM_LAUNCH(MR_ACT_GELU_ERF, true); else MR_GEMM_LAUNCH(MR_ACT_GELU_ERF, false);
+    } else {
+        if (R) MR_GEMM_LAUNCH(MR_ACT_NONE, true); else MR_GEMM_LAUNCH(MR_ACT_NONE, false);
+    }
+#undef MR_GEMM_LAUNCH
+    return mr::check_launch();
+}

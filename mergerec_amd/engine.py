@@ -173,6 +173,56 @@ class ArenaLayout:
         return groups, seg_off, seg_gid
 
 
+GEMM_MODES = ("f32", "bf16x6")
+
+
+def default_gemm_mode() -> str:
+    """Encoder GEMM arithmetic: "bf16x6" = six bf16 MFMA products per fp32 product (fp32-grade accuracy, 2.67x fewer
+    matrix-pipe cycles; the default), "f32" = exact fp32 MFMA (bit-identical to the oracle's FMA chain)."""
+    import os
+
+    m = os.environ.get("MERGEREC_GEMM_MODE", "bf16x6")
+    if m not in GEMM_MODES:
+        raise ValueError(f"MERGEREC_GEMM_MODE must be one of {GEMM_MODES}")
+    return m
+
+
+class WeightSet:
+    """What the encoder reads: named fp32 views of one arena (+ for "bf16x6" the three bf16 piece arenas that
+    mirror it element for element).  refresh() must be called after the arena's contents change (merge, load)."""
+
+    def __init__(self, layout: "ArenaLayout", flat: torch.Tensor, mode: Optional[str] = None):
+        self.layout, self.flat = layout, flat
+        self.views = layout.views(flat)
+        self.mode = default_gemm_mode() if mode is None else mode
+        if self.mode not in GEMM_MODES:
+            raise ValueError(f"gemm mode must be one of {GEMM_MODES}")
+        self.pieces = None
+        self._n = flat.numel() // 4 * 4
+
+    def __getitem__(self, k):
+        return self.views[k]
+
+    def __contains__(self, k):
+        return k in self.views
+
+    def offset(self, name: str) -> int:
+        return self.layout.offsets[name]
+
+    def refresh(self):
+        if self.mode == "bf16x6":
+            self.pieces = ops.split_bf16x3(self.flat[: self._n], self.pieces)
+        return self
+
+    @staticmethod
+    def from_views(views: Dict[str, torch.Tensor]) -> "WeightSet":
+        """Plain dict of tensors (tests): packs them into a fresh arena."""
+        layout = ArenaLayout(OrderedDict((k, tuple(v.shape)) for k, v in views.items()))
+        dev = next(iter(views.values())).device
+        flat = layout.pack(views, dev)
+        return WeightSet(layout, flat).refresh()
+
+
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class PackedBatch:
@@ -259,15 +309,28 @@ class EncoderRunner:
             w[e + "token_type_embeddings.weight"], w[e + "item_position_embeddings.weight"] if rec else None,
             w[e + "LayerNorm.weight"], w[e + "LayerNorm.bias"], self.spec.ln_eps, ops.EMBED_RECFORMER if rec else ops.EMBED_ROBERTA)
 
+    @staticmethod
+    def _ws(w) -> "WeightSet":
+        return w if isinstance(w, WeightSet) else WeightSet.from_views(dict(w))
+
+    def _linear(self, w: "WeightSet", x, wnames, bnames, act=ops.ACT_NONE, residual=None, out=None):
+        """act(x @ W_s^T + b_s) (+ residual) for 1..3 equally shaped weight segments, in the WeightSet's GEMM mode."""
+        biases = [w[b] for b in bnames]
+        seg_n, K = w[wnames[0]].shape
+        fused = len(wnames) == 1 or seg_n % 128 == 0
+        if not fused:
+            out = torch.empty(x.shape[0], len(wnames) * seg_n, dtype=torch.float32, device=x.device) if out is None else out
+            for i, (wn_, bn_) in enumerate(zip(wnames, bnames)):
+                self._linear(w, x, [wn_], [bn_], act, None, out[:, i * seg_n : (i + 1) * seg_n])
+            return out
+        if w.mode == "bf16x6":
+            if w.pieces is None:
+                w.refresh()
+            return ops.gemm_nt_split(x, w.pieces, [w.offset(n) for n in wnames], seg_n, K, biases, act, residual, out)
+        return ops.gemm_nt(x, [w[n] for n in wnames], biases, act, residual, out)
+
     def _proj(self, w, lp, names, x):
-        ws = [w[f"{lp}attention.self.{n}.weight"] for n in names]
-        bs = [w[f"{lp}attention.self.{n}.bias"] for n in names]
-        if self.fuse_qkv or len(names) == 1:
-            return ops.gemm_nt(x, ws, bs)
-        out = torch.empty(x.shape[0], len(names) * self.spec.hidden, dtype=torch.float32, device=x.device)
-        for i, (wi, bi) in enumerate(zip(ws, bs)):
-            ops.gemm_nt(x, [wi], [bi], out=out[:, i * self.spec.hidden : (i + 1) * self.spec.hidden])
-        return out
+        return self._linear(w, x, [f"{lp}attention.self.{n}.weight" for n in names], [f"{lp}attention.self.{n}.bias" for n in names])
 
     def layer(self, w: Dict[str, torch.Tensor], l: int, x: torch.Tensor, pb: PackedBatch, cls_only: bool = False) -> torch.Tensor:
         """One post-LN transformer block.  cls_only: after attention keep only each sequence's first row
@@ -286,14 +349,16 @@ class EncoderRunner:
         if cls_only:
             ctx = ops.gather_rows(ctx, pb.cls_rows)
             x = ops.gather_rows(x, pb.cls_rows)
-        h = ops.gemm_nt(ctx, [w[lp + "attention.output.dense.weight"]], [w[lp + "attention.output.dense.bias"]], residual=x)
+        h = self._linear(w, ctx, [lp + "attention.output.dense.weight"], [lp + "attention.output.dense.bias"], residual=x)
         h = ops.layernorm(h, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps, out=h)
-        i = ops.gemm_nt(h, [w[lp + "intermediate.dense.weight"]], [w[lp + "intermediate.dense.bias"]], act=ops.ACT_GELU)
-        o = ops.gemm_nt(i, [w[lp + "output.dense.weight"]], [w[lp + "output.dense.bias"]], residual=h)
+        i = self._linear(w, h, [lp + "intermediate.dense.weight"], [lp + "intermediate.dense.bias"], act=ops.ACT_GELU)
+        o = self._linear(w, i, [lp + "output.dense.weight"], [lp + "output.dense.bias"], residual=h)
         return ops.layernorm(o, w[lp + "output.LayerNorm.weight"], w[lp + "output.LayerNorm.bias"], sp.ln_eps, out=o)
 
-    def forward_packed(self, w: Dict[str, torch.Tensor], pb: PackedBatch, normalize: bool, return_hidden: bool = False):
-        """-> (B, d) CLS embeddings (L2-normalised if ``normalize``); optionally every layer's packed hidden."""
+    def forward_packed(self, w, pb: PackedBatch, normalize: bool, return_hidden: bool = False):
+        """-> (B, d) CLS embeddings (L2-normalised if ``normalize``); optionally every layer's packed hidden.
+        ``w`` is a WeightSet (or a plain name -> tensor mapping, packed on the fly)."""
+        w = self._ws(w)
         d = self.spec.hidden
         if pb.B == 0:
             empty = torch.empty(0, d, dtype=torch.float32, device=pb.cu_seqlens.device)

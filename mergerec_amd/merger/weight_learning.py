@@ -138,6 +138,8 @@ class TaskVectorMergingModuleBase(nn.Module):
 
     def load_weights(self):
         self._merge_task_vectors()
+        if hasattr(self.model, "weights_updated"):
+            self.model.weights_updated()
         return self.model
 
     def get_state_dict(self) -> StateDict:

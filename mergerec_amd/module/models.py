@@ -19,7 +19,7 @@ from typing import Dict, Mapping, Optional
 import torch
 from torch import nn
 
-from ..engine import ArenaLayout, EncoderRunner, EncoderSpec
+from ..engine import ArenaLayout, EncoderRunner, EncoderSpec, WeightSet
 
 
 def _resolve_device(model_kwargs) -> torch.device:
@@ -54,8 +54,10 @@ class BaseEncoderModel(nn.Module):
         self.device = _resolve_device(model_kwargs)
         self.runner = EncoderRunner(spec, prefix="model.")
         self.layout = ArenaLayout(spec.param_shapes("model."))
+        self.gemm_mode = model_kwargs.pop("gemm_mode", None)  # None -> MERGEREC_GEMM_MODE or "bf16x6"
         self._flat = torch.zeros(self.layout.padded_numel, dtype=torch.float32, device=self.device)
-        self._views: Dict[str, torch.Tensor] = self.layout.views(self._flat)
+        self._weights = WeightSet(self.layout, self._flat, self.gemm_mode)
+        self._views: Dict[str, torch.Tensor] = self._weights.views
         self.tokenizer = self._load_tokenizer(tokenizer_name_or_path, tokenizer_kwargs or {})
         ckpt_path = model_kwargs.pop("ckpt_path", None)  # Recformer (interface.py:38-41)
         init_seed = model_kwargs.pop("init_seed", None)
@@ -95,6 +97,7 @@ class BaseEncoderModel(nn.Module):
                 if tuple(sd[k].shape) != self.layout.shapes[k]:
                     raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {self.layout.shapes[k]}")
                 self._views[k].copy_(sd[k].to(self._views[k].device, torch.float32))
+        self._weights.refresh()
         return missing, unexpected
 
     def bind_arena(self, layout: ArenaLayout, flat: torch.Tensor):
@@ -104,17 +107,22 @@ class BaseEncoderModel(nn.Module):
         if need:
             raise KeyError(f"arena lacks tensors the encoder reads: {need[:3]}")
         self._flat = flat
-        self._views = layout.views(flat)
+        self._weights = WeightSet(layout, flat, self.gemm_mode)
+        self._views = self._weights.views
+
+    def weights_updated(self):
+        """The bound arena was rewritten in place (a merge): re-derive the bf16 pieces the GEMMs read."""
+        self._weights.refresh()
 
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, batch) -> torch.Tensor:
         if not isinstance(batch, Mapping) and not hasattr(batch, "keys"):
             raise TypeError("Input must be a BatchEncoding object.")  # encoder/_base.py:34-35
-        return self.runner.encode(self._views, batch, self.device, normalize=False)
+        return self.runner.encode(self._weights, batch, self.device, normalize=False)
 
     def encode_normalized(self, batch, normalize: bool, lens=None, validate: bool = True) -> torch.Tensor:
         """forward + F.normalize fused into the pooling kernel (module/recommender/module.py:74-77)."""
-        return self.runner.encode(self._views, batch, self.device, normalize=normalize, lens=lens, validate=validate)
+        return self.runner.encode(self._weights, batch, self.device, normalize=normalize, lens=lens, validate=validate)
 
 
 def random_init_state_dict(spec: EncoderSpec, seed: int, std: float = 0.02) -> "OrderedDict[str, torch.Tensor]":

@@ -185,6 +185,42 @@ def gemm_nt(A: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[O
     return out
 
 
+def split_bf16x3(x: torch.Tensor, pieces=None):
+    """x (fp32, numel % 4 == 0) -> (hi, mid, lo) bf16 tensors of the same length (mr_split_bf16x3_f32)."""
+    _dev(x, "x", torch.float32)
+    n = x.numel()
+    if pieces is None:
+        pieces = tuple(torch.empty(n, dtype=torch.bfloat16, device=x.device) for _ in range(3))
+    ev = PROF.begin(x.device)
+    check(_lib.load().mr_split_bf16x3_f32(ptr(x), n, ptr(pieces[0]), ptr(pieces[1]), ptr(pieces[2]), _stream(x)), "mr_split_bf16x3_f32")
+    PROF.end(ev, x.device, "split_bf16x3", nbytes=n * 10.0)
+    return pieces
+
+
+def gemm_nt_split(A: torch.Tensor, pieces, offsets: Sequence[int], seg_n: int, K: int, biases: Sequence[Optional[torch.Tensor]] = (None,),
+                  act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Split-precision GEMM (6 bf16 MFMA products per fp32 product): weights are addressed as element offsets into the
+    three pre-split bf16 arenas `pieces` = (hi, mid, lo); otherwise the semantics of gemm_nt."""
+    if A.dim() != 2 or A.stride(1) != 1 or A.shape[1] != K:
+        raise ValueError("A must be (M, K) with unit inner stride")
+    nseg = len(offsets)
+    offs = list(offsets) + [0] * (3 - nseg)
+    biases = list(biases) + [None] * (3 - len(biases))
+    M = A.shape[0]
+    out = torch.empty(M, nseg * seg_n, dtype=torch.float32, device=A.device) if out is None else out
+    ev = PROF.begin(A.device)
+    check(
+        _lib.load().mr_gemm_nt_bf16x6_f32(
+            ptr(A), A.stride(0), ptr(pieces[0]), ptr(pieces[1]), ptr(pieces[2]), offs[0], offs[1], offs[2], ptr(biases[0]), ptr(biases[1]),
+            ptr(biases[2]), nseg, M, seg_n, K, act, ptr(residual), 0 if residual is None else residual.stride(0), ptr(out), out.stride(0),
+            _stream(A)),
+        "mr_gemm_nt_bf16x6_f32",
+    )
+    PROF.end(ev, A.device, "gemm_nt_bf16x6", flops=2.0 * M * nseg * seg_n * K,
+             nbytes=4.0 * (M * K + M * nseg * seg_n * (2 if residual is not None else 1)) + 6.0 * nseg * seg_n * K)
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma, beta, eps: float, out=None) -> torch.Tensor:
     T, d = x.shape
     out = torch.empty(T, d, dtype=torch.float32, device=x.device) if out is None else out

@@ -108,6 +108,44 @@ def test_gemm_segments_gelu_residual(ops):
     assert torch.allclose(got, want, atol=2e-6, rtol=1e-6)
 
 
+@pytest.mark.parametrize("M,N,K", [(130, 768, 768), (257, 200, 3072), (64, 333, 16)])
+def test_gemm_bf16x6_split_precision(ops, M, N, K):
+    """6 bf16 products per fp32 product: fp32-grade accuracy (not bit-exact); weights addressed inside split arenas."""
+    g = _g(M * 3 + N + K)
+    A, b = torch.randn(M, K, generator=g), torch.randn(N, generator=g)
+    arena = torch.zeros(64 * 5 + N * K + 64)  # the matrix sits at a non-zero, 64-aligned offset of a bigger arena
+    off = 64 * 5
+    W = torch.randn(N, K, generator=g) * 0.05
+    arena[off : off + N * K] = W.reshape(-1)
+    ad = arena.to(DEV)
+    pieces = ops.split_bf16x3(ad)
+    hi, mid, lo = (p.float().cpu() for p in pieces)
+    assert torch.equal(hi, arena.to(torch.bfloat16).float())
+    assert float((arena - (hi + mid + lo)).abs().max()) <= 2.0 ** -23 * float(arena.abs().max())
+    got = ops.gemm_nt_split(A.to(DEV), pieces, [off], N, K, [b.to(DEV)]).cpu()
+    ref = (A.double() @ W.double().T + b.double())
+    scale = (A.abs().double() @ W.abs().double().T).max()
+    assert float((got.double() - ref).abs().max()) <= 4e-7 * float(scale), float((got.double() - ref).abs().max() / scale)
+    R = torch.randn(M, N, generator=g)
+    got = ops.gemm_nt_split(A.to(DEV), pieces, [off], N, K, [b.to(DEV)], act=ops.ACT_GELU, residual=R.to(DEV)).cpu()
+    want = torch.nn.functional.gelu(ref.float()) + R
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-5)
+
+
+def test_gemm_bf16x6_segments(ops):
+    g = _g(77)
+    M, K, n = 150, 128, 128
+    A = torch.randn(M, K, generator=g)
+    Ws = [torch.randn(n, K, generator=g) * 0.1 for _ in range(3)]
+    bs = [torch.randn(n, generator=g) for _ in range(3)]
+    arena = torch.cat([Ws[0].reshape(-1), torch.zeros(64), Ws[1].reshape(-1), torch.zeros(128), Ws[2].reshape(-1)])
+    offs = [0, n * K + 64, 2 * n * K + 64 + 128]
+    pieces = ops.split_bf16x3(arena.to(DEV))
+    got = ops.gemm_nt_split(A.to(DEV), pieces, offs, n, K, [b.to(DEV) for b in bs]).cpu()
+    want = torch.cat([A @ w.T + b for w, b in zip(Ws, bs)], dim=1)
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-5)
+
+
 # ------------------------------------------------------------------ K2 / LN / pooling
 def _ragged_batch(B, L, vocab, g, pad=1):
     lens = torch.randint(1, L + 1, (B,), generator=g)

@@ -22,8 +22,15 @@ def _spec(cfgd, kind="roberta"):
                        one_sided_window=cfgd["one_sided_window"] if kind == "recformer" else -1)
 
 
-def _dev_weights(sd):
-    return {k: v.to(DEV, torch.float32).contiguous() for k, v in sd.items()}
+def _dev_weights(sd, mode="bf16x6"):
+    from mergerec_amd.engine import ArenaLayout, WeightSet
+
+    views = OrderedDict((k, v.to(torch.float32)) for k, v in sd.items())
+    layout = ArenaLayout(OrderedDict((k, tuple(v.shape)) for k, v in views.items()))
+    return WeightSet(layout, layout.pack(views, DEV), mode).refresh()
+
+
+MODES = ["f32", "bf16x6"]
 
 
 def _unpack(hidden_packed, mask):
@@ -34,12 +41,13 @@ def _unpack(hidden_packed, mask):
 
 
 # ------------------------------------------------------------------ encoder vs reference goldens
-def test_roberta_encoder_matches_library_golden():
+@pytest.mark.parametrize("mode", MODES)
+def test_roberta_encoder_matches_library_golden(mode):
     from mergerec_amd.engine import EncoderRunner
 
     g3 = load_golden("g3_roberta.pt")
     run = EncoderRunner(_spec(g3["cfg"]))
-    w = _dev_weights(g3["state_dict"])
+    w = _dev_weights(g3["state_dict"], mode)
     batch = {"input_ids": g3["input_ids"], "attention_mask": g3["attention_mask"]}
     pb = run.pack(batch, DEV)
     cls, hidden = run.forward_packed(w, pb, normalize=False, return_hidden=True)
@@ -54,7 +62,8 @@ def test_roberta_encoder_matches_library_golden():
     assert torch.allclose(nrm, O.maybe_normalize(g3["cls"]), atol=1e-5)
 
 
-def test_roberta_true_dims_layer_matches_library_golden():
+@pytest.mark.parametrize("mode", MODES)
+def test_roberta_true_dims_layer_matches_library_golden(mode):
     from mergerec_amd.engine import EncoderRunner
 
     big = load_golden("g3_roberta.pt")["big"]
@@ -62,19 +71,20 @@ def test_roberta_true_dims_layer_matches_library_golden():
     sd = O.random_state_dict(O.roberta_param_shapes(cfg), seed=big["seed"], std=big["std"])
     run = EncoderRunner(_spec(big["cfg"]))
     pb = run.pack({"input_ids": big["input_ids"], "attention_mask": big["attention_mask"]}, DEV)
-    _, hidden = run.forward_packed(_dev_weights(sd), pb, normalize=False, return_hidden=True)
+    _, hidden = run.forward_packed(_dev_weights(sd, mode), pb, normalize=False, return_hidden=True)
     m = big["attention_mask"].bool()
     assert torch.allclose(_unpack(hidden[0], big["attention_mask"])[m], big["emb"][m], atol=1e-5)
     got = _unpack(hidden[-1], big["attention_mask"])[m]
     assert torch.allclose(got, big["last"][m], atol=1e-4, rtol=1e-5), (got - big["last"][m]).abs().max()
 
 
-def test_recformer_encoder_matches_reference_golden():
+@pytest.mark.parametrize("mode", MODES)
+def test_recformer_encoder_matches_reference_golden(mode):
     from mergerec_amd.engine import EncoderRunner
 
     for case in load_golden("g4_recformer.pt")["cases"]:
         run = EncoderRunner(_spec(case["cfg"], "recformer"))
-        w = _dev_weights({k: v for k, v in case["state_dict"].items()})
+        w = _dev_weights({k: v for k, v in case["state_dict"].items()}, mode)
         b = case["batch"]
         pb = run.pack(b, DEV)
         cls, hidden = run.forward_packed(w, pb, normalize=False, return_hidden=True)
