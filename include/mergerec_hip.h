@@ -123,9 +123,11 @@ int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float* w0, const 
  * 2.67x fewer matrix-pipe cycles): every fp32 value x is x = hi + mid + lo with three bf16 pieces and a*b is the
  * six products hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid accumulated in fp32 (relative error ~2^-24 per
  * product; NOT bit-identical to the fp32 FMA chain -- the scoring GEMM keeps the exact kernel).
- * Weights come pre-split: w_hi / w_mid / w_lo are bf16 arrays with the SAME element layout as the fp32 arena
- * (mr_split_bf16x3_f32 of the whole arena after each merge); segment s is the (seg_n, K) row-major matrix that
- * starts at element offset off_s (multiple of 8).  Activations A (fp32) are split on the fly.
+ * Weights come pre-split in K-BLOCKED form (mr_split_weights_kblock_f32 after each merge): w_hi / w_mid / w_lo are
+ * bf16 arenas in which the (seg_n, K) matrix of segment s occupies the same element range [off_s, off_s + seg_n*K)
+ * as in the fp32 arena, but element (n, k) sits at off_s + ((k / 16) * seg_n + n) * 16 + k % 16 -- the 128 x 16
+ * tile a workgroup needs per k-step is then one contiguous 4 KB chunk per piece.  off_s % 8 == 0.
+ * Activations A (fp32, row-major) are split on the fly.
  * replaces: the same torch.nn.functional.linear calls as mr_gemm_nt_bias_act_f32. */
 int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t* w_hi, const uint16_t* w_mid,
                           const uint16_t* w_lo, int64_t off0, int64_t off1, int64_t off2, const float* b0,
@@ -135,6 +137,12 @@ int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t* w_hi, con
 /* hi[i] = bf16(x[i]); mid[i] = bf16(x[i] - hi[i]); lo[i] = bf16(x[i] - hi[i] - mid[i])  (round-to-nearest-even;
  * the subtractions are exact in fp32).  n % 4 == 0.  Run once per merge over the parameter arena. */
 int mr_split_bf16x3_f32(const float* x, int64_t n, uint16_t* hi, uint16_t* mid, uint16_t* lo, mr_stream_t stream);
+
+/* Split every weight matrix listed in `table` (device int64, 3 per matrix: arena offset, N, K; K % 16 == 0, offset % 8
+ * == 0) from the fp32 arena into the three bf16 piece arenas in the k-blocked layout mr_gemm_nt_bf16x6_f32 reads.
+ * unit_prefix (device int64, n_mat + 1) holds the exclusive prefix sums of N*K/4; total_units = unit_prefix[n_mat]. */
+int mr_split_weights_kblock_f32(const float* arena, const int64_t* table, const int64_t* unit_prefix, int n_mat,
+                                int64_t total_units, uint16_t* hi, uint16_t* mid, uint16_t* lo, mr_stream_t stream);
 
 /* out[t,:] = LayerNorm(x[t,:]) * gamma + beta   (x already holds dense(...) + residual).
  * replaces: the LayerNorm of transformers RobertaSelfOutput / RobertaOutput (post-LN blocks). */

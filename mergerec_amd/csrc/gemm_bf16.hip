@@ -6,10 +6,14 @@
 // accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Per 32x32x16 tile-step that is 6 MFMAs x 32 clk = 192 clk
 // against 8 x 64 = 512 clk for v_mfma_f32_32x32x2_f32: 2.67x fewer matrix-pipe cycles at fp32-grade accuracy
 // (measured: 12-layer BLaIR-base embeddings within 2e-7 of the fp32 path; tolerance of the path is 1e-4).
-// Weights are pre-split once per merge into three bf16 arenas (mr_split_bf16x3_f32); activations are split while
+// Weights are pre-split once per merge into three bf16 arenas in a K-BLOCKED layout (mr_split_weights_kblock_f32:
+// matrix (N, K) at arena offset off is stored as [K/16][N][16] starting at the same offset), so the B tile a workgroup
+// needs per k-step (128 rows x 16 k) is ONE contiguous 4 KB chunk per piece -- full cache lines instead of 32-byte row
+// fragments (the row-major form ran at half the speed: global-load throughput bound).  Activations are split while
 // they are staged global -> registers -> LDS.  Structure otherwise as gemm.hip: 128x128x16 block tile, 4 waves
 // (2x2), wave tile 64x64 = 2x2 MFMA tiles, double-buffered LDS, one barrier per k-tile, prefetch pinned ahead of the
-// MFMA block.  LDS rows are 16 bf16 + 8 pad (48 B): the ds_read_b128 of 16 distinct rows is conflict-free.
+// MFMA block.  LDS rows are 16 bf16 (32 B, unpadded) with an XOR swizzle of the 16-B halves: conflict-free b128 reads,
+// 48 KB of LDS per workgroup (double-buffered) -> 3 workgroups per CU.
 #include "common.h"
 #include <stdint.h>
 
@@ -19,7 +23,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int ROWB = 48;                 // bytes per LDS row (16 bf16 + pad)
+constexpr int ROWB = 32;                 // bytes per LDS row: 16 bf16, unpadded; the two 16-B halves of rows 8..15 (mod 16)
+                                         // are swapped (chunk ^= (row >> 3) & 1) so a ds_read_b128 of 16 rows is conflict-free
 constexpr int PIECE = 128 * ROWB;        // bytes per (operand, piece) tile
 constexpr int BUF = 6 * PIECE;           // A{hi,mid,lo} B{hi,mid,lo}
 constexpr int kThreads = 256;
@@ -58,8 +63,34 @@ __global__ __launch_bounds__(kThreads) void split_bf16x3_kernel(const float* __r
     }
 }
 
-template <int ACT, bool HAS_R>
-__global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16x6_kernel(
+// table[3*i .. 3*i+2] = (arena offset, N, K) of weight matrix i; unit_prefix[i] = number of 4-element units before it.
+// Each thread converts 4 consecutive k of one row and writes them at the k-blocked position of the three piece arenas.
+__global__ __launch_bounds__(kThreads) void split_weights_kblock_kernel(const float* __restrict__ arena,
+                                                                       const int64_t* __restrict__ table,
+                                                                       const int64_t* __restrict__ unit_prefix, int n_mat,
+                                                                       uint16_t* __restrict__ hi, uint16_t* __restrict__ mid,
+                                                                       uint16_t* __restrict__ lo) {
+    const int64_t total = unit_prefix[n_mat];
+    for (int64_t u = (int64_t)blockIdx.x * kThreads + threadIdx.x; u < total; u += (int64_t)gridDim.x * kThreads) {
+        int a = 0, b = n_mat - 1;  // largest i with unit_prefix[i] <= u
+        while (a < b) {
+            const int c = (a + b + 1) >> 1;
+            if (unit_prefix[c] <= u) a = c; else b = c - 1;
+        }
+        const int64_t off = table[3 * a], N = table[3 * a + 1], K = table[3 * a + 2];
+        const int64_t e = (u - unit_prefix[a]) * 4;  // row-major element index inside the matrix
+        const int64_t n = e / K, k = e - n * K;
+        uint2 h, m, l;
+        split4(*reinterpret_cast<const float4*>(arena + off + e), h, m, l);
+        const int64_t dst = off + ((k >> 4) * N + n) * 16 + (k & 15);
+        *reinterpret_cast<uint2*>(hi + dst) = h;
+        *reinterpret_cast<uint2*>(mid + dst) = m;
+        *reinterpret_cast<uint2*>(lo + dst) = l;
+    }
+}
+
+template <int ACT, bool HAS_R, bool PF2>
+__global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16x6_kernel(
     const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ wh, const uint16_t* __restrict__ wm_,
     const uint16_t* __restrict__ wl, int64_t off0, int64_t off1, int64_t off2, const float* __restrict__ b0,
     const float* __restrict__ b1, const float* __restrict__ b2, int M, int seg_n, int K,
@@ -87,16 +118,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16x6_kernel(
     ar1 = ar1 < M ? ar1 : M - 1;
     const float* ga0 = A + (int64_t)ar0 * lda + kq * 4;
     const float* ga1 = A + (int64_t)ar1 * lda + kq * 4;
-    const int wa0 = sr * ROWB + kq * 8, wa1 = (sr + 64) * ROWB + kq * 8;  // byte offsets inside an A piece
+    const int swz_a = (sr >> 3) & 1;  // same for row sr + 64
+    const int wa0 = sr * ROWB + (((kq >> 1) ^ swz_a) * 16) + (kq & 1) * 8;  // byte offsets inside an A piece
+    const int wa1 = wa0 + 64 * ROWB;
     // B (pre-split bf16): thread -> row br, 16-byte half bh (8 consecutive k) of each piece
     const int brow = tid >> 1, bh = tid & 1;
     int br = n0 + brow;
     br = br < seg_n ? br : seg_n - 1;
-    const int64_t gboff = woff + (int64_t)br * K + bh * 8;
-    const int wb = brow * ROWB + bh * 16;
+    const int64_t gboff = woff + (int64_t)br * 16 + bh * 8;  // k-blocked: element (n, k) lives at off + ((k / 16) * N + n) * 16 + k % 16
+    const int64_t kstep = (int64_t)seg_n;                     // elements per k-tile advance = N * 16 / 16 per unit k -> k0 * N
+    const int wb = brow * ROWB + ((bh ^ ((brow >> 3) & 1)) * 16);
     // fragment read offsets (bytes)
-    const int ra = (wm * 64 + lr) * ROWB + lh * 16;
-    const int rb = (wn * 64 + lr) * ROWB + lh * 16;
+    const int ra = (wm * 64 + lr) * ROWB + ((lh ^ ((lr >> 3) & 1)) * 16);  // rows +32 keep the same swizzle bit
+    const int rb = (wn * 64 + lr) * ROWB + ((lh ^ ((lr >> 3) & 1)) * 16);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -106,40 +140,32 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16x6_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 sa0, sa1;
-    uint4 sbh, sbm, sbl;
-    auto gload = [&](int k0) {
-        sa0 = *reinterpret_cast<const float4*>(ga0 + k0);
-        sa1 = *reinterpret_cast<const float4*>(ga1 + k0);
-        sbh = *reinterpret_cast<const uint4*>(wh + gboff + k0);
-        sbm = *reinterpret_cast<const uint4*>(wm_ + gboff + k0);
-        sbl = *reinterpret_cast<const uint4*>(wl + gboff + k0);
+    struct Stage {  // one k-tile of this thread's global data: 2 float4 of A, 3 x 16 B of pre-split B
+        float4 a0, a1;
+        uint4 bh, bm, bl;
     };
-    auto lstore = [&](unsigned char* buf) {
+    auto gload = [&](Stage& st, int k0) {
+        st.a0 = *reinterpret_cast<const float4*>(ga0 + k0);
+        st.a1 = *reinterpret_cast<const float4*>(ga1 + k0);
+        st.bh = *reinterpret_cast<const uint4*>(wh + gboff + k0 * kstep);
+        st.bm = *reinterpret_cast<const uint4*>(wm_ + gboff + k0 * kstep);
+        st.bl = *reinterpret_cast<const uint4*>(wl + gboff + k0 * kstep);
+    };
+    auto lstore = [&](const Stage& st, unsigned char* buf) {
         uint2 h, m, l;
-        split4(sa0, h, m, l);
+        split4(st.a0, h, m, l);
         *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa0) = h;
         *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa0) = m;
         *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa0) = l;
-        split4(sa1, h, m, l);
+        split4(st.a1, h, m, l);
         *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa1) = h;
         *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa1) = m;
         *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa1) = l;
-        *reinterpret_cast<uint4*>(buf + 3 * PIECE + wb) = sbh;
-        *reinterpret_cast<uint4*>(buf + 4 * PIECE + wb) = sbm;
-        *reinterpret_cast<uint4*>(buf + 5 * PIECE + wb) = sbl;
+        *reinterpret_cast<uint4*>(buf + 3 * PIECE + wb) = st.bh;
+        *reinterpret_cast<uint4*>(buf + 4 * PIECE + wb) = st.bm;
+        *reinterpret_cast<uint4*>(buf + 5 * PIECE + wb) = st.bl;
     };
-
-    const int nk = K / BK;
-    gload(0);
-    lstore(lds);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned char* buf = lds + (kt & 1) * BUF;
-        gload((kt + 1 < nk) ? (kt + 1) * BK : 0);  // unconditional prefetch, see gemm.hip
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+    auto compute = [&](const unsigned char* buf) {
         bf16x8 a[2][3], b[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -162,9 +188,48 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16x6_kernel(
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);  // hi  * hi
                 acc[i][j] = c;
             }
-        __builtin_amdgcn_sched_barrier(0);
-        lstore(lds + ((kt + 1) & 1) * BUF);
+    };
+
+    const int nk = K / BK;
+    auto ktile = [&](int kt) { return (kt < nk ? kt : 0) * BK; };  // past-the-end prefetches re-read tile 0 (never consumed)
+    unsigned char* buf0 = lds;
+    unsigned char* buf1 = lds + BUF;
+    if (PF2) {
+        // Prefetch distance 2 (nk even): a k-tile's global loads are issued two steps before they are split and stored
+        // to LDS, so the store waits on loads that have had two MFMA phases to land (counted vmcnt: the newer tile's
+        // loads stay in flight).  Two named staging sets keep every register index static.
+        Stage s0, s1;
+        gload(s0, 0);
+        lstore(s0, buf0);
+        gload(s1, ktile(1));
+        gload(s0, ktile(2));
         __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            compute(buf0);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(s1, buf1);
+            gload(s1, ktile(kt + 3));
+            __syncthreads();
+            compute(buf1);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(s0, buf0);
+            gload(s0, ktile(kt + 4));
+            __syncthreads();
+        }
+    } else {
+        Stage s0;
+        gload(s0, 0);
+        lstore(s0, buf0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            gload(s0, ktile(kt + 1));  // unconditional prefetch, see gemm.hip
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            compute((kt & 1) ? buf1 : buf0);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(s0, (kt & 1) ? buf0 : buf1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue (C/D layout of the 32x32 MFMA is dtype independent)
@@ -208,6 +273,21 @@ extern "C" int mr_split_bf16x3_f32(const float* x, int64_t n, uint16_t* hi, uint
     return mr::check_launch();
 }
 
+extern "C" int mr_split_weights_kblock_f32(const float* arena, const int64_t* table, const int64_t* unit_prefix, int n_mat,
+                                          int64_t total_units, uint16_t* hi, uint16_t* mid, uint16_t* lo,
+                                          mr_stream_t stream) {
+    if (!arena || !table || !unit_prefix || !hi || !mid || !lo || n_mat < 0 || total_units < 0) return MR_EINVAL;
+    if (!mr::aligned16(arena) || (reinterpret_cast<uintptr_t>(hi) & 15) || (reinterpret_cast<uintptr_t>(mid) & 15) ||
+        (reinterpret_cast<uintptr_t>(lo) & 15))
+        return MR_EALIGN;
+    if (n_mat == 0 || total_units == 0) return MR_OK;
+    int64_t blocks = (total_units + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(split_weights_kblock_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, arena, table,
+                       unit_prefix, n_mat, hi, mid, lo);
+    return mr::check_launch();
+}
+
 extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t* w_hi, const uint16_t* w_mid,
                                      const uint16_t* w_lo, int64_t off0, int64_t off1, int64_t off2, const float* b0,
                                      const float* b1, const float* b2, int nseg, int M, int seg_n, int K, int act,
@@ -227,17 +307,15 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
     if (nwg64 > 0x7fffffff) return MR_EUNSUPPORTED;
     const int nwg = (int)nwg64;
     hipStream_t st = (hipStream_t)stream;
-    const size_t shm = 2 * BUF;
-#define MR_GEMM_LAUNCH(ACT_, HASR_)                                                                                      \
-    do {                                                                                                                 \
-        static bool attr_set = false;                                                                                    \
-        if (!attr_set) {                                                                                                 \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<ACT_, HASR_>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                    \
-            attr_set = true;                                                                                             \
-        }                                                                                                                \
-        hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_>), dim3(nwg), dim3(kThreads), shm, st, A, lda, w_hi, w_mid, \
-                           w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg);   \
+    const size_t shm = 2 * BUF;  // 49,152 B: within the default dynamic-LDS limit
+    const bool pf2 = ((K / BK) % 2 == 0);
+#define MR_GEMM_LAUNCH3(ACT_, HASR_, PF2_)                                                                                   \
+    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_>), dim3(nwg), dim3(kThreads), shm, st, A, lda, w_hi, w_mid, \
+                       w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg)
+#define MR_GEMM_LAUNCH(ACT_, HASR_)                         \
+    do {                                                    \
+        if (pf2) MR_GEMM_LAUNCH3(ACT_, HASR_, true);        \
+        else MR_GEMM_LAUNCH3(ACT_, HASR_, false);           \
     } while (0)
     if (act == MR_ACT_GELU_ERF) {
         if (R) MR_GEMM_LAUNCH(MR_ACT_GELU_ERF, true); else MR_GEMM_LAUNCH(MR_ACT_GELU_ERF, false);
@@ -245,5 +323,6 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
         if (R) MR_GEMM_LAUNCH(MR_ACT_NONE, true); else MR_GEMM_LAUNCH(MR_ACT_NONE, false);
     }
 #undef MR_GEMM_LAUNCH
+#undef MR_GEMM_LAUNCH3
     return mr::check_launch();
 }

@@ -198,7 +198,7 @@ class WeightSet:
         if self.mode not in GEMM_MODES:
             raise ValueError(f"gemm mode must be one of {GEMM_MODES}")
         self.pieces = None
-        self._n = flat.numel() // 4 * 4
+        self._table = None
 
     def __getitem__(self, k):
         return self.views[k]
@@ -211,7 +211,11 @@ class WeightSet:
 
     def refresh(self):
         if self.mode == "bf16x6":
-            self.pieces = ops.split_bf16x3(self.flat[: self._n], self.pieces)
+            if self._table is None:  # every 2-D tensor a Linear reads (not the embedding tables), K % 16 == 0
+                ent = [(self.layout.offsets[k], shp[0], shp[1]) for k, shp in self.layout.shapes.items()
+                       if len(shp) == 2 and "embeddings" not in k and shp[1] % 16 == 0]
+                self._table = ops.KBlockTable(ent, self.flat.device)
+            self.pieces = ops.split_weights_kblock(self.flat, self._table, self.pieces)
         return self
 
     @staticmethod

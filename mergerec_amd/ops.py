@@ -197,10 +197,41 @@ def split_bf16x3(x: torch.Tensor, pieces=None):
     return pieces
 
 
+class KBlockTable:
+    """Device table of the weight matrices to pre-split: rows (arena offset, N, K)."""
+
+    def __init__(self, entries, device):
+        ent = [(int(o), int(n), int(k)) for o, n, k in entries]
+        for o, n, k in ent:
+            if k % 16 or o % 8:
+                raise ValueError("k-blocked split needs K % 16 == 0 and offset % 8 == 0")
+        self.n_mat = len(ent)
+        units = [n * k // 4 for _, n, k in ent]
+        pref = [0]
+        for u in units:
+            pref.append(pref[-1] + u)
+        self.total_units = pref[-1]
+        self.table = torch.tensor([x for e in ent for x in e], dtype=torch.int64, device=device)
+        self.prefix = torch.tensor(pref, dtype=torch.int64, device=device)
+        self.bytes = sum(n * k for _, n, k in ent) * 10.0  # 4 B read + 3 x 2 B written per element
+
+
+def split_weights_kblock(flat: torch.Tensor, table: KBlockTable, pieces=None):
+    """fp32 arena -> three bf16 piece arenas (same length) holding the listed matrices in k-blocked form."""
+    _dev(flat, "flat", torch.float32)
+    if pieces is None:
+        pieces = tuple(torch.zeros(flat.numel(), dtype=torch.bfloat16, device=flat.device) for _ in range(3))
+    ev = PROF.begin(flat.device)
+    check(_lib.load().mr_split_weights_kblock_f32(ptr(flat), ptr(table.table), ptr(table.prefix), table.n_mat, table.total_units,
+                                                  ptr(pieces[0]), ptr(pieces[1]), ptr(pieces[2]), _stream(flat)), "mr_split_weights_kblock_f32")
+    PROF.end(ev, flat.device, "split_weights", nbytes=table.bytes)
+    return pieces
+
+
 def gemm_nt_split(A: torch.Tensor, pieces, offsets: Sequence[int], seg_n: int, K: int, biases: Sequence[Optional[torch.Tensor]] = (None,),
                   act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Split-precision GEMM (6 bf16 MFMA products per fp32 product): weights are addressed as element offsets into the
-    three pre-split bf16 arenas `pieces` = (hi, mid, lo); otherwise the semantics of gemm_nt."""
+    three pre-split, K-BLOCKED bf16 arenas `pieces` = (hi, mid, lo) (split_weights_kblock); otherwise as gemm_nt."""
     if A.dim() != 2 or A.stride(1) != 1 or A.shape[1] != K:
         raise ValueError("A must be (M, K) with unit inner stride")
     nseg = len(offsets)

@@ -118,10 +118,14 @@ def test_gemm_bf16x6_split_precision(ops, M, N, K):
     W = torch.randn(N, K, generator=g) * 0.05
     arena[off : off + N * K] = W.reshape(-1)
     ad = arena.to(DEV)
-    pieces = ops.split_bf16x3(ad)
-    hi, mid, lo = (p.float().cpu() for p in pieces)
+    flat_pieces = ops.split_bf16x3(ad)
+    hi, mid, lo = (p.float().cpu() for p in flat_pieces)
     assert torch.equal(hi, arena.to(torch.bfloat16).float())
     assert float((arena - (hi + mid + lo)).abs().max()) <= 2.0 ** -23 * float(arena.abs().max())
+    pieces = ops.split_weights_kblock(ad, ops.KBlockTable([(off, N, K)], DEV))
+    # k-blocked layout: element (n, k) at off + ((k // 16) * N + n) * 16 + k % 16
+    kb = pieces[0].float().cpu()[off : off + N * K].view(K // 16, N, 16).permute(1, 0, 2).reshape(N, K)
+    assert torch.equal(kb, W.to(torch.bfloat16).float())
     got = ops.gemm_nt_split(A.to(DEV), pieces, [off], N, K, [b.to(DEV)]).cpu()
     ref = (A.double() @ W.double().T + b.double())
     scale = (A.abs().double() @ W.abs().double().T).max()
@@ -140,7 +144,7 @@ def test_gemm_bf16x6_segments(ops):
     bs = [torch.randn(n, generator=g) for _ in range(3)]
     arena = torch.cat([Ws[0].reshape(-1), torch.zeros(64), Ws[1].reshape(-1), torch.zeros(128), Ws[2].reshape(-1)])
     offs = [0, n * K + 64, 2 * n * K + 64 + 128]
-    pieces = ops.split_bf16x3(arena.to(DEV))
+    pieces = ops.split_weights_kblock(arena.to(DEV), ops.KBlockTable([(o, n, K) for o in offs], DEV))
     got = ops.gemm_nt_split(A.to(DEV), pieces, offs, n, K, [b.to(DEV) for b in bs]).cpu()
     want = torch.cat([A @ w.T + b for w, b in zip(Ws, bs)], dim=1)
     assert torch.allclose(got, want, atol=2e-5, rtol=1e-5)
