@@ -222,12 +222,12 @@ def main():
         # (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950; tools/pmc_summary.py) -- PMC cannot be
         # collected from inside the timed run.
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{gemm_mode}.json")
         if world == 1 and os.path.exists(tpath):
             t = json.load(open(tpath)).get(dom[0])
             if t:
                 traffic = t["fetch_bytes_x2_per_launch"] + t["write_bytes_per_launch"]
-                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+                traffic_src = f"profiles/r01_pmc_traffic_{gemm_mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
         roofline = dict(kernel=dom[0], **{k: dom[1][k] for k in ("mfma_flops_per_algorithmic_flop", "mfma_utilization") if k in dom[1]}, bound=dom[1]["bound"], achieved=dom[1]["achieved"], peak=dom[1]["peak"], unit=dom[1]["unit"],
                         frac=dom[1]["frac"], traffic=traffic, traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=ops.PROF.summary()[dom[0]]["bytes"] / max(dom[1]["launches"], 1),

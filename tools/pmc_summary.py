@@ -6,8 +6,10 @@ FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coal
 Only the dispatches of the timed region are used: the last `launches_per_step * n_timed_steps` of each family."""
 import collections, csv, glob, json, sys
 
-FAMILIES = {"gemm_nt_kernel": ("gemm_nt", 96), "attn_kernel": ("attention", 24), "merge_nway_kernel": ("merge_nway", 1),
-            "embed_gather_ln_kernel": ("embed_gather_ln", 2), "layernorm_kernel": ("layernorm", 48), "topk_rows_kernel": ("topk_rows", 1)}
+# kernel-name substring -> (family name used by bench.py's LaunchProfiler, launches per bench step)
+FAMILIES = {"gemm_nt_bf16x6_kernel": ("gemm_nt_bf16x6", 48), "gemm_nt_kernel": ("gemm_nt", 48), "attn_kernel": ("attention", 12),
+            "merge_nway_kernel": ("merge_nway", 1), "split_weights_kblock_kernel": ("split_weights", 1),
+            "embed_gather_ln_kernel": ("embed_gather_ln", 1), "layernorm_kernel": ("layernorm", 24), "topk_rows_kernel": ("topk_rows", 1)}
 
 
 def load(d, counter):
@@ -19,6 +21,7 @@ def load(d, counter):
         for key, (fam, _) in FAMILIES.items():
             if key in r["Kernel_Name"]:
                 per[fam].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+                break
     return per
 
 
