@@ -153,14 +153,15 @@ int mr_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const floa
 
 /* Multi-head self-attention over packed tokens.  qkv is (T, 3*H*dh): [q | k | v] per token, head h at
  * columns h*dh.  ctx is (T, H*dh).  dh == 64.  Keys of a sequence are its own tokens only.
+ * seq_order (int32, B entries, may be NULL): a permutation of the sequence ids, heaviest first -- scheduling hint only.
  * window < 0  : full attention   softmax(q k^T * scale) v                     (RoBERTa / BLaIR)
  * window >= 0 : Longformer local attention with the first token of every sequence global:
  *               query i >= 1 sees key j iff j == 0 or |i - j| <= window; row 0 is NOT written
  *               (it is produced by mr_attn_global_row_f32 from the *_global projections).
  * replaces: transformers RobertaSelfAttention.forward (eager/sdpa) and LongformerSelfAttention.forward
  *           (sliding_chunks + global key column), reached from recformer/models.py:340-348. */
-int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, int B, int H, int dh, int max_len, float scale,
-                int window, float* ctx, mr_stream_t stream);
+int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh, int max_len,
+                float scale, int window, float* ctx, mr_stream_t stream);
 
 /* Global-token row of Longformer attention: for each sequence b, ctx[cu[b], :] =
  * softmax(qg_b kg^T * scale) vg over all tokens of b, where qg is (B, H*dh) (the global query of

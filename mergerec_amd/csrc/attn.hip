@@ -25,11 +25,13 @@ constexpr int kTileFloats = 32 * kKS + 32 * kVS;
 // (coalesced 256-B rows; the next tile's global loads are issued before the current tile's 64 MFMAs and
 // stored to the idle buffer after them, one barrier per tile), every wave reads its MFMA operands from LDS.
 template <bool WINDOWED>
-__global__ __launch_bounds__(kThreads) void attn_kernel(const float* __restrict__ qkv,
-                                                       const int32_t* __restrict__ cu, int H, float scale_log2e,
-                                                       int window, float* __restrict__ ctx) {
+__global__ __launch_bounds__(kThreads, 4) void attn_kernel(const float* __restrict__ qkv,
+                                                       const int32_t* __restrict__ cu,
+                                                       const int32_t* __restrict__ seq_order, int H,
+                                                       float scale_log2e, int window, float* __restrict__ ctx) {
     __shared__ __attribute__((aligned(16))) float lds[2][kTileFloats];
-    const int b = blockIdx.z, h = blockIdx.y;
+    // seq_order (optional): sequence ids by decreasing length, so the heaviest workgroups are dispatched first
+    const int b = seq_order ? seq_order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 31, lh = lane >> 5;
     const int t0 = cu[b], len = cu[b + 1] - t0;
@@ -224,8 +226,8 @@ __global__ __launch_bounds__(MR_WAVE) void attn_global_row_kernel(const float* _
 
 }  // namespace
 
-extern "C" int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, int B, int H, int dh, int max_len, float scale,
-                           int window, float* ctx, mr_stream_t stream) {
+extern "C" int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh,
+                           int max_len, float scale, int window, float* ctx, mr_stream_t stream) {
     if (!qkv || !cu_seqlens || !ctx || B < 0 || H < 1 || max_len < 0) return MR_EINVAL;
     if (dh != kDh) return MR_EUNSUPPORTED;
     if (!mr::aligned16(qkv) || !mr::aligned16(ctx)) return MR_EALIGN;
@@ -233,9 +235,9 @@ extern "C" int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, int B, i
     const dim3 grid((max_len + 127) / 128, H, B);
     const float scale_log2e = scale * 1.4426950408889634f;
     if (window >= 0)
-        hipLaunchKernelGGL((attn_kernel<true>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, H, scale_log2e, window, ctx);
+        hipLaunchKernelGGL((attn_kernel<true>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, seq_order, H, scale_log2e, window, ctx);
     else
-        hipLaunchKernelGGL((attn_kernel<false>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, H, scale_log2e, window, ctx);
+        hipLaunchKernelGGL((attn_kernel<false>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, seq_order, H, scale_log2e, window, ctx);
     return mr::check_launch();
 }
 

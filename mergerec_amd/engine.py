@@ -242,6 +242,7 @@ class PackedBatch:
     tok_tt: Optional[torch.Tensor] = None
     tok_ip: Optional[torch.Tensor] = None
     sum_len_sq: float = 0.0  # sum_b L_b^2 (algorithmic attention work, for the profiler)
+    seq_order: Optional[torch.Tensor] = None  # int32 (B): sequence ids by decreasing length (attention scheduling hint)
 
 
 def _lens_from_mask(attention_mask: torch.Tensor) -> torch.Tensor:
@@ -302,7 +303,8 @@ class EncoderRunner:
         dev = lambda t: None if t is None else t.to(device, torch.int64, non_blocking=True).contiguous()
         tw, tp, ttp, tip = ops.pack_tokens(dev(ids), dev(mask), cu_d, T, self.spec.pad_id, dev(tt), dev(ip))
         return PackedBatch(B=B, T=T, max_len=int(lens.max()) if B else 0, cu_seqlens=cu_d, cls_rows=cu_d[:-1].contiguous(),
-                           tok_word=tw, tok_pos=tp, tok_tt=ttp, tok_ip=tip, sum_len_sq=float((lens.double() ** 2).sum()) if B else 0.0)
+                           tok_word=tw, tok_pos=tp, tok_tt=ttp, tok_ip=tip, sum_len_sq=float((lens.double() ** 2).sum()) if B else 0.0,
+                           seq_order=torch.argsort(lens, descending=True, stable=True).to(torch.int32).to(device, non_blocking=True) if B > 1 else None)
 
     # ---- forward ---------------------------------------------------------------------------------
     def embed(self, w: Dict[str, torch.Tensor], pb: PackedBatch) -> torch.Tensor:
@@ -344,7 +346,8 @@ class EncoderRunner:
         if ops.PROF.enabled:
             w_ = sp.one_sided_window
             ops.ATTN_FLOPS_HINT[0] = 4.0 * sp.hidden * (pb.sum_len_sq if sp.kind != "recformer" else pb.T * (2 * w_ + 2))
-        ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=sp.one_sided_window if sp.kind == "recformer" else -1)
+        ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=sp.one_sided_window if sp.kind == "recformer" else -1,
+                            seq_order=pb.seq_order)
         if sp.kind == "recformer":
             x_cls = ops.gather_rows(x, pb.cls_rows)
             qg = self._proj(w, lp, ("query_global",), x_cls)

@@ -264,12 +264,13 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float, out=None) -> torch.Tenso
 ATTN_FLOPS_HINT = [0.0]  # algorithmic 4 * sum(L_b^2) * d of the next attention launch (set by the engine)
 
 
-def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, window: int = -1, out=None) -> torch.Tensor:
+def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, window: int = -1, out=None,
+              seq_order: Optional[torch.Tensor] = None) -> torch.Tensor:
     T = qkv.shape[0]
     dh = qkv.shape[1] // (3 * H)
     out = torch.empty(T, H * dh, dtype=torch.float32, device=qkv.device) if out is None else out
     ev = PROF.begin(qkv.device)
-    check(_lib.load().mr_attn_f32(ptr(qkv), ptr(cu_seqlens), B, H, dh, max_len, dh ** -0.5, window, ptr(out), _stream(qkv)), "mr_attn_f32")
+    check(_lib.load().mr_attn_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, ptr(out), _stream(qkv)), "mr_attn_f32")
     PROF.end(ev, qkv.device, "attention", flops=ATTN_FLOPS_HINT[0], nbytes=4.0 * T * 4 * H * dh)
     ATTN_FLOPS_HINT[0] = 0.0
     return out
