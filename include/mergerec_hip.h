@@ -76,6 +76,34 @@ size_t mr_merge_bwd_alpha_ws_bytes(int N, int S, int64_t P);
 int mr_merge_bwd_alpha_f32(const float* tv, int64_t tv_stride, const float* g, const int64_t* seg_off, int N, int S,
                            int64_t P, float* dalpha, void* ws, size_t ws_bytes, mr_stream_t stream);
 
+/* ---- task-vector pre-processing at init (TIES / Localize-and-Stitch) ------------------------ */
+
+/* T = the k-th largest |x[i]| over i < n (1 <= k <= n), by exact radix select: *thr_bits = float bits of T and
+ * *need_eq = how many elements with |x| == T belong to the top-k (both written to DEVICE memory; no host sync).
+ * ws: mr_select_ws_bytes(n) bytes, 16-byte aligned.
+ * replaces: the threshold implied by torch.topk(update.abs(), k) in merger/algorithms/ties.py:21 and
+ *           merger/algorithms/localize_and_stitch.py:40. */
+size_t mr_select_ws_bytes(int64_t n);
+int mr_abs_kth_largest_f32(const float* x, int64_t n, int64_t k, uint32_t* thr_bits, int64_t* need_eq, void* ws,
+                           size_t ws_bytes, mr_stream_t stream);
+
+/* y[i] = x[i] if x[i] is among the k largest magnitudes (|x| > T, or |x| == T and fewer than need_eq equal elements
+ * precede i: ties resolved towards LOWER indices; torch.topk leaves that choice unspecified), else 0;
+ * mask_or_null[i] = 1 / 0 likewise.  thr_bits / need_eq come from mr_abs_kth_largest_f32 (device memory).
+ * replaces: merger/algorithms/ties.py:21-23 (sparse_update) and localize_and_stitch.py:40-42 (masks). */
+int mr_abs_topk_mask_f32(const float* x, int64_t n, const uint32_t* thr_bits, const int64_t* need_eq, float* y,
+                         uint8_t* mask_or_null, void* ws, size_t ws_bytes, mr_stream_t stream);
+
+/* In place on sparse (N rows of length P, row stride `stride`): sign election by summed positive / negative mass,
+ * keep the entries that agree with the elected sign, divide by their count (0/0 -> 0); sums run sequentially over
+ * the task index exactly like torch's dim-0 sum.
+ * replaces: merger/algorithms/ties.py:31-72 (_compute_final_sign + disjoint mean of get_ties_vectors). */
+int mr_ties_combine_f32(float* sparse, int64_t stride, int N, int64_t P, mr_stream_t stream);
+
+/* out[i, p] = (mask[i, p] / max(sum_j mask[j, p], 1)) * tv[i, p]   (two separate roundings, as torch computes it).
+ * replaces: merger/algorithms/localize_and_stitch.py:43-49. */
+int mr_lns_combine_f32(const float* tv, const uint8_t* mask, int64_t stride, int N, int64_t P, float* out, mr_stream_t stream);
+
 /* ---- encoder: token packing + embeddings --------------------------------------------------- */
 
 /* From the reference's padded batch tensors (int64 (B, L), row-major) build packed per-token index

@@ -35,6 +35,11 @@ SIGNATURES = {
     "mr_merge_nway_f32": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i, c_i, c_i64, c_i64, c_p, c_p]),
     "mr_merge_bwd_alpha_ws_bytes": (c_sz, [c_i, c_i, c_i64]),
     "mr_merge_bwd_alpha_f32": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_sz, c_p]),
+    "mr_select_ws_bytes": (c_sz, [c_i64]),
+    "mr_abs_kth_largest_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_sz, c_p]),
+    "mr_abs_topk_mask_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "mr_ties_combine_f32": (c_i, [c_p, c_i64, c_i, c_i64, c_p]),
+    "mr_lns_combine_f32": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_p, c_p]),
     "mr_pack_tokens": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mr_embed_gather_ln_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p]),
     "mr_gemm_nt_bias_act_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p]),

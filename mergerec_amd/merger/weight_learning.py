@@ -222,18 +222,39 @@ def load_merging_module(
     base = layout.pack(pre, device)
     n = len(finetune_state_dicts)
     tv = torch.empty(n, layout.padded_numel, dtype=torch.float32, device=device)
+    stage = torch.empty(layout.padded_numel, dtype=torch.float32, device=device)
+    for i, ckpt in enumerate(finetune_state_dicts):
+        layout.pack(ckpt, device, out=stage)
+        ops.task_vector(stage, base, out=tv[i])  # algorithms/task_vector.py:8-10
+    del stage
     if merge_type is MergeType.TASK_VECTOR:
-        stage = torch.empty(layout.padded_numel, dtype=torch.float32, device=device)
-        for i, ckpt in enumerate(finetune_state_dicts):
-            layout.pack(ckpt, device, out=stage)
-            ops.task_vector(stage, base, out=tv[i])  # algorithms/task_vector.py:8-10
-        del stage
-    elif merge_type in (MergeType.TIES, MergeType.PCB, MergeType.LOCALIZE_AND_STITCH):
+        pass
+    elif merge_type in (MergeType.TIES, MergeType.LOCALIZE_AND_STITCH):
         if merge_type is MergeType.TIES:
             assert ties_density is not None, "Density should be provided for ties merging."
+        density = ties_density if ties_density is not None else 0.05  # L&S default (localize_and_stitch.py:9)
+        # k counts the reference's flat length (no arena pads); pads are zeros and can only tie with true zeros,
+        # whose selection never changes a result (ties.py:16, localize_and_stitch.py:33)
+        k = int(density * layout.numel)
+        if merge_type is MergeType.TIES:
+            for i in range(n):
+                ops.abs_topk_mask(tv[i], k, out=tv[i])  # ties.py:15-25
+            ops.ties_combine(tv)                           # ties.py:31-72
+        else:
+            if k <= 0:
+                tv.zero_()
+            else:
+                masks = torch.empty(n, layout.padded_numel, dtype=torch.uint8, device=device)
+                scratch = torch.empty(layout.padded_numel, dtype=torch.float32, device=device)
+                for i in range(n):
+                    _, m = ops.abs_topk_mask(tv[i], k, out=scratch, want_mask=True)
+                    masks[i].copy_(m)
+                ops.lns_combine(tv, masks, out=tv)          # localize_and_stitch.py:43-49
+                del masks, scratch
+    elif merge_type is MergeType.PCB:
         raise NotImplementedError(
-            f"{merge_type.name} task-vector pre-processing (one-shot, at init) is the next row of the hot-path scope "
-            "(SURVEY 8(f).1); only MergeType.TASK_VECTOR is built"
+            "PCB task-vector pre-processing (two per-row quantile clamps + exp/tanh maps, one-shot at init) is not built yet "
+            "(SURVEY 8(f).1); TASK_VECTOR, TIES and LOCALIZE_AND_STITCH are"
         )
     else:
         raise ValueError(f"Invalid merge type: {merge_type}")

@@ -123,6 +123,44 @@ def merge_bwd_alpha(tv: torch.Tensor, g: torch.Tensor, seg_off: Optional[torch.T
     return out
 
 
+def abs_topk_mask(x: torch.Tensor, k: int, out: Optional[torch.Tensor] = None, want_mask: bool = False):
+    """y = x where |x| is among the k largest of the vector (ties at the threshold -> lowest indices), else 0.
+    Returns (y, mask uint8 or None).  Exact radix select + ordered tie ranking on the device, no host sync."""
+    _dev(x, "x", torch.float32)
+    n = x.numel()
+    y = torch.empty_like(x) if out is None else out
+    m = torch.empty(n, dtype=torch.uint8, device=x.device) if want_mask else None
+    if k <= 0:
+        y.zero_()
+        if m is not None:
+            m.zero_()
+        return y, m
+    lib = _lib.load()
+    nbytes = lib.mr_select_ws_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    thr = torch.empty(1, dtype=torch.int32, device=x.device)
+    need = torch.empty(1, dtype=torch.int64, device=x.device)
+    check(lib.mr_abs_kth_largest_f32(ptr(x), n, min(k, n), ptr(thr), ptr(need), ptr(ws), nbytes, _stream(x)), "mr_abs_kth_largest_f32")
+    check(lib.mr_abs_topk_mask_f32(ptr(x), n, ptr(thr), ptr(need), ptr(y), ptr(m), ptr(ws), nbytes, _stream(x)), "mr_abs_topk_mask_f32")
+    return y, m
+
+
+def ties_combine(sparse: torch.Tensor) -> torch.Tensor:
+    """In place on (N, P) masked updates: TIES sign election + disjoint mean."""
+    _dev(sparse, "sparse", torch.float32)
+    N, P = sparse.shape
+    check(_lib.load().mr_ties_combine_f32(ptr(sparse), sparse.stride(0), N, P, _stream(sparse)), "mr_ties_combine_f32")
+    return sparse
+
+
+def lns_combine(tv: torch.Tensor, mask: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(tv, "tv", torch.float32), _dev(mask, "mask", torch.uint8)
+    N, P = tv.shape
+    out = torch.empty_like(tv) if out is None else out
+    check(_lib.load().mr_lns_combine_f32(ptr(tv), ptr(mask), tv.stride(0), N, P, ptr(out), _stream(tv)), "mr_lns_combine_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ encoder
 def pack_tokens(input_ids, attention_mask, cu_seqlens, T: int, pad_id: int, token_type_ids=None, item_position_ids=None):
     _dev(input_ids, "input_ids", torch.int64), _dev(attention_mask, "attention_mask", torch.int64)

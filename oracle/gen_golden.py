@@ -327,6 +327,28 @@ def main():
     torch.save(g4, OUT / "g4_recformer.pt")
     print("G4 ok", g4["cases"][0]["cls"][0, :4])
 
+    # ------------------------------------------------------------------ G6 task-vector pre-processing (8(f).1)
+    from rec_retrieval.merger.algorithms.ties import get_ties_vectors
+    from rec_retrieval.merger.algorithms.localize_and_stitch import get_localize_and_stitch_vectors
+    from rec_retrieval.merger.algorithms.pcb import get_pcb_vectors
+
+    g6 = dict(cases=[])
+    for ci, (Pn, Nn, dens) in enumerate([(20000, 3, 0.2), (5000, 5, 0.05), (4096, 2, 0.5)]):
+        gg = torch.Generator().manual_seed(600 + ci)
+        base6 = torch.randn(Pn, generator=gg) * 0.02
+        models6 = [base6 + torch.randn(Pn, generator=gg) * 1e-3 for _ in range(Nn)]
+        models6[0][100:140] = base6[100:140]          # exact zeros in a task vector
+        if ci == 0:
+            models6[1][:50] = base6[:50] + 0.25       # a block of equal large magnitudes well inside the top-k (never at the threshold)
+        g6["cases"].append(dict(
+            base=base6, models=models6, density=dens,
+            ties=get_ties_vectors(base_model=base6, models=models6, density=dens).clone(),
+            lns=get_localize_and_stitch_vectors(base_model=base6, models=models6, density=dens).clone(),
+            pcb=get_pcb_vectors(base_model=base6, models=models6, density=dens).clone(),
+        ))
+    torch.save(g6, OUT / "g6_taskvector_algos.pt")
+    print("G6 ok", g6["cases"][0]["ties"].abs().sum().item())
+
     for f in sorted(OUT.glob("*.pt")):
         print(f.name, f.stat().st_size)
 

@@ -127,6 +127,76 @@ def merge_bwd_alpha(tv: torch.Tensor, grad: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------
+# 8(f).1: task-vector pre-processing run once at init (TIES, Localize-and-Stitch, PCB)
+# --------------------------------------------------------------------------------------------
+
+
+def topk_abs_mask(x: torch.Tensor, k: int) -> torch.Tensor:
+    """Boolean mask of the k largest |x| (ties at the threshold resolved towards LOWER indices -- torch.topk leaves
+    that order unspecified; algorithms/ties.py:21, localize_and_stitch.py:40)."""
+    if k <= 0:
+        return torch.zeros_like(x, dtype=torch.bool)
+    order = torch.sort(x.abs(), descending=True, stable=True).indices[:k]
+    m = torch.zeros_like(x, dtype=torch.bool)
+    m[order] = True
+    return m
+
+
+def ties_vectors(base: torch.Tensor, models: Sequence[torch.Tensor], density: float) -> torch.Tensor:
+    """algorithms/ties.py:8-72 -- per-model top-(density*P) by |tau|, sign election by summed mass, disjoint mean."""
+    k = int(density * base.numel())
+    sparse = []
+    for m in models:
+        u = m - base
+        keep = topk_abs_mask(u, k)
+        sparse.append(torch.where(keep, u, torch.zeros_like(u)))
+    sp = torch.stack(sparse, 0)
+    zero = torch.zeros_like(sp)
+    pos_sum = torch.where(sp > 0, sp, zero).sum(0)
+    neg_sum = torch.where(sp < 0, sp, zero).sum(0)
+    conflict = (pos_sum != 0) & (neg_sum != 0)
+    sign = torch.where(conflict, torch.where(pos_sum.abs() >= neg_sum.abs(), 1.0, -1.0), torch.sign(pos_sum + neg_sum))
+    sign = torch.where(sign == 0, torch.ones_like(sign), sign)
+    sel = torch.where(sign.unsqueeze(0) > 0, torch.where(sp > 0, sp, zero), torch.where(sp < 0, sp, zero))
+    cnt = torch.count_nonzero(sel, dim=0).unsqueeze(0)
+    return (sel / cnt).nan_to_num(0.0)
+
+
+def localize_and_stitch_vectors(base: torch.Tensor, models: Sequence[torch.Tensor], density: float) -> torch.Tensor:
+    """algorithms/localize_and_stitch.py:8-49 -- top-k masks, overlap-normalised: (mask_i / max(sum_j mask_j, 1)) * tau_i."""
+    upd = torch.stack([m - base for m in models], 0)
+    k = int(density * upd.shape[1])
+    if k <= 0:
+        return torch.zeros_like(upd)
+    masks = torch.stack([topk_abs_mask(u, k) for u in upd], 0).to(upd.dtype)
+    denom = masks.sum(0).clamp(min=1.0)
+    return (masks / denom) * upd
+
+
+def pcb_vectors(base: torch.Tensor, models: Sequence[torch.Tensor], density: float = 0.2) -> torch.Tensor:
+    """algorithms/pcb.py:8-58."""
+    tv = torch.stack([m - base for m in models], 0)
+    n, d = tv.shape
+
+    def clamp_rows(x, lo, hi):
+        srt = torch.sort(x, dim=1).values
+        return torch.maximum(torch.minimum(x, srt[:, int(d * (1 - hi) - 1)].unsqueeze(1)), srt[:, int(d * lo)].unsqueeze(1))
+
+    def normalize(x):
+        mn, mx = x.min(1, keepdim=True).values, x.max(1, keepdim=True).values
+        return (x - mn) / (mx - mn)
+
+    a = clamp_rows(tv.abs(), 0.01, 0.01)
+    clamped = torch.sign(tv) * a
+    self_act = torch.exp(n * normalize(a) ** 2)
+    cross_act = torch.tanh(tv * tv.sum(0))
+    scale = normalize(clamp_rows(self_act * cross_act, 1 - density, 0))
+    out = clamped * scale
+    out = out / torch.clamp(scale.sum(0, keepdim=True), min=1e-12)
+    return out / n
+
+
+# --------------------------------------------------------------------------------------------
 # a8/a11/a13/a14: RoBERTa (BLaIR) encoder; the reference delegates to transformers RobertaModel
 # via module/models/encoder/_base.py:32-39.  Restated from the library's published architecture.
 # --------------------------------------------------------------------------------------------

@@ -134,3 +134,13 @@ def test_recformer_matches_reference():
 def test_position_ids():
     ids = torch.tensor([[0, 5, 1, 7, 1, 1], [0, 2, 1, 1, 1, 1]])
     assert O.position_ids_from_input_ids(ids, 1).tolist() == [[2, 3, 1, 4, 1, 1], [2, 3, 1, 1, 1, 1]]
+
+
+# ------------------------------------------------------------------ G6: TIES / Localize-and-Stitch / PCB (8(f).1)
+def test_taskvector_algorithms_match_reference():
+    for case in load_golden("g6_taskvector_algos.pt")["cases"]:
+        base, models, dens = case["base"], case["models"], case["density"]
+        assert torch.equal(O.ties_vectors(base, models, dens), case["ties"])
+        assert torch.equal(O.localize_and_stitch_vectors(base, models, dens), case["lns"])
+        got = O.pcb_vectors(base, models, dens)
+        assert torch.allclose(got, case["pcb"], rtol=1e-5, atol=1e-9), (got - case["pcb"]).abs().max()

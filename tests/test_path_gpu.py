@@ -153,7 +153,9 @@ def test_merging_module_errors_mirror_reference():
     with pytest.raises(AssertionError):
         mm.load_weights_from_dict({"global_weights": {"nope": [1.0]}, "global_biases": {}, "per_weights": {}})
     with pytest.raises(NotImplementedError):
-        load_merging_module(MergeType.TIES, LearnType.TASK_WISE, model, g2["pretrain"], [dict(f) for f in g2["finetunes"]], set(), ties_density=0.2)
+        load_merging_module(MergeType.PCB, LearnType.TASK_WISE, model, g2["pretrain"], [dict(f) for f in g2["finetunes"]], set(), ties_density=0.2)
+    with pytest.raises(AssertionError):
+        load_merging_module(MergeType.TIES, LearnType.TASK_WISE, _tiny_model(g2["cfg"]), g2["pretrain"], [dict(f) for f in g2["finetunes"]], set())
 
 
 # ------------------------------------------------------------------ the whole path vs the oracle
@@ -291,3 +293,57 @@ def test_merge_autograd_alpha_gradient():
             assert torch.allclose(mm.per_weights[k].grad.cpu(), per.grad, rtol=1e-3, atol=1e-3 * scale), (k, mm.per_weights[k].grad, per.grad)
             assert torch.allclose(mm.global_weights[k].grad.cpu(), gw.grad, rtol=1e-3, atol=1e-3 * scale)
             assert torch.allclose(mm.global_biases[k].grad.cpu(), gb.grad, rtol=1e-3, atol=1e-3 * scale)
+
+
+# ------------------------------------------------------------------ 8(f).1: TIES / Localize-and-Stitch pre-processing
+def test_ties_and_lns_kernels_match_reference_golden():
+    from mergerec_amd import ops
+
+    for case in load_golden("g6_taskvector_algos.pt")["cases"]:
+        base, models, dens = case["base"], case["models"], case["density"]
+        P, N = base.numel(), len(models)
+        k = int(dens * P)
+        tv = torch.stack([m - base for m in models]).to(DEV)
+        # top-k mask: exactly k kept, equal to the oracle's lowest-index tie rule
+        y, m = ops.abs_topk_mask(tv[0].contiguous(), k, want_mask=True)
+        want = O.topk_abs_mask(tv[0].cpu(), k)
+        assert int(m.sum()) == k and torch.equal(m.cpu().bool(), want)
+        sp = torch.stack([ops.abs_topk_mask(tv[i].contiguous(), k)[0] for i in range(N)])
+        got = ops.ties_combine(sp).cpu()
+        assert torch.equal(got, case["ties"]), (got - case["ties"]).abs().max()
+        masks = torch.stack([ops.abs_topk_mask(tv[i].contiguous(), k, want_mask=True)[1] for i in range(N)])
+        got = ops.lns_combine(tv.contiguous(), masks).cpu()
+        assert torch.equal(got, case["lns"]), (got - case["lns"]).abs().max()
+
+
+def test_topk_mask_ties_at_threshold_and_sizes():
+    from mergerec_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    for n, k in [(5, 2), (2048, 2048), (70001, 14000), (4097, 1)]:
+        x = torch.randn(n, generator=g)
+        x[torch.randperm(n, generator=g)[: n // 3]] = 0.5  # a large block of exact ties that straddles the threshold
+        x[::7] *= -1
+        y, m = ops.abs_topk_mask(x.to(DEV), k, want_mask=True)
+        want = O.topk_abs_mask(x, k)
+        assert int(m.sum()) == k
+        assert torch.equal(m.cpu().bool(), want)
+        assert torch.equal(y.cpu(), torch.where(want, x, torch.zeros_like(x)))
+
+
+@pytest.mark.parametrize("merge_type", ["TIES", "LOCALIZE_AND_STITCH"])
+def test_load_merging_module_ties_lns(merge_type):
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+
+    g2 = load_golden("g2_merger.pt")
+    model = _tiny_model(g2["cfg"])
+    fts = [dict(f) for f in g2["finetunes"]]
+    mm = load_merging_module(MergeType[merge_type], LearnType.TASK_WISE, model, g2["pretrain"], fts, set(), ties_density=0.2,
+                             disable_softmax=True, initial_per_weight=0.4)
+    pre, al = O.align_state_dicts(g2["pretrain"], g2["finetunes"])
+    base, _ = O.flatten_model(pre)
+    models = [O.flatten_model(f)[0] for f in al]
+    want_tv = O.ties_vectors(base, models, 0.2) if merge_type == "TIES" else O.localize_and_stitch_vectors(base, models, 0.2)
+    assert torch.equal(mm.compact_task_vectors().cpu(), want_tv)
+    merged = torch.cat([v.reshape(-1) for v in mm.get_state_dict().values()]).cpu()
+    assert torch.equal(merged, O.merge_task_wise(base, want_tv, torch.full((3,), 0.4)))
