@@ -104,3 +104,45 @@ def load_domain(spec: str, kind: str = "roberta", vocab: int = 50265, seed: int 
         )
     d = torch.load(f, map_location="cpu")
     return TokenizedDomain(p.name if p.is_dir() else p.stem, d["items"], d["sequences"], d["labels"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+_PAD_VALUES = {"input_ids": 1, "attention_mask": 0, "token_type_ids": 3, "item_position_ids": 0, "global_attention_mask": 0}
+
+
+def _cat_encodings(encs, pad_id: int = 1):
+    L = max(e["input_ids"].shape[1] for e in encs)
+    out = {}
+    for k in encs[0].keys():
+        rows = []
+        for e in encs:
+            t = e[k]
+            if t.shape[1] < L:
+                t = torch.nn.functional.pad(t, (0, L - t.shape[1]), value=pad_id if k == "input_ids" else _PAD_VALUES.get(k, 0))
+            rows.append(t)
+        out[k] = torch.cat(rows)
+    return out
+
+
+def coalesce_batches(batches, max_tokens: int = 65536, pad_id: int = 1):
+    """Merge consecutive BatchItem / BatchSequence objects into larger ones of up to ~max_tokens attended tokens.
+    The kernels work on packed tokens (padding never reaches them), so the per-sequence results are unchanged; only
+    the launch granularity changes (a 32-sequence batch fills less than one wave of GEMM workgroups on 256 CUs)."""
+    buf, tokens = [], 0
+
+    def flush():
+        first = buf[0]
+        if isinstance(first, BatchItem):
+            return BatchItem(items=_cat_encodings([b.items for b in buf], pad_id))
+        return BatchSequence(sequence=_cat_encodings([b.sequence for b in buf], pad_id), labels=torch.cat([b.labels for b in buf]))
+
+    for b in batches:
+        enc = b.items if isinstance(b, BatchItem) else b.sequence
+        n = int(enc["attention_mask"].sum())
+        if buf and tokens + n > max_tokens:
+            yield flush()
+            buf, tokens = [], 0
+        buf.append(b)
+        tokens += n
+    if buf:
+        yield flush()

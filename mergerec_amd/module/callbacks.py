@@ -14,6 +14,11 @@ class ItemEncoderMixin:
         train_status = pl_module.training
         pl_module.eval()
         out = []
+        tokens = getattr(getattr(pl_module, "trainer", None), "coalesce_tokens", 65536)
+        if tokens:
+            from ..data import coalesce_batches
+
+            item_dataloader = coalesce_batches(item_dataloader, tokens)
         for batch in item_dataloader:
             out.append(pl_module.forward(batch.to(pl_module.device)))
         pl_module.train(train_status)

@@ -34,10 +34,11 @@ class Trainer:
     """``lightning.Trainer(...).test(module, dataloader)`` hook order: callbacks' on_test_epoch_start,
     module.on_test_epoch_start, test_step per batch (moved to the module's device), on_test_epoch_end."""
 
-    def __init__(self, precision: str = "32-true", callbacks: Sequence = (), **_):
+    def __init__(self, precision: str = "32-true", callbacks: Sequence = (), coalesce_tokens: int = 65536, **_):
         if precision not in ("32-true", "32", 32):
             raise NotImplementedError("the HIP path computes in fp32 (parity configuration); bf16-mixed is not built")
         self.callbacks = list(callbacks)
+        self.coalesce_tokens = coalesce_tokens  # 0: one kernel pass per dataloader batch, like the reference
 
     @torch.no_grad()
     def test(self, module: RecModule, dataloader: Iterable, verbose: bool = False) -> List[Dict[str, float]]:
@@ -47,7 +48,10 @@ class Trainer:
             if hasattr(cb, "on_test_epoch_start"):
                 cb.on_test_epoch_start(self, module)
         module.on_test_epoch_start()
-        for i, batch in enumerate(dataloader):
+        from .data import coalesce_batches
+
+        stream = coalesce_batches(dataloader, self.coalesce_tokens) if self.coalesce_tokens else dataloader
+        for i, batch in enumerate(stream):
             module.test_step(batch.to(module.device), i)
         metrics = module.on_test_epoch_end()
         return [dict(metrics)]

@@ -347,3 +347,28 @@ def test_load_merging_module_ties_lns(merge_type):
     assert torch.equal(mm.compact_task_vectors().cpu(), want_tv)
     merged = torch.cat([v.reshape(-1) for v in mm.get_state_dict().values()]).cpu()
     assert torch.equal(merged, O.merge_task_wise(base, want_tv, torch.full((3,), 0.4)))
+
+
+def test_coalesced_batches_give_identical_results():
+    """Macro-batching of the dataloader stream (padding-invariant kernels) must not change any per-sequence result."""
+    from mergerec_amd.data import coalesce_batches
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.module import ModelType, RecModule
+    from mergerec_amd.synthetic import make_domain
+    from mergerec_amd.utils import Trainer
+    from mergerec_amd.module.callbacks import ItemEncodingCallback
+
+    over = dict(hidden=128, heads=2, layers=2, intermediate=256, vocab=300, max_pos=200)
+    model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 3, "spec_overrides": over, "device": DEV, "gemm_mode": "f32"})
+    dom = make_domain("Toy", n_items=150, n_users=90, batch_size=16, vocab=300, seed=4, max_seq_len=150, item_len_scale=0.3)
+    assert len(list(coalesce_batches(dom.sequence_batches, 2000))) < len(dom.sequence_batches)
+    res = []
+    for tokens in (0, 2000, 1 << 20):
+        module = RecModule(model=model, evaluator=Evaluator(["NDCG", "RECALL"], [1, 5, 10, 50]), similarity="cosine")
+        cb = ItemEncodingCallback(dom.item_batches)
+        tr = Trainer(callbacks=[cb], coalesce_tokens=tokens)
+        m = tr.test(module, dom.sequence_batches)[0]
+        res.append((m, module.item_embeddings.detach().cpu().clone(), module.eval_user_embeddings.clone(), module.eval_topk_indices.clone()))
+    for m, e, u, idx in res[1:]:
+        assert m == res[0][0]
+        assert torch.equal(e, res[0][1]) and torch.equal(u, res[0][2]) and torch.equal(idx, res[0][3])
