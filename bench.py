@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--cpu-seqs", type=int, default=64)
     ap.add_argument("--cpu-items", type=int, default=128)
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP-event timing")
-    ap.add_argument("--gemm-mode", choices=["bf16x6", "f32"], default=None,
-                    help="encoder GEMM arithmetic: bf16x6 = 6 bf16 MFMA products per fp32 product (default), f32 = exact fp32 MFMA")
+    ap.add_argument("--gemm-mode", choices=["bf16x6", "bf16x3", "f32"], default=None,
+                    help="encoder GEMM arithmetic: bf16x3 (bench default) / bf16x6 = 3 / 6 bf16 MFMA products per fp32 product, "
+                         "f32 = exact fp32 MFMA.  The in-run `parity` object reports the distance to the CPU oracle for the chosen mode.")
     return ap.parse_args()
 
 
@@ -114,7 +115,9 @@ def main():
     base, tv = synth_arena(layout, plan.padded, n_dom, dev)
     alpha = torch.full((1, n_dom), 1.0 / n_dom, dtype=torch.float32, device=dev)  # "average" weights
     arena = torch.zeros(plan.padded, dtype=torch.float32, device=dev)
-    gemm_mode = args.gemm_mode or default_gemm_mode()
+    # bench default: the fastest arithmetic that meets the path's 1e-4 logit tolerance with >= 50x margin on these dims
+    # (bf16x3: measured 1.1e-6 on embeddings, 6e-7 on logits); MERGEREC_GEMM_MODE / --gemm-mode select the others
+    gemm_mode = args.gemm_mode or os.environ.get("MERGEREC_GEMM_MODE") or "bf16x3"
     W = WeightSet(layout, arena[: layout.padded_numel], gemm_mode)
     lo, hi = plan.bounds(rank)
     scratch = torch.empty(hi - lo, dtype=torch.float32, device=dev) if world > 1 else None
@@ -208,9 +211,10 @@ def main():
             sec = r["ms"] / 1e3
             ent = dict(launches=r["launches"], avg_ms=r["ms"] / max(r["launches"], 1), share_of_step=r["ms"] / (elapsed * 1e3))
             if r["flops"] > 0:
-                if name == "gemm_nt_bf16x6":  # 6 bf16 MFMA flops are executed per algorithmic flop; peak = dense bf16 MFMA
+                if name in ("gemm_nt_bf16x6", "gemm_nt_bf16x3"):  # 6 (3) bf16 MFMA flops are executed per algorithmic flop; peak = dense bf16 MFMA
+                    np_ = 6 if name.endswith("x6") else 3
                     ent.update(bound="mfma", achieved=r["flops"] / sec / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
-                               mfma_flops_per_algorithmic_flop=6, mfma_utilization=6 * r["flops"] / sec / 1e12 / MFMA_BF16_PEAK_TF)
+                               mfma_flops_per_algorithmic_flop=np_, mfma_utilization=np_ * r["flops"] / sec / 1e12 / MFMA_BF16_PEAK_TF)
                 else:
                     ent.update(bound="mfma", achieved=r["flops"] / sec / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
             else:
@@ -224,7 +228,7 @@ def main():
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{gemm_mode}.json")
         if world == 1 and os.path.exists(tpath):
-            t = json.load(open(tpath)).get(dom[0])
+            t = json.load(open(tpath)).get("gemm_nt_bf16x" if dom[0].startswith("gemm_nt_bf16x") else dom[0])
             if t:
                 traffic = t["fetch_bytes_x2_per_launch"] + t["write_bytes_per_launch"]
                 traffic_src = f"profiles/r01_pmc_traffic_{gemm_mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
@@ -244,7 +248,7 @@ def main():
             metric="sequences/sec full-catalog scoring, 8-domain merged BLaIR-base; NDCG@10 parity",
             value=value, unit="sequences/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype="f32" if gemm_mode == "f32" else "f32 via bf16x6 split MFMA (encoder GEMMs: 6 bf16 products per fp32 product; merge, attention, scoring in f32)",
+            dtype="f32" if gemm_mode == "f32" else f"f32 via {gemm_mode} split MFMA (encoder GEMMs: {gemm_mode[-1]} bf16 products per fp32 product; merge, attention, scoring in f32)",
             data="synthetic",
             config=dict(
                 workload=f"{n_dom}-domain merged BLaIR-base (alpha=1/{n_dom}), full-catalog scoring, Arts-sized catalog",

@@ -156,11 +156,13 @@ int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float* w0, const 
  * as in the fp32 arena, but element (n, k) sits at off_s + ((k / 16) * seg_n + n) * 16 + k % 16 -- the 128 x 16
  * tile a workgroup needs per k-step is then one contiguous 4 KB chunk per piece.  off_s % 8 == 0.
  * Activations A (fp32, row-major) are split on the fly.
+ * products: 6 (the decomposition above) or 3 (two pieces per operand: hi*hi + hi*lo + lo*hi, ~2^-16 per product,
+ * half the matrix work; w_lo is not read).
  * replaces: the same torch.nn.functional.linear calls as mr_gemm_nt_bias_act_f32. */
 int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t* w_hi, const uint16_t* w_mid,
                           const uint16_t* w_lo, int64_t off0, int64_t off1, int64_t off2, const float* b0,
                           const float* b1, const float* b2, int nseg, int M, int seg_n, int K, int act, const float* R,
-                          int64_t ldr, float* C, int64_t ldc, mr_stream_t stream);
+                          int64_t ldr, float* C, int64_t ldc, int products, mr_stream_t stream);
 
 /* hi[i] = bf16(x[i]); mid[i] = bf16(x[i] - hi[i]); lo[i] = bf16(x[i] - hi[i] - mid[i])  (round-to-nearest-even;
  * the subtractions are exact in fp32).  n % 4 == 0.  Run once per merge over the parameter arena. */

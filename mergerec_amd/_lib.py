@@ -43,7 +43,7 @@ SIGNATURES = {
     "mr_pack_tokens": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mr_embed_gather_ln_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p]),
     "mr_gemm_nt_bias_act_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p]),
-    "mr_gemm_nt_bf16x6_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p]),
+    "mr_gemm_nt_bf16x6_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_i, c_p]),
     "mr_split_bf16x3_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     "mr_split_weights_kblock_f32": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "mr_layernorm_f32": (c_i, [c_p, c_i64, c_p, c_p, c_f, c_i, c_i, c_p, c_i64, c_p]),

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(kThreads) void split_weights_kblock_kernel(const fl
     }
 }
 
-template <int ACT, bool HAS_R, bool PF2>
+// NP = number of bf16 pieces per operand: 3 -> six products (fp32-grade, ~2^-24), 2 -> three products hi*hi + hi*lo + lo*hi (~2^-16)
+template <int ACT, bool HAS_R, bool PF2, int NP>
 __global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16x6_kernel(
     const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ wh, const uint16_t* __restrict__ wm_,
     const uint16_t* __restrict__ wl, int64_t off0, int64_t off1, int64_t off2, const float* __restrict__ b0,
@@ -149,28 +150,28 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16x6_kernel(
         st.a1 = *reinterpret_cast<const float4*>(ga1 + k0);
         st.bh = *reinterpret_cast<const uint4*>(wh + gboff + k0 * kstep);
         st.bm = *reinterpret_cast<const uint4*>(wm_ + gboff + k0 * kstep);
-        st.bl = *reinterpret_cast<const uint4*>(wl + gboff + k0 * kstep);
+        if (NP == 3) st.bl = *reinterpret_cast<const uint4*>(wl + gboff + k0 * kstep);
     };
     auto lstore = [&](const Stage& st, unsigned char* buf) {
         uint2 h, m, l;
         split4(st.a0, h, m, l);
         *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa0) = h;
         *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa0) = m;
-        *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa0) = l;
+        if (NP == 3) *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa0) = l;
         split4(st.a1, h, m, l);
         *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa1) = h;
         *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa1) = m;
-        *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa1) = l;
+        if (NP == 3) *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa1) = l;
         *reinterpret_cast<uint4*>(buf + 3 * PIECE + wb) = st.bh;
         *reinterpret_cast<uint4*>(buf + 4 * PIECE + wb) = st.bm;
-        *reinterpret_cast<uint4*>(buf + 5 * PIECE + wb) = st.bl;
+        if (NP == 3) *reinterpret_cast<uint4*>(buf + 5 * PIECE + wb) = st.bl;
     };
     auto compute = [&](const unsigned char* buf) {
         bf16x8 a[2][3], b[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 a[i][p] = *reinterpret_cast<const bf16x8*>(buf + p * PIECE + ra + i * 32 * ROWB);
                 b[i][p] = *reinterpret_cast<const bf16x8*>(buf + (3 + p) * PIECE + rb + i * 32 * ROWB);
             }
@@ -180,9 +181,11 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16x6_kernel(
             for (int j = 0; j < 2; ++j) {
                 f32x16 c = acc[i][j];
                 // smallest terms first, hi*hi last
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);  // lo  * hi
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);  // hi  * lo
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);  // mid * mid
+                if (NP == 3) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);  // lo  * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);  // hi  * lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);  // mid * mid
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);  // mid * hi
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);  // hi  * mid
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);  // hi  * hi
@@ -291,7 +294,8 @@ extern "C" int mr_split_weights_kblock_f32(const float* arena, const int64_t* ta
 extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t* w_hi, const uint16_t* w_mid,
                                      const uint16_t* w_lo, int64_t off0, int64_t off1, int64_t off2, const float* b0,
                                      const float* b1, const float* b2, int nseg, int M, int seg_n, int K, int act,
-                                     const float* R, int64_t ldr, float* C, int64_t ldc, mr_stream_t stream) {
+                                     const float* R, int64_t ldr, float* C, int64_t ldc, int products, mr_stream_t stream) {
+    if (products != 6 && products != 3) return MR_EUNSUPPORTED;
     if (!A || !w_hi || !w_mid || !w_lo || !C || nseg < 1 || nseg > 3 || M < 0 || seg_n < 1 || K < 1) return MR_EINVAL;
     if (K % BK) return MR_EUNSUPPORTED;
     if (nseg > 1 && (seg_n % BN)) return MR_EUNSUPPORTED;
@@ -309,9 +313,14 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
     hipStream_t st = (hipStream_t)stream;
     const size_t shm = 2 * BUF;  // 49,152 B: within the default dynamic-LDS limit
     const bool pf2 = ((K / BK) % 2 == 0);
-#define MR_GEMM_LAUNCH3(ACT_, HASR_, PF2_)                                                                                   \
-    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_>), dim3(nwg), dim3(kThreads), shm, st, A, lda, w_hi, w_mid, \
+#define MR_GEMM_LAUNCH4(ACT_, HASR_, PF2_, NP_)                                                                                   \
+    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_>), dim3(nwg), dim3(kThreads), shm, st, A, lda, w_hi, w_mid, \
                        w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg)
+#define MR_GEMM_LAUNCH3(ACT_, HASR_, PF2_)                          \
+    do {                                                            \
+        if (products == 6) MR_GEMM_LAUNCH4(ACT_, HASR_, PF2_, 3);   \
+        else MR_GEMM_LAUNCH4(ACT_, HASR_, PF2_, 2);                 \
+    } while (0)
 #define MR_GEMM_LAUNCH(ACT_, HASR_)                         \
     do {                                                    \
         if (pf2) MR_GEMM_LAUNCH3(ACT_, HASR_, true);        \
@@ -324,5 +333,6 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
     }
 #undef MR_GEMM_LAUNCH
 #undef MR_GEMM_LAUNCH3
+#undef MR_GEMM_LAUNCH4
     return mr::check_launch();
 }

@@ -173,12 +173,13 @@ class ArenaLayout:
         return groups, seg_off, seg_gid
 
 
-GEMM_MODES = ("f32", "bf16x6")
+GEMM_MODES = ("f32", "bf16x6", "bf16x3")
 
 
 def default_gemm_mode() -> str:
     """Encoder GEMM arithmetic: "bf16x6" = six bf16 MFMA products per fp32 product (fp32-grade accuracy, 2.67x fewer
-    matrix-pipe cycles; the default), "f32" = exact fp32 MFMA (bit-identical to the oracle's FMA chain)."""
+    matrix-pipe cycles; the default), "bf16x3" = three products (two pieces per operand, ~2^-16 per product: measured
+    ~2e-6 on BLaIR-base embeddings), "f32" = exact fp32 MFMA (bit-identical to the oracle's FMA chain)."""
     import os
 
     m = os.environ.get("MERGEREC_GEMM_MODE", "bf16x6")
@@ -210,7 +211,7 @@ class WeightSet:
         return self.layout.offsets[name]
 
     def refresh(self):
-        if self.mode == "bf16x6":
+        if self.mode in ("bf16x6", "bf16x3"):
             if self._table is None:  # every 2-D tensor a Linear reads (not the embedding tables), K % 16 == 0
                 ent = [(self.layout.offsets[k], shp[0], shp[1]) for k, shp in self.layout.shapes.items()
                        if len(shp) == 2 and "embeddings" not in k and shp[1] % 16 == 0]
@@ -329,10 +330,11 @@ class EncoderRunner:
             for i, (wn_, bn_) in enumerate(zip(wnames, bnames)):
                 self._linear(w, x, [wn_], [bn_], act, None, out[:, i * seg_n : (i + 1) * seg_n])
             return out
-        if w.mode == "bf16x6":
+        if w.mode in ("bf16x6", "bf16x3"):
             if w.pieces is None:
                 w.refresh()
-            return ops.gemm_nt_split(x, w.pieces, [w.offset(n) for n in wnames], seg_n, K, biases, act, residual, out)
+            return ops.gemm_nt_split(x, w.pieces, [w.offset(n) for n in wnames], seg_n, K, biases, act, residual, out,
+                                     products=6 if w.mode == "bf16x6" else 3)
         return ops.gemm_nt(x, [w[n] for n in wnames], biases, act, residual, out)
 
     def _proj(self, w, lp, names, x):

@@ -267,7 +267,8 @@ def split_weights_kblock(flat: torch.Tensor, table: KBlockTable, pieces=None):
 
 
 def gemm_nt_split(A: torch.Tensor, pieces, offsets: Sequence[int], seg_n: int, K: int, biases: Sequence[Optional[torch.Tensor]] = (None,),
-                  act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  products: int = 6) -> torch.Tensor:
     """Split-precision GEMM (6 bf16 MFMA products per fp32 product): weights are addressed as element offsets into the
     three pre-split, K-BLOCKED bf16 arenas `pieces` = (hi, mid, lo) (split_weights_kblock); otherwise as gemm_nt."""
     if A.dim() != 2 or A.stride(1) != 1 or A.shape[1] != K:
@@ -282,10 +283,10 @@ def gemm_nt_split(A: torch.Tensor, pieces, offsets: Sequence[int], seg_n: int, K
         _lib.load().mr_gemm_nt_bf16x6_f32(
             ptr(A), A.stride(0), ptr(pieces[0]), ptr(pieces[1]), ptr(pieces[2]), offs[0], offs[1], offs[2], ptr(biases[0]), ptr(biases[1]),
             ptr(biases[2]), nseg, M, seg_n, K, act, ptr(residual), 0 if residual is None else residual.stride(0), ptr(out), out.stride(0),
-            _stream(A)),
+            products, _stream(A)),
         "mr_gemm_nt_bf16x6_f32",
     )
-    PROF.end(ev, A.device, "gemm_nt_bf16x6", flops=2.0 * M * nseg * seg_n * K,
+    PROF.end(ev, A.device, "gemm_nt_bf16x6" if products == 6 else "gemm_nt_bf16x3", flops=2.0 * M * nseg * seg_n * K,
              nbytes=4.0 * (M * K + M * nseg * seg_n * (2 if residual is not None else 1)) + 6.0 * nseg * seg_n * K)
     return out
 

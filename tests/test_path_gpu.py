@@ -30,7 +30,15 @@ def _dev_weights(sd, mode="bf16x6"):
     return WeightSet(layout, layout.pack(views, DEV), mode).refresh()
 
 
-MODES = ["f32", "bf16x6"]
+MODES = ["f32", "bf16x6", "bf16x3"]
+# hidden-state tolerance per GEMM arithmetic on the STRESS goldens (tiny models with std-0.2 weights: |activations| and attention
+# logits far larger than in the real models); the contract of the path is 1e-4 on the cosine logits, asserted separately below
+HID_TOL = {"f32": 1e-4, "bf16x6": 1e-4, "bf16x3": 1e-3}
+
+
+def _cosine_logits_close(a, b, atol=1e-4):
+    a, b = O.maybe_normalize(a), O.maybe_normalize(b)
+    return float((a @ a.T - b @ b.T).abs().max()) <= atol and float((a - b).abs().max()) <= atol
 
 
 def _unpack(hidden_packed, mask):
@@ -54,10 +62,11 @@ def test_roberta_encoder_matches_library_golden(mode):
     m = g3["attention_mask"].bool()
     for li, (h, ref) in enumerate(zip(hidden, g3["hidden_states"])):
         got = _unpack(h, g3["attention_mask"])
-        assert torch.allclose(got[m], ref[m], atol=1e-4, rtol=1e-5), (li, (got[m] - ref[m]).abs().max())
-    assert torch.allclose(cls.cpu(), g3["cls"], atol=1e-4, rtol=1e-5)
+        assert torch.allclose(got[m], ref[m], atol=HID_TOL[mode], rtol=1e-5), (li, (got[m] - ref[m]).abs().max())
+    assert torch.allclose(cls.cpu(), g3["cls"], atol=HID_TOL[mode], rtol=1e-5)
+    assert _cosine_logits_close(cls.cpu(), g3["cls"])
     fast = run.forward_packed(w, pb, normalize=False)  # last layer on CLS rows only
-    assert torch.allclose(fast.cpu(), g3["cls"], atol=1e-4, rtol=1e-5)
+    assert torch.allclose(fast.cpu(), g3["cls"], atol=HID_TOL[mode], rtol=1e-5)
     nrm = run.forward_packed(w, pb, normalize=True).cpu()
     assert torch.allclose(nrm, O.maybe_normalize(g3["cls"]), atol=1e-5)
 
@@ -75,7 +84,7 @@ def test_roberta_true_dims_layer_matches_library_golden(mode):
     m = big["attention_mask"].bool()
     assert torch.allclose(_unpack(hidden[0], big["attention_mask"])[m], big["emb"][m], atol=1e-5)
     got = _unpack(hidden[-1], big["attention_mask"])[m]
-    assert torch.allclose(got, big["last"][m], atol=1e-4, rtol=1e-5), (got - big["last"][m]).abs().max()
+    assert torch.allclose(got, big["last"][m], atol=1e-4, rtol=1e-5), (got - big["last"][m]).abs().max()  # true dims: every mode within 1e-4
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -91,10 +100,11 @@ def test_recformer_encoder_matches_reference_golden(mode):
         m = b["attention_mask"].bool()
         for li, (h, ref) in enumerate(zip(hidden, case["hidden_states"])):
             got = _unpack(h, b["attention_mask"])
-            assert torch.allclose(got[m], ref[m], atol=1e-4, rtol=1e-5), (li, (got[m] - ref[m]).abs().max())
-        assert torch.allclose(cls.cpu(), case["cls"], atol=1e-4, rtol=1e-5)
+            assert torch.allclose(got[m], ref[m], atol=HID_TOL[mode], rtol=1e-5), (li, (got[m] - ref[m]).abs().max())
+        assert torch.allclose(cls.cpu(), case["cls"], atol=HID_TOL[mode], rtol=1e-5)
+        assert _cosine_logits_close(cls.cpu(), case["cls"])
         fast = run.forward_packed(w, pb, normalize=False)
-        assert torch.allclose(fast.cpu(), case["cls"], atol=1e-4, rtol=1e-5)
+        assert torch.allclose(fast.cpu(), case["cls"], atol=HID_TOL[mode], rtol=1e-5)
 
 
 # ------------------------------------------------------------------ merger behind load_merging_module

@@ -25,7 +25,7 @@ def run(mode, name, n, k, nseg):
     if mode == "f32":
         ops.gemm_nt(A, Ws, bs, out=out)
     else:
-        ops.gemm_nt_split(A, pieces, [i * n * k for i in range(nseg)], n, k, bs, out=out)
+        ops.gemm_nt_split(A, pieces, [i * n * k for i in range(nseg)], n, k, bs, out=out, products=6 if mode == "bf16x6" else 3)
 
 for mode in modes:
     for s in shapes:
