@@ -193,6 +193,12 @@ int mr_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const floa
 int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh, int max_len,
                 float scale, int window, float* ctx, mr_stream_t stream);
 
+/* mr_attn_f32 with both products (S = Q K^T and O = P V) evaluated in split precision on the bf16 matrix cores:
+ * products = 3 (two bf16 pieces per operand) or 6 (three pieces, fp32-grade), fp32 accumulation and an fp32 online softmax.
+ * Same arguments, masking rules and output as mr_attn_f32. */
+int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh, int max_len,
+                      float scale, int window, int products, float* ctx, mr_stream_t stream);
+
 /* Global-token row of Longformer attention: for each sequence b, ctx[cu[b], :] =
  * softmax(qg_b kg^T * scale) vg over all tokens of b, where qg is (B, H*dh) (the global query of
  * each sequence's first token) and kvg is (T, 2*H*dh) = [k_global | v_global] per token.

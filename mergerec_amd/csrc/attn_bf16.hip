@@ -1,0 +1,288 @@
+// K4': the attention kernel of attn.hip with both products (S^T = K Q^T and O^T = V^T P^T) evaluated in split precision
+// on the bf16 matrix cores (see gemm_bf16.hip): every fp32 operand is NP bf16 pieces (NP = 2: three products, NP = 3: six),
+// products accumulate in fp32.  Per 32-query x 32-key tile that is 24 (48) v_mfma_f32_32x32x16_bf16 = 768 (1536) matrix-pipe
+// cycles instead of 64 x 64 = 4096 for the fp32 MFMA kernel.
+//
+// Same decomposition as attn.hip: workgroup = 4 waves = 128 queries of one (sequence, head); K/V tiles of 32 keys go through
+// double-buffered LDS with the next tile's loads in flight under the current tile's math; scores are computed transposed so P
+// stays in registers as the B operand of the second product.  Differences:
+//   * K is split into its pieces while it is staged; LDS image per piece = [32 keys][64 bf16] (128-B rows), the eight 16-B
+//     chunks of a row XOR-swizzled by (row >> 1) & 7, so the ds_read_b128 of 16 keys is conflict-free.
+//   * Q is split once per wave into registers; P is split in registers after the softmax (register r = 8 s + j of the score
+//     accumulator is exactly element j of k-step s of the B operand).
+//   * V stays fp32 in LDS ([key][64]); each lane reads the 16 values of its column that the k-steps need (ds_read_b32, as in
+//     attn.hip) and splits them in registers -- a bf16 V image would need a transposed, 2-byte-granular LDS write.
+#include "common.h"
+#include <math.h>
+#include <stdint.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kDh = 64;
+constexpr int KROWB = 128;           // bytes per K piece row (64 bf16)
+constexpr int KPIECE = 32 * KROWB;   // 4 KB per piece per tile
+constexpr int VBYTES = 32 * 64 * 4;  // fp32 V tile
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// 8 fp32 -> NP pieces of 8 bf16 (4 dwords each); piece 0 = hi
+template <int NP>
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[NP]) {
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = x[i];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w = pack2(r[2 * j], r[2 * j + 1]);
+            out[p][j] = w;
+            if (p + 1 < NP) {
+                r[2 * j] -= lo_f(w);
+                r[2 * j + 1] -= hi_f(w);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
+    union { u32x4 u; bf16x8 b; } c;
+    c.u = v;
+    return c.b;
+}
+
+// acc += sum over the product set of piece pairs: NP = 2 -> (lo,hi) (hi,lo) (hi,hi); NP = 3 -> + (lo2,hi) (hi,lo2) (mid,mid)
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[NP], const u32x4 (&b)[NP], f32x16 c) {
+    if (NP == 3) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[2]), as_bf16x8(b[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[0]), as_bf16x8(b[2]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[1]), as_bf16x8(b[1]), c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[1]), as_bf16x8(b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[0]), as_bf16x8(b[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[0]), as_bf16x8(b[0]), c, 0, 0, 0);
+    return c;
+}
+
+template <bool WINDOWED, int NP>
+__global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel(const float* __restrict__ qkv,
+                                                                const int32_t* __restrict__ cu,
+                                                                const int32_t* __restrict__ seq_order, int H,
+                                                                float scale_log2e, int window, float* __restrict__ ctx) {
+    constexpr int BUFB = NP * KPIECE + VBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUFB
+    const int b = seq_order ? seq_order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int t0 = cu[b], len = cu[b + 1] - t0;
+    const int q_base = blockIdx.x * 128;
+    if (q_base >= len) return;  // the whole workgroup leaves together, before any barrier
+    const int64_t ld = (int64_t)3 * H * kDh;
+    const float* __restrict__ Qb = qkv + (int64_t)t0 * ld + h * kDh;
+    const float* __restrict__ Kb = Qb + H * kDh;
+    const float* __restrict__ Vb = Qb + 2 * H * kDh;
+
+    const int q0 = q_base + wave * 32;
+    const bool wave_active = q0 < len;  // wave-uniform
+    const int qi = q0 + lr;
+
+    // Q pieces as the B operand of S^T = K Q^T: k-step s covers d = 16 s + 8 lh + j; pre-scaled by scale * log2(e)
+    u32x4 qp[4][NP];
+    {
+        const int qrow = qi < len ? qi : len - 1;
+        const float* qr = Qb + (int64_t)qrow * ld + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 x0 = *reinterpret_cast<const float4*>(qr + 16 * s);
+            const float4 x1 = *reinterpret_cast<const float4*>(qr + 16 * s + 4);
+            const float x[8] = {x0.x * scale_log2e, x0.y * scale_log2e, x0.z * scale_log2e, x0.w * scale_log2e,
+                                x1.x * scale_log2e, x1.y * scale_log2e, x1.z * scale_log2e, x1.w * scale_log2e};
+            split8<NP>(x, qp[s]);
+        }
+    }
+
+    // key-tile schedule of the workgroup (as attn.hip)
+    int k_lo = 0, k_hi = len;
+    if (WINDOWED) {
+        k_lo = q_base - window;
+        k_lo = k_lo < 0 ? 0 : (k_lo & ~31);
+        k_hi = q_base + 127 + window + 1;
+        k_hi = k_hi > len ? len : k_hi;
+    }
+    const bool extra0 = WINDOWED && k_lo > 0;
+    const int ntiles = (k_hi - k_lo + 31) / 32 + (extra0 ? 1 : 0);
+    auto tile_base = [&](int it) { return extra0 ? (it == 0 ? 0 : k_lo + (it - 1) * 32) : k_lo + it * 32; };
+
+    // staging map: thread -> (row sr / sr + 16, 4 consecutive d at sc)
+    const int sr = tid >> 4, sc4 = tid & 15, sc = sc4 * 4;
+    float4 kreg0, kreg1, vreg0, vreg1;
+    auto gload = [&](int kb) {
+        int r0 = kb + sr, r1 = kb + sr + 16;
+        r0 = r0 < len ? r0 : len - 1;
+        r1 = r1 < len ? r1 : len - 1;
+        kreg0 = *reinterpret_cast<const float4*>(Kb + (int64_t)r0 * ld + sc);
+        kreg1 = *reinterpret_cast<const float4*>(Kb + (int64_t)r1 * ld + sc);
+        vreg0 = *reinterpret_cast<const float4*>(Vb + (int64_t)r0 * ld + sc);
+        vreg1 = *reinterpret_cast<const float4*>(Vb + (int64_t)r1 * ld + sc);
+    };
+    // K piece position of (row, 4-d group sc4): 16-B chunk (sc4 >> 1) ^ ((row >> 1) & 7), 8-B half sc4 & 1
+    const int kw0 = sr * KROWB + ((((sc4 >> 1) ^ ((sr >> 1) & 7)) << 4) | ((sc4 & 1) << 3));
+    const int kw1 = (sr + 16) * KROWB + ((((sc4 >> 1) ^ (((sr + 16) >> 1) & 7)) << 4) | ((sc4 & 1) << 3));
+    auto store_k = [&](const float4 x, unsigned char* dst) {
+        float r0 = x.x, r1 = x.y, r2 = x.z, r3 = x.w;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uint32_t w0 = pack2(r0, r1), w1 = pack2(r2, r3);
+            *reinterpret_cast<uint2*>(dst + p * KPIECE) = make_uint2(w0, w1);
+            if (p + 1 < NP) { r0 -= lo_f(w0); r1 -= hi_f(w0); r2 -= lo_f(w1); r3 -= hi_f(w1); }
+        }
+    };
+    auto lstore = [&](unsigned char* buf) {
+        store_k(kreg0, buf + kw0);
+        store_k(kreg1, buf + kw1);
+        float* vs = reinterpret_cast<float*>(buf + NP * KPIECE);
+        *reinterpret_cast<float4*>(vs + sr * kDh + sc) = vreg0;
+        *reinterpret_cast<float4*>(vs + (sr + 16) * kDh + sc) = vreg1;
+    };
+    // K fragment read: lane (key lr, half lh), k-step s -> logical 16-B chunk 2 s + lh of row lr
+    const int kswz = (lr >> 1) & 7;
+
+    float m = -INFINITY, l = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+
+    gload(tile_base(0));
+    lstore(lds);
+    __syncthreads();
+
+    for (int it = 0; it < ntiles; ++it) {
+        const unsigned char* buf = lds + (it & 1) * BUFB;
+        const int kb = tile_base(it);
+        gload(tile_base(it + 1 < ntiles ? it + 1 : it));  // unconditional: keeps the loads in flight under the math
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        bool relevant = wave_active;
+        if (WINDOWED) relevant = relevant && (kb == 0 || (kb + 31 >= q0 - window && kb <= q0 + 31 + window));
+        if (relevant) {
+            // ---- S^T tile = K Q^T
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                u32x4 ka[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    ka[p] = *reinterpret_cast<const u32x4*>(buf + p * KPIECE + lr * KROWB + (((2 * st + lh) ^ kswz) << 4));
+                s = mfma_split<NP>(ka, qp[st], s);
+            }
+            // ---- mask + online softmax (base 2); s[r] is key kb + (r&3) + 8*(r>>2) + 4*lh for query q0 + lr
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                bool ok = key < len;
+                if (WINDOWED) {
+                    const int dlt = qi - key;
+                    ok = ok && (key == 0 || (dlt <= window && dlt >= -window));
+                }
+                s[r] = ok ? s[r] : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float corr = (m == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : exp2f(m - m_use);
+            float ps = 0.f;
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pv[r] = exp2f(s[r] - m_use);
+                ps += pv[r];
+            }
+            ps += __shfl_xor(ps, 32, 64);
+            l = l * corr + ps;
+            m = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+            // P pieces: k-step st of the second product takes registers 8 st .. 8 st + 7
+            u32x4 pp[2][NP];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const float x[8] = {pv[8 * st], pv[8 * st + 1], pv[8 * st + 2], pv[8 * st + 3],
+                                    pv[8 * st + 4], pv[8 * st + 5], pv[8 * st + 6], pv[8 * st + 7]};
+                split8<NP>(x, pp[st]);
+            }
+            // ---- O^T += V^T P^T: lane (column d = lr of the 32-wide d tile, half lh) reads V[kb + kappa(r, lh)][d]
+            const float* vp = reinterpret_cast<const float*>(buf + NP * KPIECE) + (4 * lh) * kDh + lr;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 8 * st + j;
+                        x[j] = vp[((r & 3) + 8 * (r >> 2)) * kDh + 32 * dt];
+                    }
+                    u32x4 va[NP];
+                    split8<NP>(x, va);
+                    if (dt == 0) o0 = mfma_split<NP>(va, pp[st], o0);
+                    else o1 = mfma_split<NP>(va, pp[st], o1);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(lds + ((it + 1) & 1) * BUFB);
+        __syncthreads();
+    }
+
+    if (wave_active && qi < len && !(WINDOWED && qi == 0)) {
+        const float inv = 1.0f / l;
+        float* op = ctx + (int64_t)(t0 + qi) * ((int64_t)H * kDh) + h * kDh + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<float4*>(op + 8 * g) =
+                make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 32 + 8 * g) =
+                make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh,
+                                 int max_len, float scale, int window, int products, float* ctx, mr_stream_t stream) {
+    if (!qkv || !cu_seqlens || !ctx || B < 0 || H < 1 || max_len < 0) return MR_EINVAL;
+    if (dh != kDh || (products != 3 && products != 6)) return MR_EUNSUPPORTED;
+    if (!mr::aligned16(qkv) || !mr::aligned16(ctx)) return MR_EALIGN;
+    if (B == 0 || max_len == 0) return MR_OK;
+    const dim3 grid((max_len + 127) / 128, H, B);
+    const float scale_log2e = scale * 1.4426950408889634f;
+    hipStream_t st = (hipStream_t)stream;
+#define MR_ATTN_LAUNCH(W_, NP_)                                                                                          \
+    hipLaunchKernelGGL((attn_split_kernel<W_, NP_>), grid, dim3(kThreads), (size_t)2 * (NP_ * KPIECE + VBYTES), st, qkv, \
+                       cu_seqlens, seq_order, H, scale_log2e, window, ctx)
+    if (window >= 0) {
+        if (products == 3) MR_ATTN_LAUNCH(true, 2); else MR_ATTN_LAUNCH(true, 3);
+    } else {
+        if (products == 3) MR_ATTN_LAUNCH(false, 2); else MR_ATTN_LAUNCH(false, 3);
+    }
+#undef MR_ATTN_LAUNCH
+    return mr::check_launch();
+}

@@ -349,7 +349,7 @@ class EncoderRunner:
             w_ = sp.one_sided_window
             ops.ATTN_FLOPS_HINT[0] = 4.0 * sp.hidden * (pb.sum_len_sq if sp.kind != "recformer" else pb.T * (2 * w_ + 2))
         ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=sp.one_sided_window if sp.kind == "recformer" else -1,
-                            seq_order=pb.seq_order)
+                            seq_order=pb.seq_order, products={"f32": 0, "bf16x6": 6, "bf16x3": 3}[w.mode])
         if sp.kind == "recformer":
             x_cls = ops.gather_rows(x, pb.cls_rows)
             qg = self._proj(w, lp, ("query_global",), x_cls)

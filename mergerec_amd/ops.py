@@ -304,13 +304,18 @@ ATTN_FLOPS_HINT = [0.0]  # algorithmic 4 * sum(L_b^2) * d of the next attention 
 
 
 def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, window: int = -1, out=None,
-              seq_order: Optional[torch.Tensor] = None) -> torch.Tensor:
+              seq_order: Optional[torch.Tensor] = None, products: int = 0) -> torch.Tensor:
+    """products = 0: exact fp32 MFMA kernel; 3 / 6: split-precision bf16 MFMA kernel (mr_attn_split_f32)."""
     T = qkv.shape[0]
     dh = qkv.shape[1] // (3 * H)
     out = torch.empty(T, H * dh, dtype=torch.float32, device=qkv.device) if out is None else out
     ev = PROF.begin(qkv.device)
-    check(_lib.load().mr_attn_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, ptr(out), _stream(qkv)), "mr_attn_f32")
-    PROF.end(ev, qkv.device, "attention", flops=ATTN_FLOPS_HINT[0], nbytes=4.0 * T * 4 * H * dh)
+    if products:
+        check(_lib.load().mr_attn_split_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, products,
+                                            ptr(out), _stream(qkv)), "mr_attn_split_f32")
+    else:
+        check(_lib.load().mr_attn_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, ptr(out), _stream(qkv)), "mr_attn_f32")
+    PROF.end(ev, qkv.device, "attention" if not products else f"attention_bf16x{products}", flops=ATTN_FLOPS_HINT[0], nbytes=4.0 * T * 4 * H * dh)
     ATTN_FLOPS_HINT[0] = 0.0
     return out
 

@@ -247,6 +247,24 @@ def test_attention_full(ops, H, lens):
     assert torch.allclose(got, want, atol=3e-6, rtol=1e-5), (got - want).abs().max()
 
 
+@pytest.mark.parametrize("products,tol", [(3, 3e-4), (6, 5e-6)])
+@pytest.mark.parametrize("window", [-1, 4, 32])
+def test_attention_split_precision(ops, products, tol, window):
+    g = _g(100 + products + window)
+    H, lens = 4, [300, 1, 2, 70, 33, 129, 512]
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    T = int(cu[-1])
+    qkv = torch.randn(T, 3 * H * 64, generator=g)
+    ctx = torch.full((T, H * 64), 7.5, device=DEV)
+    ops.attention(qkv.to(DEV), cu.to(DEV), len(lens), H, max(lens), window=window, out=ctx, products=products)
+    got, want = ctx.cpu(), _attn_ref(qkv, cu, H, window)
+    keep = torch.ones(T, dtype=torch.bool)
+    if window >= 0:
+        keep[cu[:-1].long()] = False
+        assert bool((got[~keep] == 7.5).all())
+    assert torch.allclose(got[keep], want[keep], atol=tol, rtol=tol), (got[keep] - want[keep]).abs().max()
+
+
 @pytest.mark.parametrize("window", [4, 32])
 def test_attention_band_global(ops, window):
     g = _g(window)

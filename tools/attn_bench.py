@@ -21,14 +21,15 @@ out = torch.empty(T, H * 64, device=dev)
 flops = 4.0 * 768 * float((lens.double() ** 2).sum())
 pad = lambda x, m: (x + m - 1) // m * m
 work = 4.0 * 768 * float((pad(lens, 32).double() ** 2).sum())
+prod = int(os.environ.get("AB_PRODUCTS", "0"))
 order = torch.argsort(lens, descending=True, stable=True).to(torch.int32).to(dev) if os.environ.get("AB_ORDER", "1") == "1" else None
 for _ in range(3):
-    ops.attention(qkv, cu_d, B, H, int(lens.max()), out=out, seq_order=order)
+    ops.attention(qkv, cu_d, B, H, int(lens.max()), out=out, seq_order=order, products=prod)
 torch.cuda.synchronize()
 ts = []
 for _ in range(int(os.environ.get("AB_ROUNDS", 10))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); ops.attention(qkv, cu_d, B, H, int(lens.max()), out=out, seq_order=order); e1.record(); torch.cuda.synchronize()
+    e0.record(); ops.attention(qkv, cu_d, B, H, int(lens.max()), out=out, seq_order=order, products=prod); e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 ms = sorted(ts)[len(ts) // 2]
-print(f"{mode}: B={B} T={T} max_len={int(lens.max())}  {ms:.3f} ms  algorithmic {flops/ms/1e9:.1f} TFLOP/s  tile-padded work {work/ms/1e9:.1f} TFLOP/s")
+print(f"products={prod} {mode}: B={B} T={T} max_len={int(lens.max())}  {ms:.3f} ms  algorithmic {flops/ms/1e9:.1f} TFLOP/s  tile-padded work {work/ms/1e9:.1f} TFLOP/s")
