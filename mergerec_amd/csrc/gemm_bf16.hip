@@ -16,17 +16,17 @@
 // 48 KB of LDS per workgroup (double-buffered) -> 3 workgroups per CU.
 #include "common.h"
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BM = 128, BK = 16;
 constexpr int ROWB = 32;                 // bytes per LDS row: 16 bf16, unpadded; the two 16-B halves of rows 8..15 (mod 16)
                                          // are swapped (chunk ^= (row >> 3) & 1) so a ds_read_b128 of 16 rows is conflict-free
-constexpr int PIECE = 128 * ROWB;        // bytes per (operand, piece) tile
-constexpr int BUF = 6 * PIECE;           // A{hi,mid,lo} B{hi,mid,lo}
+constexpr int PIECE = 128 * ROWB;        // bytes per 128-row piece tile
 constexpr int kThreads = 256;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -90,14 +90,20 @@ __global__ __launch_bounds__(kThreads) void split_weights_kblock_kernel(const fl
 }
 
 // NP = number of bf16 pieces per operand: 3 -> six products (fp32-grade, ~2^-24), 2 -> three products hi*hi + hi*lo + lo*hi (~2^-16)
-template <int ACT, bool HAS_R, bool PF2, int NP>
-__global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16x6_kernel(
+// NT = MFMA tiles along N per wave: 2 -> 128x128 block tile (3 workgroups/CU), 4 -> 128x256 block tile (wave tile 64x128:
+// twice the MFMAs per barrier / LDS read / A byte; 128 accumulator VGPRs, 2 workgroups/CU)
+template <int ACT, bool HAS_R, bool PF2, int NP, int NT>
+__global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_kernel(
     const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ wh, const uint16_t* __restrict__ wm_,
     const uint16_t* __restrict__ wl, int64_t off0, int64_t off1, int64_t off2, const float* __restrict__ b0,
     const float* __restrict__ b1, const float* __restrict__ b2, int M, int seg_n, int K,
     const float* __restrict__ R, int64_t ldr, float* __restrict__ C, int64_t ldc, int tiles_n_seg, int tiles_n,
     int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUF bytes
+    constexpr int BN = 64 * NT;                 // 128 or 256 columns per workgroup
+    constexpr int BPIECE = (BN / 128) * PIECE;  // bytes of one B piece tile
+    constexpr int BOFF = 3 * PIECE;             // B pieces start behind the (up to) three A pieces
+    constexpr int BUF = BOFF + 3 * BPIECE;
 
     const int pid = mr::xcd_remap(blockIdx.x, nwg);
     const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
@@ -124,33 +130,41 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16x6_kernel(
     const int wa1 = wa0 + 64 * ROWB;
     // B (pre-split bf16): thread -> row br, 16-byte half bh (8 consecutive k) of each piece
     const int brow = tid >> 1, bh = tid & 1;
-    int br = n0 + brow;
-    br = br < seg_n ? br : seg_n - 1;
-    const int64_t gboff = woff + (int64_t)br * 16 + bh * 8;  // k-blocked: element (n, k) lives at off + ((k / 16) * N + n) * 16 + k % 16
+    constexpr int BQ = BN / 128;  // 128-row passes over the B tile
+    int64_t gboff[BQ];            // k-blocked: element (n, k) lives at off + ((k / 16) * N + n) * 16 + k % 16
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+        int br = n0 + brow + 128 * q;
+        br = br < seg_n ? br : seg_n - 1;
+        gboff[q] = woff + (int64_t)br * 16 + bh * 8;
+    }
     const int64_t kstep = (int64_t)seg_n;                     // elements per k-tile advance = N * 16 / 16 per unit k -> k0 * N
     const int wb = brow * ROWB + ((bh ^ ((brow >> 3) & 1)) * 16);
     // fragment read offsets (bytes)
     const int ra = (wm * 64 + lr) * ROWB + ((lh ^ ((lr >> 3) & 1)) * 16);  // rows +32 keep the same swizzle bit
-    const int rb = (wn * 64 + lr) * ROWB + ((lh ^ ((lr >> 3) & 1)) * 16);
+    const int rb = (wn * 32 * NT + lr) * ROWB + ((lh ^ ((lr >> 3) & 1)) * 16);
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    struct Stage {  // one k-tile of this thread's global data: 2 float4 of A, 3 x 16 B of pre-split B
+    struct Stage {  // one k-tile of this thread's global data: 2 float4 of A, NP x BQ x 16 B of pre-split B
         float4 a0, a1;
-        uint4 bh, bm, bl;
+        uint4 bh[BQ], bm[BQ], bl[BQ];
     };
     auto gload = [&](Stage& st, int k0) {
         st.a0 = *reinterpret_cast<const float4*>(ga0 + k0);
         st.a1 = *reinterpret_cast<const float4*>(ga1 + k0);
-        st.bh = *reinterpret_cast<const uint4*>(wh + gboff + k0 * kstep);
-        st.bm = *reinterpret_cast<const uint4*>(wm_ + gboff + k0 * kstep);
-        if (NP == 3) st.bl = *reinterpret_cast<const uint4*>(wl + gboff + k0 * kstep);
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) {
+            st.bh[q] = *reinterpret_cast<const uint4*>(wh + gboff[q] + k0 * kstep);
+            st.bm[q] = *reinterpret_cast<const uint4*>(wm_ + gboff[q] + k0 * kstep);
+            if (NP == 3) st.bl[q] = *reinterpret_cast<const uint4*>(wl + gboff[q] + k0 * kstep);
+        }
     };
     auto lstore = [&](const Stage& st, unsigned char* buf) {
         uint2 h, m, l;
@@ -162,23 +176,26 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16x6_kernel(
         *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa1) = h;
         *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa1) = m;
         if (NP == 3) *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa1) = l;
-        *reinterpret_cast<uint4*>(buf + 3 * PIECE + wb) = st.bh;
-        *reinterpret_cast<uint4*>(buf + 4 * PIECE + wb) = st.bm;
-        if (NP == 3) *reinterpret_cast<uint4*>(buf + 5 * PIECE + wb) = st.bl;
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) {  // rows brow + 128 q: same swizzle bit
+            *reinterpret_cast<uint4*>(buf + BOFF + 0 * BPIECE + q * PIECE + wb) = st.bh[q];
+            *reinterpret_cast<uint4*>(buf + BOFF + 1 * BPIECE + q * PIECE + wb) = st.bm[q];
+            if (NP == 3) *reinterpret_cast<uint4*>(buf + BOFF + 2 * BPIECE + q * PIECE + wb) = st.bl[q];
+        }
     };
     auto compute = [&](const unsigned char* buf) {
-        bf16x8 a[2][3], b[2][3];
+        bf16x8 a[2][3], b[NT][3];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i][p] = *reinterpret_cast<const bf16x8*>(buf + p * PIECE + ra + i * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j][p] = *reinterpret_cast<const bf16x8*>(buf + BOFF + p * BPIECE + rb + j * 32 * ROWB);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                a[i][p] = *reinterpret_cast<const bf16x8*>(buf + p * PIECE + ra + i * 32 * ROWB);
-                b[i][p] = *reinterpret_cast<const bf16x8*>(buf + (3 + p) * PIECE + rb + i * 32 * ROWB);
-            }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 f32x16 c = acc[i][j];
                 // smallest terms first, hi*hi last
                 if (NP == 3) {
@@ -238,8 +255,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_bf16x6_kernel(
     // ---- epilogue (C/D layout of the 32x32 MFMA is dtype independent)
     const bool interior = (m0 + BM <= M) && (n0 + BN <= seg_n);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + lr;
+    for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * 32 * NT + j * 32 + lr;
         const bool col_ok = interior || col < seg_n;
         const float bz = (bias && col_ok) ? bias[col] : 0.f;
         const int64_t colg = (int64_t)seg * seg_n + col;
@@ -298,24 +315,44 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
     if (products != 6 && products != 3) return MR_EUNSUPPORTED;
     if (!A || !w_hi || !w_mid || !w_lo || !C || nseg < 1 || nseg > 3 || M < 0 || seg_n < 1 || K < 1) return MR_EINVAL;
     if (K % BK) return MR_EUNSUPPORTED;
-    if (nseg > 1 && (seg_n % BN)) return MR_EUNSUPPORTED;
+    if (nseg > 1 && (seg_n % 128)) return MR_EUNSUPPORTED;
     if (act != MR_ACT_NONE && act != MR_ACT_GELU_ERF) return MR_EUNSUPPORTED;
     if ((lda & 3) || !mr::aligned16(A) || !mr::aligned16(w_hi) || !mr::aligned16(w_mid) || !mr::aligned16(w_lo) ||
         (off0 & 7) || (nseg > 1 && (off1 & 7)) || (nseg > 2 && (off2 & 7)))
         return MR_EALIGN;
     if (M == 0) return MR_OK;
+    // wide (128 x 256) tiles when a segment is a multiple of 256 columns and the grid still fills the chip
+    static const int force_nt = [] { const char* e = getenv("MR_GEMM_NT"); return e ? atoi(e) : 0; }();
     const int tiles_m = (M + BM - 1) / BM;
+    // (three-piece x6 staging does not fit the register file next to 128 accumulators: narrow tiles there)
+    bool wide = products == 3 && (seg_n % 256 == 0) && ((int64_t)tiles_m * (seg_n / 256) * nseg >= 512);
+    if (force_nt == 2) wide = false;
+    if (force_nt == 4 && products == 3 && (seg_n % 256 == 0 || nseg == 1)) wide = true;
+    const int BN = wide ? 256 : 128;
     const int tiles_n_seg = (seg_n + BN - 1) / BN;
     const int tiles_n = tiles_n_seg * nseg;
     const int64_t nwg64 = (int64_t)tiles_m * tiles_n;
     if (nwg64 > 0x7fffffff) return MR_EUNSUPPORTED;
     const int nwg = (int)nwg64;
     hipStream_t st = (hipStream_t)stream;
-    const size_t shm = 2 * BUF;  // 49,152 B: within the default dynamic-LDS limit
+    const size_t shm = 2 * (size_t)(3 * PIECE + 3 * (BN / 128) * PIECE);  // 48 KB (narrow) / 72 KB (wide)
     const bool pf2 = ((K / BK) % 2 == 0);
-#define MR_GEMM_LAUNCH4(ACT_, HASR_, PF2_, NP_)                                                                                   \
-    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_>), dim3(nwg), dim3(kThreads), shm, st, A, lda, w_hi, w_mid, \
-                       w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg)
+#define MR_GEMM_LAUNCH5(ACT_, HASR_, PF2_, NP_, NT_)                                                                                  \
+    do {                                                                                                                              \
+        static bool attr_done = false;                                                                                                \
+        if (!attr_done) {                                                                                                             \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_>),                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * PIECE + 3 * (NT_ / 2) * PIECE));                  \
+            attr_done = true;                                                                                                         \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_>), dim3(nwg), dim3(kThreads), shm, st, A, lda, w_hi,     \
+                           w_mid, w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg);          \
+    } while (0)
+#define MR_GEMM_LAUNCH4(ACT_, HASR_, PF2_, NP_)                           \
+    do {                                                                  \
+        if (NP_ == 2 && wide) MR_GEMM_LAUNCH5(ACT_, HASR_, PF2_, 2, 4);   \
+        else MR_GEMM_LAUNCH5(ACT_, HASR_, PF2_, NP_, 2);                  \
+    } while (0)
 #define MR_GEMM_LAUNCH3(ACT_, HASR_, PF2_)                          \
     do {                                                            \
         if (products == 6) MR_GEMM_LAUNCH4(ACT_, HASR_, PF2_, 3);   \
@@ -334,5 +371,6 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
 #undef MR_GEMM_LAUNCH
 #undef MR_GEMM_LAUNCH3
 #undef MR_GEMM_LAUNCH4
+#undef MR_GEMM_LAUNCH5
     return mr::check_launch();
 }
