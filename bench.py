@@ -211,7 +211,7 @@ def main():
             sec = r["ms"] / 1e3
             ent = dict(launches=r["launches"], avg_ms=r["ms"] / max(r["launches"], 1), share_of_step=r["ms"] / (elapsed * 1e3))
             if r["flops"] > 0:
-                if name in ("gemm_nt_bf16x6", "gemm_nt_bf16x3"):  # 6 (3) bf16 MFMA flops are executed per algorithmic flop; peak = dense bf16 MFMA
+                if name.endswith(("bf16x6", "bf16x3")):  # 6 (3) bf16 MFMA flops are executed per algorithmic flop; peak = dense bf16 MFMA
                     np_ = 6 if name.endswith("x6") else 3
                     ent.update(bound="mfma", achieved=r["flops"] / sec / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
                                mfma_flops_per_algorithmic_flop=np_, mfma_utilization=np_ * r["flops"] / sec / 1e12 / MFMA_BF16_PEAK_TF)
