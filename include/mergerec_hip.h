@@ -104,6 +104,23 @@ int mr_ties_combine_f32(float* sparse, int64_t stride, int N, int64_t P, mr_stre
  * replaces: merger/algorithms/localize_and_stitch.py:43-49. */
 int mr_lns_combine_f32(const float* tv, const uint8_t* mask, int64_t stride, int N, int64_t P, float* out, mr_stream_t stream);
 
+/* *out (device float) = the k-th largest element of x[0..n): by value (is_signed != 0) or by magnitude (the |x| value).
+ * Order statistics for PCB's quantile clamps: sorted_x[j] (ascending) is the (n - j)-th largest.
+ * replaces: torch.sort(...)[index] in merger/algorithms/pcb.py:15-25 (_clamp). */
+int mr_kth_largest_value_f32(const float* x, int64_t n, int64_t k, int is_signed, float* out, void* ws, size_t ws_bytes,
+                             mr_stream_t stream);
+
+/* PCB, per task row `row` of tv (N rows of length P, COMPACT layout -- pads would shift the quantiles):
+ * clamped = sign(tau) * clamp(|tau|, lo, hi); task_pcb = exp(N * ((clamp - lo)/(hi - lo))^2) * tanh(tau * sum_j tau_j);
+ * q_lo_hi = device [lo, hi].   replaces: merger/algorithms/pcb.py:44-52. */
+int mr_pcb_stage1_f32(const float* tv, int64_t stride, int N, int row, int64_t P, const float* q_lo_hi, float* clamped,
+                      float* task_pcb, mr_stream_t stream);
+
+/* out_i = clamped_i * scale_i / max(sum_j scale_j, 1e-12) / N with scale_i = (clamp(task_pcb_i, q2[2i], q2[2i+1]) - q2[2i]) /
+ * (q2[2i+1] - q2[2i]).   replaces: merger/algorithms/pcb.py:54-58. */
+int mr_pcb_stage2_f32(const float* clamped, const float* task_pcb, int64_t stride, int N, int64_t P, const float* q2, float* out,
+                      mr_stream_t stream);
+
 /* ---- encoder: token packing + embeddings --------------------------------------------------- */
 
 /* From the reference's padded batch tensors (int64 (B, L), row-major) build packed per-token index

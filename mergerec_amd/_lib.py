@@ -40,6 +40,9 @@ SIGNATURES = {
     "mr_abs_topk_mask_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "mr_ties_combine_f32": (c_i, [c_p, c_i64, c_i, c_i64, c_p]),
     "mr_lns_combine_f32": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_p, c_p]),
+    "mr_kth_largest_value_f32": (c_i, [c_p, c_i64, c_i64, c_i, c_p, c_p, c_sz, c_p]),
+    "mr_pcb_stage1_f32": (c_i, [c_p, c_i64, c_i, c_i, c_i64, c_p, c_p, c_p, c_p]),
+    "mr_pcb_stage2_f32": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_p, c_p, c_p]),
     "mr_pack_tokens": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mr_embed_gather_ln_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p]),
     "mr_gemm_nt_bias_act_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p]),

@@ -21,12 +21,21 @@ struct SelectState {  // lives in the caller's workspace
 };
 
 __device__ __forceinline__ unsigned abs_key(float f) { return __float_as_uint(f) & 0x7fffffffu; }
+// order-preserving key of a signed float (-0.0 == +0.0); larger value <=> larger key
+__device__ __forceinline__ unsigned ord_key(float f) {
+    unsigned u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+template <int SIGNED>
+__device__ __forceinline__ unsigned sel_key(float f) { return SIGNED ? ord_key(f) : abs_key(f); }
 
 __global__ void select_init_kernel(SelectState* st, long long k) {
     if (threadIdx.x == 0) { st->prefix = 0u; st->mask = 0u; st->remaining = k; st->total_eq = 0; }
     st->hist[threadIdx.x] = 0u;
 }
 
+template <int SIGNED>
 __global__ __launch_bounds__(kThreads) void abs_hist_kernel(const float* __restrict__ x, int64_t n, int shift,
                                                            SelectState* __restrict__ st) {
     __shared__ unsigned h[256];
@@ -36,14 +45,14 @@ __global__ __launch_bounds__(kThreads) void abs_hist_kernel(const float* __restr
     const int64_t n4 = n >> 2;
     for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < n4; v += (int64_t)gridDim.x * kThreads) {
         const float4 f = reinterpret_cast<const float4*>(x)[v];
-        const unsigned k0 = abs_key(f.x), k1 = abs_key(f.y), k2 = abs_key(f.z), k3 = abs_key(f.w);
+        const unsigned k0 = sel_key<SIGNED>(f.x), k1 = sel_key<SIGNED>(f.y), k2 = sel_key<SIGNED>(f.z), k3 = sel_key<SIGNED>(f.w);
         if ((k0 & mask) == prefix) atomicAdd(&h[(k0 >> shift) & 0xffu], 1u);
         if ((k1 & mask) == prefix) atomicAdd(&h[(k1 >> shift) & 0xffu], 1u);
         if ((k2 & mask) == prefix) atomicAdd(&h[(k2 >> shift) & 0xffu], 1u);
         if ((k3 & mask) == prefix) atomicAdd(&h[(k3 >> shift) & 0xffu], 1u);
     }
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
-        const unsigned kk = abs_key(x[i]);
+        const unsigned kk = sel_key<SIGNED>(x[i]);
         if ((kk & mask) == prefix) atomicAdd(&h[(kk >> shift) & 0xffu], 1u);
     }
     __syncthreads();
@@ -197,6 +206,57 @@ __global__ __launch_bounds__(kThreads) void lns_combine_kernel(const float* __re
     }
 }
 
+// converts the selected key back to the float value it encodes
+__global__ void select_publish_value_kernel(const SelectState* st, int is_signed, float* out) {
+    if (threadIdx.x == 0) {
+        unsigned k = st->prefix;
+        if (is_signed) k = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+        *out = __uint_as_float(k);
+    }
+}
+
+// pcb.py:44-52 for one task row: a = clamp(|tau|, lo, hi); clamped = sign(tau) * a; self = ((a - lo) / (hi - lo))^2;
+// task_pcb = exp(n * self) * tanh(tau * sum_j tau_j).  q holds [lo, hi] of this row (device).
+__global__ __launch_bounds__(kThreads) void pcb_stage1_kernel(const float* __restrict__ tv_all, int64_t stride, int N, int row,
+                                                             int64_t P, const float* __restrict__ q,
+                                                             float* __restrict__ clamped, float* __restrict__ task_pcb) {
+    const float lo = q[0], hi = q[1];
+    const float* tv = tv_all + (int64_t)row * stride;
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < P; p += (int64_t)gridDim.x * kThreads) {
+        const float t = tv[p];
+        float a = fabsf(t);
+        a = fminf(fmaxf(a, lo), hi);
+        const float sgn = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f);
+        clamped[p] = sgn * a;
+        float nrm = (a - lo) / (hi - lo);
+        nrm = nrm * nrm;
+        float sum = 0.f;
+        for (int j = 0; j < N; ++j) sum += tv_all[(int64_t)j * stride + p];
+        task_pcb[p] = expf((float)N * nrm) * tanhf(t * sum);
+    }
+}
+
+// pcb.py:54-58: scale_i = (clamp(task_pcb_i, q_i, max_i) - q_i) / (max_i - q_i); out_i = clamped_i * scale_i / max(sum_j scale_j, 1e-12) / n
+__global__ __launch_bounds__(kThreads) void pcb_stage2_kernel(const float* __restrict__ clamped, const float* __restrict__ task_pcb,
+                                                             int64_t stride, int N, int64_t P, const float* __restrict__ q2,
+                                                             float* __restrict__ out) {
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < P; p += (int64_t)gridDim.x * kThreads) {
+        float ssum = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float lo = q2[2 * j], hi = q2[2 * j + 1];
+            const float x = fminf(fmaxf(task_pcb[(int64_t)j * stride + p], lo), hi);
+            ssum += (x - lo) / (hi - lo);
+        }
+        const float den = fmaxf(ssum, 1e-12f);
+        for (int j = 0; j < N; ++j) {
+            const float lo = q2[2 * j], hi = q2[2 * j + 1];
+            const float x = fminf(fmaxf(task_pcb[(int64_t)j * stride + p], lo), hi);
+            const float sc = (x - lo) / (hi - lo);
+            out[(int64_t)j * stride + p] = clamped[(int64_t)j * stride + p] * sc / den / (float)N;
+        }
+    }
+}
+
 inline int64_t nchunks(int64_t n) { return (n + kChunk - 1) / kChunk; }
 inline unsigned stream_blocks(int64_t n) {
     int64_t b = (n / 4 + kThreads - 1) / kThreads;
@@ -222,7 +282,7 @@ extern "C" int mr_abs_kth_largest_f32(const float* x, int64_t n, int64_t k, uint
     hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, st, s, (long long)k);
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        hipLaunchKernelGGL(abs_hist_kernel, dim3(stream_blocks(n)), dim3(kThreads), 0, st, x, n, shift, s);
+        hipLaunchKernelGGL(abs_hist_kernel<0>, dim3(stream_blocks(n)), dim3(kThreads), 0, st, x, n, shift, s);
         hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, st, s, shift);
     }
     hipLaunchKernelGGL(select_publish_kernel, dim3(1), dim3(64), 0, st, s, thr_bits, reinterpret_cast<long long*>(need_eq));
@@ -255,5 +315,44 @@ extern "C" int mr_lns_combine_f32(const float* tv, const uint8_t* mask, int64_t 
     if (!tv || !mask || !out || N < 1 || P < 0 || stride < P) return MR_EINVAL;
     if (P == 0) return MR_OK;
     hipLaunchKernelGGL(lns_combine_kernel, dim3(stream_blocks(P * 4)), dim3(kThreads), 0, (hipStream_t)stream, tv, mask, stride, N, P, out);
+    return mr::check_launch();
+}
+
+// value of the k-th largest element of x (is_signed: by value; else by magnitude), written to *out (device float)
+extern "C" int mr_kth_largest_value_f32(const float* x, int64_t n, int64_t k, int is_signed, float* out, void* ws, size_t ws_bytes,
+                                        mr_stream_t stream) {
+    if (!x || !out || !ws || n < 1 || k < 1 || k > n) return MR_EINVAL;
+    if (!mr::aligned16(x) || !mr::aligned16(ws)) return MR_EALIGN;
+    if (ws_bytes < mr_select_ws_bytes(n)) return MR_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    SelectState* s = reinterpret_cast<SelectState*>(ws);
+    hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, st, s, (long long)k);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (is_signed)
+            hipLaunchKernelGGL(abs_hist_kernel<1>, dim3(stream_blocks(n)), dim3(kThreads), 0, st, x, n, shift, s);
+        else
+            hipLaunchKernelGGL(abs_hist_kernel<0>, dim3(stream_blocks(n)), dim3(kThreads), 0, st, x, n, shift, s);
+        hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, st, s, shift);
+    }
+    hipLaunchKernelGGL(select_publish_value_kernel, dim3(1), dim3(64), 0, st, s, is_signed, out);
+    return mr::check_launch();
+}
+
+extern "C" int mr_pcb_stage1_f32(const float* tv, int64_t stride, int N, int row, int64_t P, const float* q_lo_hi, float* clamped,
+                                 float* task_pcb, mr_stream_t stream) {
+    if (!tv || !q_lo_hi || !clamped || !task_pcb || N < 1 || row < 0 || row >= N || P < 0 || stride < P) return MR_EINVAL;
+    if (P == 0) return MR_OK;
+    hipLaunchKernelGGL(pcb_stage1_kernel, dim3(stream_blocks(P * 4)), dim3(kThreads), 0, (hipStream_t)stream, tv, stride, N, row, P,
+                       q_lo_hi, clamped, task_pcb);
+    return mr::check_launch();
+}
+
+extern "C" int mr_pcb_stage2_f32(const float* clamped, const float* task_pcb, int64_t stride, int N, int64_t P, const float* q2,
+                                 float* out, mr_stream_t stream) {
+    if (!clamped || !task_pcb || !q2 || !out || N < 1 || P < 0 || stride < P) return MR_EINVAL;
+    if (P == 0) return MR_OK;
+    hipLaunchKernelGGL(pcb_stage2_kernel, dim3(stream_blocks(P * 4)), dim3(kThreads), 0, (hipStream_t)stream, clamped, task_pcb, stride,
+                       N, P, q2, out);
     return mr::check_launch();
 }

@@ -252,10 +252,20 @@ def load_merging_module(
                 ops.lns_combine(tv, masks, out=tv)          # localize_and_stitch.py:43-49
                 del masks, scratch
     elif merge_type is MergeType.PCB:
-        raise NotImplementedError(
-            "PCB task-vector pre-processing (two per-row quantile clamps + exp/tanh maps, one-shot at init) is not built yet "
-            "(SURVEY 8(f).1); TASK_VECTOR, TIES and LOCALIZE_AND_STITCH are"
-        )
+        # pcb.py:37-58 works on order statistics of each row, so it runs on the COMPACT vectors (arena pads would shift the
+        # quantiles); the result is scattered back into arena layout.  density defaults to 0.2 (pcb.py:37).
+        density = ties_density if ties_density is not None else 0.2
+        compact = torch.stack([layout.compact(tv[i]) for i in range(n)]).contiguous()
+        pcb = ops.pcb_vectors(compact, density)
+        tv.zero_()
+        off = 0
+        for k, shp in layout.shapes.items():
+            cnt = 1
+            for x_ in shp:
+                cnt *= x_
+            tv[:, layout.offsets[k] : layout.offsets[k] + cnt] = pcb[:, off : off + cnt]
+            off += cnt
+        del compact, pcb
     else:
         raise ValueError(f"Invalid merge type: {merge_type}")
 

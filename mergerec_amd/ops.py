@@ -145,6 +145,39 @@ def abs_topk_mask(x: torch.Tensor, k: int, out: Optional[torch.Tensor] = None, w
     return y, m
 
 
+def kth_largest_value(x: torch.Tensor, k: int, signed: bool, out: torch.Tensor) -> torch.Tensor:
+    """out[0] (device float) = k-th largest element of x by value (signed) or by magnitude."""
+    _dev(x, "x", torch.float32)
+    lib = _lib.load()
+    n = x.numel()
+    nbytes = lib.mr_select_ws_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(lib.mr_kth_largest_value_f32(ptr(x), n, k, int(signed), ptr(out), ptr(ws), nbytes, _stream(x)), "mr_kth_largest_value_f32")
+    return out
+
+
+def pcb_vectors(tv: torch.Tensor, density: float) -> torch.Tensor:
+    """merger/algorithms/pcb.py:37-58 on a COMPACT (N, P) task-vector matrix; returns the (N, P) PCB vectors."""
+    _dev(tv, "tv", torch.float32)
+    N, d = tv.shape
+    lib = _lib.load()
+    q1 = torch.empty(N, 2, dtype=torch.float32, device=tv.device)
+    q2 = torch.empty(N, 2, dtype=torch.float32, device=tv.device)
+    clamped, task = torch.empty_like(tv), torch.empty_like(tv)
+    j_lo, j_hi = int(d * 0.01), int(d * (1 - 0.01) - 1)          # _clamp(|tv|, 0.01, 0.01): ascending indices
+    for i in range(N):
+        kth_largest_value(tv[i], d - j_lo, False, q1[i, 0:1])
+        kth_largest_value(tv[i], d - j_hi, False, q1[i, 1:2])
+        check(lib.mr_pcb_stage1_f32(ptr(tv), tv.stride(0), N, i, d, ptr(q1[i]), ptr(clamped[i]), ptr(task[i]), _stream(tv)), "mr_pcb_stage1_f32")
+    j_lo2, j_hi2 = int(d * (1 - density)), int(d * (1 - 0) - 1)  # _clamp(task_pcb, 1 - density, 0)
+    for i in range(N):
+        kth_largest_value(task[i], d - j_lo2, True, q2[i, 0:1])
+        kth_largest_value(task[i], d - j_hi2, True, q2[i, 1:2])
+    out = torch.empty_like(tv)
+    check(lib.mr_pcb_stage2_f32(ptr(clamped), ptr(task), tv.stride(0), N, d, ptr(q2), ptr(out), _stream(tv)), "mr_pcb_stage2_f32")
+    return out
+
+
 def ties_combine(sparse: torch.Tensor) -> torch.Tensor:
     """In place on (N, P) masked updates: TIES sign election + disjoint mean."""
     _dev(sparse, "sparse", torch.float32)

@@ -162,8 +162,6 @@ def test_merging_module_errors_mirror_reference():
     mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, g2["pretrain"], [dict(f) for f in g2["finetunes"]], set())
     with pytest.raises(AssertionError):
         mm.load_weights_from_dict({"global_weights": {"nope": [1.0]}, "global_biases": {}, "per_weights": {}})
-    with pytest.raises(NotImplementedError):
-        load_merging_module(MergeType.PCB, LearnType.TASK_WISE, model, g2["pretrain"], [dict(f) for f in g2["finetunes"]], set(), ties_density=0.2)
     with pytest.raises(AssertionError):
         load_merging_module(MergeType.TIES, LearnType.TASK_WISE, _tiny_model(g2["cfg"]), g2["pretrain"], [dict(f) for f in g2["finetunes"]], set())
 
@@ -382,3 +380,27 @@ def test_coalesced_batches_give_identical_results():
     for m, e, u, idx in res[1:]:
         assert m == res[0][0]
         assert torch.equal(e, res[0][1]) and torch.equal(u, res[0][2]) and torch.equal(idx, res[0][3])
+
+
+def test_pcb_vectors_match_reference_golden():
+    from mergerec_amd import ops
+
+    for case in load_golden("g6_taskvector_algos.pt")["cases"]:
+        base, models, dens = case["base"], case["models"], case["density"]
+        tv = torch.stack([m - base for m in models]).to(DEV).contiguous()
+        got = ops.pcb_vectors(tv, dens).cpu()
+        ref = case["pcb"]
+        assert torch.allclose(got, ref, rtol=2e-4, atol=1e-9), ((got - ref).abs().max(), ref.abs().max())
+
+
+def test_load_merging_module_pcb():
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+
+    g2 = load_golden("g2_merger.pt")
+    mm = load_merging_module(MergeType.PCB, LearnType.TASK_WISE, _tiny_model(g2["cfg"]), g2["pretrain"], [dict(f) for f in g2["finetunes"]],
+                             set(), ties_density=0.2, disable_softmax=True)
+    pre, al = O.align_state_dicts(g2["pretrain"], g2["finetunes"])
+    base, _ = O.flatten_model(pre)
+    want = O.pcb_vectors(base, [O.flatten_model(f)[0] for f in al], 0.2)
+    got = mm.compact_task_vectors().cpu()
+    assert torch.allclose(got, want, rtol=2e-4, atol=1e-9), (got - want).abs().max()
