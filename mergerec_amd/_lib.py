@@ -6,6 +6,7 @@ non-zero code, a MergeRecHipError is raised.
 from __future__ import annotations
 
 import ctypes
+import os
 import re
 from pathlib import Path
 
@@ -74,12 +75,13 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    path = Path(os.environ.get("MERGEREC_HIP_LIB", LIB_PATH))  # override: A/B-testing another build of the same ABI
+    if not path.exists():
         raise MergeRecHipError(
-            f"{LIB_PATH} is missing: build it with `python -m mergerec_amd.build` (hipcc, gfx950). "
+            f"{path} is missing: build it with `python -m mergerec_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback for the merged-inference path."
         )
-    lib = ctypes.CDLL(str(LIB_PATH))
+    lib = ctypes.CDLL(str(path))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

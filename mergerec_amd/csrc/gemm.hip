@@ -23,7 +23,7 @@ constexpr int kThreads = 256;
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <int ACT, bool HAS_R>
-__global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
+__global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ w0, const float* __restrict__ w1,
     const float* __restrict__ w2, const float* __restrict__ b0, const float* __restrict__ b1,
     const float* __restrict__ b2, int M, int seg_n, int K, const float* __restrict__ R, int64_t ldr,
@@ -129,37 +129,55 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const bool interior = (m0 + BM <= M) && (n0 + BN <= seg_n);
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).
+    // One branch-free path for interior and edge tiles: C and R are addressed through tile-local buffer resources whose
+    // num_records ends at the tile's last valid element, so rows past M are dropped by the hardware bounds check and
+    // lanes whose column is past seg_n carry an out-of-range offset.  (Per-element guards put every store in its own
+    // basic block behind `s_waitcnt vmcnt(0)`, i.e. each store waited for the previous one to complete.)
+    const int rows_valid = (M - m0) < BM ? (M - m0) : BM;
+    const int cols_valid = (seg_n - n0) < BN ? (seg_n - n0) : BN;
+    const int64_t col0 = (int64_t)seg * seg_n + n0;
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+        C + (int64_t)m0 * ldc + col0, 0, (int)(((int64_t)(rows_valid - 1) * ldc + cols_valid) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(HAS_R ? R + (int64_t)m0 * ldr + col0 : C), 0,
+        HAS_R ? (int)(((int64_t)(rows_valid - 1) * ldr + cols_valid) * 4) : 0, 0x00020000);
+    // opaque copies of the lane coordinates: keeps this address arithmetic from being hoisted above the main loop
+    int lr_e = lr, lh_e = lh;
+    asm volatile("" : "+v"(lr_e), "+v"(lh_e));
+    const uint32_t ldc4 = (uint32_t)ldc * 4u, ldr4 = (uint32_t)ldr * 4u;
+    float bz[2];
+    uint32_t coff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + lr;
-        const bool col_ok = interior || col < seg_n;
-        const float bz = (bias && col_ok) ? bias[col] : 0.f;
-        const int64_t colg = (int64_t)seg * seg_n + col;
+        const int colt = wn * 64 + j * 32 + lr_e;
+        const bool ok = colt < cols_valid;
+        bz[j] = bias ? bias[n0 + (ok ? colt : cols_valid - 1)] : 0.f;
+        coff[j] = ok ? (uint32_t)colt * 4u : 0x80000000u;
+    }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rbase = m0 + wm * 64 + i * 32 + 4 * lh;
-            if (interior) {
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t rowt = wm * 64 + i * 32 + 4 * lh_e;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r] + bz;
-                    if (ACT == MR_ACT_GELU_ERF) v = gelu_erf(v);
-                    if (HAS_R) v += R[row * ldr + colg];
-                    C[row * ldc + colg] = v;
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // four rows at a time (one accumulator quad)
+                float v[4], rr[4];
+                if (HAS_R) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        rr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (rowt + r + 8 * q) * ldr4 + coff[j], 0, 0));
                 }
-            } else if (col_ok) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (row < M) {
-                        float v = acc[i][j][r] + bz;
-                        if (ACT == MR_ACT_GELU_ERF) v = gelu_erf(v);
-                        if (HAS_R) v += R[row * ldr + colg];
-                        C[row * ldc + colg] = v;
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][j][4 * q + r] + bz[j];
+                    if (ACT == MR_ACT_GELU_ERF) v[r] = gelu_erf(v[r]);
+                    if (HAS_R) v[r] += rr[r];
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[r]), crs, (rowt + r + 8 * q) * ldc4 + coff[j], 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -179,6 +197,7 @@ extern "C" int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float*
     if (lda & 3) return MR_EALIGN;  // A and W rows are read as float4; C and R are accessed per element
     if (!mr::aligned16(A) || !mr::aligned16(w0) || (w1 && !mr::aligned16(w1)) || (w2 && !mr::aligned16(w2)))
         return MR_EALIGN;
+    if (ldc < 1 || ldc > (1 << 21) || (R && (ldr < 1 || ldr > (1 << 21)))) return MR_EUNSUPPORTED;  // 32-bit tile-local offsets in the epilogue
     if (M == 0) return MR_OK;
     const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n_seg = (seg_n + BN - 1) / BN;
