@@ -18,6 +18,13 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+// phase-timing hooks: empty in the library; exp/gemm_phases.hip defines them to accumulate s_memtime deltas per phase
+#ifndef MR_PH_DECL
+#define MR_PH_DECL
+#define MR_PH(i)
+#define MR_PH_FLUSH(pid)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -98,15 +105,22 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
     const uint16_t* __restrict__ wl, int64_t off0, int64_t off1, int64_t off2, const float* __restrict__ b0,
     const float* __restrict__ b1, const float* __restrict__ b2, int M, int seg_n, int K,
     const float* __restrict__ R, int64_t ldr, float* __restrict__ C, int64_t ldc, int tiles_n_seg, int tiles_n,
-    int nwg) {
+    int nwg, int group_n, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUF bytes
     constexpr int BN = 64 * NT;                 // 128 or 256 columns per workgroup
     constexpr int BPIECE = (BN / 128) * PIECE;  // bytes of one B piece tile
     constexpr int BOFF = 3 * PIECE;             // B pieces start behind the (up to) three A pieces
     constexpr int BUF = BOFF + 3 * BPIECE;
 
+    // Column-group-major tile order: all row tiles of the first group_n column tiles, then the next group.  The weight
+    // panels of one group (group_n x BN x K x 4 B) stay resident in each XCD's 4 MiB L2 while the activations stream past
+    // once per group; inside a group the column tile runs fastest, so the workgroups sharing an A panel are co-resident.
     const int pid = mr::xcd_remap(blockIdx.x, nwg);
-    const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
+    const int per_group = tiles_m * group_n;
+    const int ng = pid / per_group;
+    const int rem = pid - ng * per_group;
+    const int gw = (tiles_n - ng * group_n) < group_n ? (tiles_n - ng * group_n) : group_n;  // width of this (maybe last) group
+    const int tm = rem / gw, tn = ng * group_n + (rem - tm * gw);
     const int seg = tn / tiles_n_seg;
     const int n0 = (tn - seg * tiles_n_seg) * BN;
     const int m0 = tm * BM;
@@ -168,19 +182,39 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
     };
     auto lstore = [&](const Stage& st, unsigned char* buf) {
         uint2 h, m, l;
+#if defined(MR_ABL_NOSPLIT)  // diagnostic: no conversion work (wrong numerics)
+        h = make_uint2(__float_as_uint(st.a0.x), __float_as_uint(st.a0.y)); m = make_uint2(__float_as_uint(st.a0.z), __float_as_uint(st.a0.w)); l = h;
+#else
         split4(st.a0, h, m, l);
+#endif
+#if defined(MR_ABL_NOLDSWRITE)  // diagnostic: values only kept alive
+        asm volatile("" ::"v"(h.x), "v"(h.y), "v"(m.x), "v"(m.y), "v"(l.x), "v"(l.y));
+#else
         *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa0) = h;
         *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa0) = m;
         if (NP == 3) *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa0) = l;
+#endif
+#if defined(MR_ABL_NOSPLIT)
+        h = make_uint2(__float_as_uint(st.a1.x), __float_as_uint(st.a1.y)); m = make_uint2(__float_as_uint(st.a1.z), __float_as_uint(st.a1.w)); l = h;
+#else
         split4(st.a1, h, m, l);
+#endif
+#if defined(MR_ABL_NOLDSWRITE)
+        asm volatile("" ::"v"(h.x), "v"(h.y), "v"(m.x), "v"(m.y), "v"(l.x), "v"(l.y));
+#else
         *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa1) = h;
         *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa1) = m;
         if (NP == 3) *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa1) = l;
+#endif
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {  // rows brow + 128 q: same swizzle bit
+#if defined(MR_ABL_NOLDSWRITE)
+            asm volatile("" ::"v"(st.bh[q].x), "v"(st.bh[q].w), "v"(st.bm[q].x), "v"(st.bm[q].w));
+#else
             *reinterpret_cast<uint4*>(buf + BOFF + 0 * BPIECE + q * PIECE + wb) = st.bh[q];
             *reinterpret_cast<uint4*>(buf + BOFF + 1 * BPIECE + q * PIECE + wb) = st.bm[q];
             if (NP == 3) *reinterpret_cast<uint4*>(buf + BOFF + 2 * BPIECE + q * PIECE + wb) = st.bl[q];
+#endif
         }
     };
     auto compute = [&](const unsigned char* buf) {
@@ -210,6 +244,12 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
             }
     };
 
+#ifdef MR_GEMM_SLOT_PRIO
+    // the two waves sharing a SIMD (one per resident workgroup) sit in different wave slots: give the odd slot priority so the
+    // pair runs in anti-phase (one wave's MFMA burst beside the other's staging phase) instead of contending in lockstep
+    if (__builtin_amdgcn_s_getreg(0x1804) & 1) __builtin_amdgcn_s_setprio(2);
+#endif
+    MR_PH_DECL
     const int nk = K / BK;
     auto ktile = [&](int kt) { return (kt < nk ? kt : 0) * BK; };  // past-the-end prefetches re-read tile 0 (never consumed)
     unsigned char* buf0 = lds;
@@ -224,18 +264,49 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
         gload(s1, ktile(1));
         gload(s0, ktile(2));
         __syncthreads();
+        MR_PH(0)
+        // NP == 2, NT == 4 (the bf16x3 hot path): one scheduling region per k-tile -- this tile's 24 MFMAs interleaved with
+        // the split + LDS store of the next tile and the global prefetch two tiles further on, so the wave's own VALU / LDS /
+        // VMEM work runs in the gaps of its MFMA stream instead of after it (measured +6..9 %; a wave does not start the
+        // staging phase until its queued MFMAs have drained, and the co-resident workgroup covers little of that).
+#define MR_SGB(m, n) __builtin_amdgcn_sched_group_barrier(m, n, 0)
+#define MR_SLOT_V MR_SGB(0x008, 1); MR_SGB(0x002, 2);
+#define MR_SLOT_VD MR_SGB(0x008, 1); MR_SGB(0x002, 2); MR_SGB(0x200, 1);
+#define MR_SLOT_VM MR_SGB(0x008, 1); MR_SGB(0x002, 1); MR_SGB(0x020, 1);
+#define MR_PIPE24                                                                                                        \
+    MR_SLOT_V MR_SLOT_V MR_SLOT_V MR_SLOT_V MR_SLOT_V MR_SLOT_V MR_SLOT_V MR_SLOT_V                                      \
+    MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD                              \
+    MR_SLOT_VM MR_SLOT_VM MR_SLOT_VM MR_SLOT_VM MR_SLOT_VM MR_SLOT_VM MR_SLOT_V MR_SLOT_V
+        constexpr bool ILV = (NP == 2 && NT == 4);
         for (int kt = 0; kt < nk; kt += 2) {
             compute(buf0);
-            __builtin_amdgcn_sched_barrier(0);
+            MR_PH(1)
+            if (!ILV) __builtin_amdgcn_sched_barrier(0);
             lstore(s1, buf1);
+            MR_PH(5)
             gload(s1, ktile(kt + 3));
+            MR_PH(2)
+            if (ILV) { MR_PIPE24 }
             __syncthreads();
-            compute(buf1);
             __builtin_amdgcn_sched_barrier(0);
+            MR_PH(3)
+            compute(buf1);
+            MR_PH(1)
+            if (!ILV) __builtin_amdgcn_sched_barrier(0);
             lstore(s0, buf0);
+            MR_PH(5)
             gload(s0, ktile(kt + 4));
+            MR_PH(2)
+            if (ILV) { MR_PIPE24 }
             __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            MR_PH(3)
         }
+#undef MR_PIPE24
+#undef MR_SLOT_VM
+#undef MR_SLOT_VD
+#undef MR_SLOT_V
+#undef MR_SGB
     } else {
         Stage s0;
         gload(s0, 0);
@@ -304,6 +375,8 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
             }
         }
     }
+    MR_PH(4)
+    MR_PH_FLUSH(pid)
 }
 
 }  // namespace
@@ -354,33 +427,38 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
     // wide (128 x 256) tiles when a segment is a multiple of 256 columns and the grid still fills the chip
     static const int force_nt = [] { const char* e = getenv("MR_GEMM_NT"); return e ? atoi(e) : 0; }();
     const int tiles_m = (M + BM - 1) / BM;
-    // (three-piece x6 staging does not fit the register file next to 128 accumulators: narrow tiles there)
-    bool wide = products == 3 && (seg_n % 256 == 0) && ((int64_t)tiles_m * (seg_n / 256) * nseg >= 512);
+    bool wide = (seg_n % 256 == 0) && ((int64_t)tiles_m * (seg_n / 256) * nseg >= 512);
     if (force_nt == 2) wide = false;
-    if (force_nt == 4 && products == 3 && (seg_n % 256 == 0 || nseg == 1)) wide = true;
+    if (force_nt == 4 && (seg_n % 256 == 0 || nseg == 1)) wide = true;
     const int BN = wide ? 256 : 128;
     const int tiles_n_seg = (seg_n + BN - 1) / BN;
     const int tiles_n = tiles_n_seg * nseg;
     const int64_t nwg64 = (int64_t)tiles_m * tiles_n;
     if (nwg64 > 0x7fffffff) return MR_EUNSUPPORTED;
     const int nwg = (int)nwg64;
+    static const int force_gn = [] { const char* e = getenv("MR_GEMM_GROUPN"); return e ? atoi(e) : 0; }();
+    int group_n = tiles_n;
+    if (force_gn > 0) group_n = force_gn < tiles_n ? force_gn : tiles_n;
     hipStream_t st = (hipStream_t)stream;
-    const size_t shm = 2 * (size_t)(3 * PIECE + 3 * (BN / 128) * PIECE);  // 48 KB (narrow) / 72 KB (wide)
-    const bool pf2 = ((K / BK) % 2 == 0);
+    static const int shm_pad = [] { const char* e = getenv("MR_GEMM_SHM_PAD"); return e ? atoi(e) : 0; }();  // diagnostic: lowers occupancy
+    const size_t shm = 2 * (size_t)(3 * PIECE + 3 * (BN / 128) * PIECE) + shm_pad;  // 48 KB (narrow) / 72 KB (wide)
+    // (three pieces + 128 accumulators + two staging sets do not fit 256 VGPRs: the wide x6 kernel prefetches one tile ahead)
+    const bool pf2 = ((K / BK) % 2 == 0) && !(wide && products == 6);
 #define MR_GEMM_LAUNCH5(ACT_, HASR_, PF2_, NP_, NT_)                                                                                  \
     do {                                                                                                                              \
         static bool attr_done = false;                                                                                                \
         if (!attr_done) {                                                                                                             \
             hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_>),                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * PIECE + 3 * (NT_ / 2) * PIECE));                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * PIECE + 3 * (NT_ / 2) * PIECE) + shm_pad);                  \
             attr_done = true;                                                                                                         \
         }                                                                                                                             \
         hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_>), dim3(nwg), dim3(kThreads), shm, st, A, lda, w_hi,     \
-                           w_mid, w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg);          \
+                           w_mid, w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg, group_n,  \
+                           tiles_m);                                                                                                  \
     } while (0)
 #define MR_GEMM_LAUNCH4(ACT_, HASR_, PF2_, NP_)                           \
     do {                                                                  \
-        if (NP_ == 2 && wide) MR_GEMM_LAUNCH5(ACT_, HASR_, PF2_, 2, 4);   \
+        if (wide) MR_GEMM_LAUNCH5(ACT_, HASR_, PF2_, NP_, 4);             \
         else MR_GEMM_LAUNCH5(ACT_, HASR_, PF2_, NP_, 2);                  \
     } while (0)
 #define MR_GEMM_LAUNCH3(ACT_, HASR_, PF2_)                          \
