@@ -4,10 +4,11 @@
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imergerec_amd/csrc -o exp/gemm_phases exp/gemm_phases.hip
 #include <hip/hip_runtime.h>
 __device__ unsigned long long g_ph[16384 * 8];
-#define MR_PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long ph_t0 = ph_t;
+__device__ unsigned long long g_rt[16384 * 2];
+#define MR_PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long ph_t0 = ph_t; const unsigned long long ph_r0 = __builtin_amdgcn_s_memrealtime();
 #define MR_PH(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += n_ - ph_t; ph_t = n_; }
 #define MR_PH_WAITLOADS(i) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); MR_PH(i) }  /* NT=4, NP=2: the newer stage's 6 loads stay in flight */
-#define MR_PH_FLUSH(pid) if (threadIdx.x == 0 && (pid) < 16384) { for (int z = 0; z < 6; ++z) g_ph[(pid) * 8 + z] = ph_acc[z]; g_ph[(pid) * 8 + 6] = ph_t0; g_ph[(pid) * 8 + 7] = ph_t; }
+#define MR_PH_FLUSH(pid) if (threadIdx.x == 0 && (pid) < 16384) { for (int z = 0; z < 6; ++z) g_ph[(pid) * 8 + z] = ph_acc[z]; g_ph[(pid) * 8 + 6] = ph_t0; g_ph[(pid) * 8 + 7] = ph_t; g_rt[(pid) * 2] = ph_r0; g_rt[(pid) * 2 + 1] = __builtin_amdgcn_s_memrealtime(); }
 #include "../mergerec_amd/csrc/gemm_bf16.hip"
 #include "../mergerec_amd/csrc/capi.hip"
 #include <stdio.h>
@@ -69,6 +70,11 @@ int main(int argc, char** argv) {
             tot += (double)(ph[w * 8 + 7] - ph[w * 8 + 6]);
             tmin = std::min(tmin, ph[w * 8 + 6]); tmax = std::max(tmax, ph[w * 8 + 7]);
         }
+        std::vector<unsigned long long> rt((size_t)16384 * 2);
+        CK(hipMemcpyFromSymbol(rt.data(), HIP_SYMBOL(g_rt), rt.size() * 8));
+        double cs = 0, rs = 0;  // per workgroup (the counters of different XCDs are not aligned): sum of both deltas
+        for (int w = 0; w < n; ++w) { cs += (double)(ph[w * 8 + 7] - ph[w * 8 + 6]); rs += (double)(rt[w * 2 + 1] - rt[w * 2]); }
+        printf("      in-kernel clock: s_memtime / s_memrealtime (100 MHz) over all workgroups = %.3f GHz; mean workgroup life %.1f us\n", cs / rs * 0.1, rs / n / 100.0);
         const int nk = K / 16;
         printf("%-5s M=%d N=%d K=%d products=%d: %.3f ms (%.1f TF alg), %d WGs; kernel span %.0f cyc; per WG avg %.0f cyc = prologue %.0f + loop[compute %.0f + stage %.0f + barrier %.0f] + epilogue %.0f;  per k-tile: compute %.0f split+ldswrite %.0f gload-issue %.0f barrier %.0f\n",
                sh.name, M, N, K, products, ms, 2.0 * M * N * K / ms / 1e9, nwg, (double)(tmax - tmin), tot / n, sum[0] / n, sum[1] / n, sum[2] / n,

@@ -10,8 +10,11 @@
 //     chunks of a row XOR-swizzled by (row >> 1) & 7, so the ds_read_b128 of 16 keys is conflict-free.
 //   * Q is split once per wave into registers; P is split in registers after the softmax (register r = 8 s + j of the score
 //     accumulator is exactly element j of k-step s of the B operand).
-//   * V stays fp32 in LDS ([key][64]); each lane reads the 16 values of its column that the k-steps need (ds_read_b32, as in
-//     attn.hip) and splits them in registers -- a bf16 V image would need a transposed, 2-byte-granular LDS write.
+//   * V is split while it is staged, too: LDS image per piece = [32 keys][64 bf16] row-major (coalesced 8-byte stores), and
+//     the A operand of O^T = V^T P^T (k = key, so column-wise through that image) comes from gfx950's transposed LDS read
+//     ds_read_b64_tr_b16: a 16-lane group fetches a 4-key x 16-d block and lane i receives column i.  The 16-B chunks of a
+//     row are XOR-swizzled by 4 * ((row >> 1) & 1), which makes the 4 rows x 64 B of a 32-lane half hit all 64 banks once.
+//     (Splitting V in registers per wave, as before, cost more VALU time than both MFMA products together.)
 #include "common.h"
 #include <math.h>
 #include <stdint.h>
@@ -21,12 +24,12 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int kDh = 64;
 constexpr int KROWB = 128;           // bytes per K piece row (64 bf16)
 constexpr int KPIECE = 32 * KROWB;   // 4 KB per piece per tile
-constexpr int VBYTES = 32 * 64 * 4;  // fp32 V tile
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
     uint32_t r;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
                                                                 const int32_t* __restrict__ cu,
                                                                 const int32_t* __restrict__ seq_order, int H,
                                                                 float scale_log2e, int window, float* __restrict__ ctx) {
-    constexpr int BUFB = NP * KPIECE + VBYTES;
+    constexpr int BUFB = 2 * NP * KPIECE;  // K pieces, then V pieces
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUFB
     const int b = seq_order ? seq_order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -149,13 +152,24 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
             if (p + 1 < NP) { r0 -= lo_f(w0); r1 -= hi_f(w0); r2 -= lo_f(w1); r3 -= hi_f(w1); }
         }
     };
+    // V piece position of (row, 4-d group sc4): 16-B chunk (sc4 >> 1) ^ (4 * ((row >> 1) & 1)); rows sr and sr + 16 share the bit
+    const int vw0 = sr * KROWB + ((((sc4 >> 1) ^ (((sr >> 1) & 1) << 2)) << 4) | ((sc4 & 1) << 3));
+    const int vw1 = vw0 + 16 * KROWB;
     auto lstore = [&](unsigned char* buf) {
         store_k(kreg0, buf + kw0);
         store_k(kreg1, buf + kw1);
-        float* vs = reinterpret_cast<float*>(buf + NP * KPIECE);
-        *reinterpret_cast<float4*>(vs + sr * kDh + sc) = vreg0;
-        *reinterpret_cast<float4*>(vs + (sr + 16) * kDh + sc) = vreg1;
+        store_k(vreg0, buf + NP * KPIECE + vw0);
+        store_k(vreg1, buf + NP * KPIECE + vw1);
     };
+    // transposed V read: lane 4 q + p4 of a 16-lane group addresses row (4 lh + q) + 16 st + 8 jj, d columns 4 p4 .. + 3 of the
+    // 16-d block g1 of d tile dt; it receives column (lane & 15) of the block's four keys
+    int vtr[2];
+    {
+        const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, g1 = (lane >> 4) & 1, bsw = (q >> 1) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            vtr[dt] = (4 * lh + q) * KROWB + ((4 * (dt ^ bsw) + 2 * g1 + (p4 >> 1)) << 4) + ((p4 & 1) << 3);
+    }
     // K fragment read: lane (key lr, half lh), k-step s -> logical 16-B chunk 2 s + lh of row lr
     const int kswz = (lr >> 1) & 7;
 
@@ -206,19 +220,21 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float corr = (m == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : exp2f(m - m_use);
+            const float corr = (m == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : __builtin_amdgcn_exp2f(m - m_use);
             float ps = 0.f;
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pv[r] = exp2f(s[r] - m_use);
+                pv[r] = __builtin_amdgcn_exp2f(s[r] - m_use);  // raw v_exp_f32 (arguments <= 0; results below 2^-126 flush to 0)
                 ps += pv[r];
             }
             ps += __shfl_xor(ps, 32, 64);
             l = l * corr + ps;
             m = m_new;
+            if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0) {  // wave-uniform: the running maxima usually stop moving early
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+                for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+            }
             // P pieces: k-step st of the second product takes registers 8 st .. 8 st + 7
             u32x4 pp[2][NP];
 #pragma unroll
@@ -227,20 +243,22 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
                                     pv[8 * st + 4], pv[8 * st + 5], pv[8 * st + 6], pv[8 * st + 7]};
                 split8<NP>(x, pp[st]);
             }
-            // ---- O^T += V^T P^T: lane (column d = lr of the 32-wide d tile, half lh) reads V[kb + kappa(r, lh)][d]
-            const float* vp = reinterpret_cast<const float*>(buf + NP * KPIECE) + (4 * lh) * kDh + lr;
+            // ---- O^T += V^T P^T: A operand element j of k-step st is V[kb + (j & 3) + 8 (2 st + (j >> 2)) + 4 lh][d]
+            const unsigned char* vbase = buf + NP * KPIECE;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
-                    float x[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = 8 * st + j;
-                        x[j] = vp[((r & 3) + 8 * (r >> 2)) * kDh + 32 * dt];
-                    }
                     u32x4 va[NP];
-                    split8<NP>(x, va);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const unsigned char* a0 = vbase + p * KPIECE + vtr[dt] + (16 * st) * KROWB;
+                        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                       (__attribute__((address_space(3))) s16x4*)a0));
+                        const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                       (__attribute__((address_space(3))) s16x4*)(a0 + 8 * KROWB)));
+                        va[p][0] = lo.x; va[p][1] = lo.y; va[p][2] = hi.x; va[p][3] = hi.y;
+                    }
                     if (dt == 0) o0 = mfma_split<NP>(va, pp[st], o0);
                     else o1 = mfma_split<NP>(va, pp[st], o1);
                 }
@@ -276,7 +294,7 @@ extern "C" int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, co
     const float scale_log2e = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
 #define MR_ATTN_LAUNCH(W_, NP_)                                                                                          \
-    hipLaunchKernelGGL((attn_split_kernel<W_, NP_>), grid, dim3(kThreads), (size_t)2 * (NP_ * KPIECE + VBYTES), st, qkv, \
+    hipLaunchKernelGGL((attn_split_kernel<W_, NP_>), grid, dim3(kThreads), (size_t)2 * (2 * NP_ * KPIECE), st, qkv,       \
                        cu_seqlens, seq_order, H, scale_log2e, window, ctx)
     if (window >= 0) {
         if (products == 3) MR_ATTN_LAUNCH(true, 2); else MR_ATTN_LAUNCH(true, 3);
