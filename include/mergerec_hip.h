@@ -228,7 +228,9 @@ int mr_attn_global_row_f32(const float* qg, const float* kvg, const int32_t* cu_
 int mr_cls_pool_normalize_f32(const float* x, int64_t ldx, const int32_t* cu_seqlens, int B, int d, int normalize,
                               float* out, mr_stream_t stream);
 
-/* Gather rows x[row_idx[i], :] -> out[i, :] (used to run the last layer's dense blocks on CLS rows only). */
+/* Gather rows x[row_idx[i], :] -> out[i, :] (the last layer's dense blocks run on CLS rows only; teacher rows
+ * S_ds[sequence_id] of module/distiller/sequence/module.py:66).  16-byte vectors when d, ldx, ldo are multiples of 4 and the
+ * pointers 16-byte aligned, one dword per lane otherwise. */
 int mr_gather_rows_f32(const float* x, int64_t ldx, const int32_t* row_idx, int n, int d, float* out, int64_t ldo,
                        mr_stream_t stream);
 
@@ -254,6 +256,21 @@ size_t mr_score_topk_ws_bytes(int64_t nU, int64_t M);
 int mr_score_topk_f32(const float* U, const float* E, int64_t nU, int64_t M, int d, int k, float* top_val,
                       int64_t* top_idx, float* scores_out, const int64_t* labels, float inv_temp, float* row_lse,
                       float* row_lab, int32_t* label_rank, void* ws, size_t ws_bytes, mr_stream_t stream);
+
+/* ---- next-row 2: distillation losses (collaborative merging optimisation, BASELINE config 5) */
+
+/* Per-row value (and gradient) of the reference's distillation losses over logit rows z ("merged model") and t ("single
+ * model"), rows x M, one launch:
+ *   loss_row[r] = w_ce CE(z, label) + w_kd T^2 KL(softmax(t/T) || softmax(z/T)) + w_ent H(softmax z; log(p + 1e-8))
+ *               + w_mse mean_j (z - t)^2 + w_pair relu(margin - (z[pos] - z[neg])) + w_listnet (-sum softmax(t/T) log_softmax(z/T))
+ * label_src: 0 none, 1 argmax t (teacher pseudo-label), 2 argmax z (merged pseudo-label); pos / neg = best / second best of t;
+ * ties go to the lowest index.  dz (may be NULL) receives grad_scale * d loss_row / d z.  The batch loss of every reference
+ * class is the mean of loss_row (CE "mean", KL "batchmean", MSE "mean", ...).  t may be NULL when no term reads it.
+ * replaces: module/recommender/loss_fn.py:37-215 (the eleven DistillLossBase subclasses), called per sample by
+ * module/distiller/sequence/module.py:62-72. */
+int mr_distill_loss_rows_f32(const float* z, int64_t ldz, const float* t, int64_t ldt, int64_t rows, int64_t M, int label_src,
+                             float w_ce, float w_kd, float temperature, float w_ent, float w_mse, float w_pair, float margin,
+                             float w_listnet, float* loss_row, float* dz, int64_t lddz, float grad_scale, mr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,7 @@ SIGNATURES = {
     "mr_kth_largest_value_f32": (c_i, [c_p, c_i64, c_i64, c_i, c_p, c_p, c_sz, c_p]),
     "mr_pcb_stage1_f32": (c_i, [c_p, c_i64, c_i, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "mr_pcb_stage2_f32": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_p, c_p, c_p]),
+    "mr_distill_loss_rows_f32": (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_i64, c_f, c_p]),
     "mr_pack_tokens": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mr_embed_gather_ln_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p]),
     "mr_gemm_nt_bias_act_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p]),

@@ -173,6 +173,17 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __re
     for (int c = lane * 4; c < d; c += MR_WAVE * 4) *reinterpret_cast<float4*>(out + (int64_t)i * ldo + c) = ld4(r + c);
 }
 
+// any width / alignment (teacher-score rows have the catalog's length): one dword per lane, still coalesced
+__global__ __launch_bounds__(kThreads) void gather_rows_scalar_kernel(const float* __restrict__ xin, int64_t ldx,
+                                                                     const int32_t* __restrict__ idx, int n, int d,
+                                                                     float* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* r = xin + (int64_t)idx[i] * ldx;
+    for (int c = lane; c < d; c += MR_WAVE) out[(int64_t)i * ldo + c] = r[c];
+}
+
 #define MR_DISPATCH_NV(d, CALL)                                  \
     do {                                                         \
         const int nv_ = ((d) / 4 + MR_WAVE - 1) / MR_WAVE;       \
@@ -248,9 +259,13 @@ extern "C" int mr_cls_pool_normalize_f32(const float* x, int64_t ldx, const int3
 extern "C" int mr_gather_rows_f32(const float* x, int64_t ldx, const int32_t* row_idx, int n, int d, float* out,
                                   int64_t ldo, mr_stream_t stream) {
     if (!x || !row_idx || !out || n < 0 || d <= 0) return MR_EINVAL;
-    if ((d & 3) || (ldx & 3) || (ldo & 3) || !mr::aligned16(x) || !mr::aligned16(out)) return MR_EALIGN;
     if (n == 0) return MR_OK;
     const unsigned blocks = (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    if ((d & 3) || (ldx & 3) || (ldo & 3) || !mr::aligned16(x) || !mr::aligned16(out)) {
+        hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, row_idx, n, d, out,
+                           ldo);
+        return mr::check_launch();
+    }
     hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, row_idx, n, d, out, ldo);
     return mr::check_launch();
 }

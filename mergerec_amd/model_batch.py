@@ -1,4 +1,4 @@
-"""Mirror of rec_retrieval/types/model_batch.py:19-45 (the hot path's input dataclasses)."""
+"""Mirror of rec_retrieval/types/model_batch.py:19-66 (the input dataclasses of the hot path and of the distillation step)."""
 from __future__ import annotations
 
 from dataclasses import dataclass, fields, replace
@@ -32,3 +32,17 @@ class BatchItem(ToDeviceMixin):
 class BatchSequence(ToDeviceMixin):
     sequence: Any
     labels: torch.Tensor
+
+
+@dataclass
+class BatchSequenceWithNegative(ToDeviceMixin):  # model_batch.py:47-52
+    sequence: Any
+    target: Any
+    negatives: Any = None
+
+
+@dataclass
+class BatchDistillationSequence(ToDeviceMixin):  # model_batch.py:62-66
+    dataset_indexes: list
+    sequence_ids: list
+    sequence: Any

@@ -1,5 +1,8 @@
-"""Mirror of rec_retrieval/module/callbacks.py:18-64 (ItemEncoderMixin, ItemEncodingCallback)."""
+"""Mirror of rec_retrieval/module/callbacks.py:18-64 (ItemEncoderMixin, ItemEncodingCallback) and :139-174 (SaveWeightsCallback)."""
 from __future__ import annotations
+
+from pathlib import Path
+from uuid import uuid4
 
 import torch
 from torch import nn
@@ -36,3 +39,34 @@ class ItemEncodingCallback(ItemEncoderMixin):
         if pl_module.item_embeddings is None:
             print("[Test - epoch start] Encoding items as no item embeddings are found.")
             self.inject_item_embeddings(self.item_dataloader, pl_module)
+
+
+class SaveWeightsCallback:
+    """callbacks.py:139-174: one line per logged step, ``str(dict)`` of {"epoch", "step", "weights"} -- the file format
+    ``merge_test.py --weight_file`` reads back (merge_test.py:67-68; use ``mergerec_amd.utils.load_alpha_file``)."""
+
+    def __init__(self, version: str | None = None, save_dir: str | Path = "weights", log_every_steps: int = 5):
+        if version is None:
+            version = str(uuid4())[:8]
+        self.version = version
+        self.save_dir = Path(save_dir)
+        self.save_file = self.save_dir / f"{version}.jsonl"
+        self.log_every_steps = log_every_steps
+        if not self.save_dir.exists():
+            print(f"{self.__class__.__name__}: Creating directory {self.save_dir.absolute()}.")
+            self.save_dir.mkdir(parents=True, exist_ok=True)
+        self._file_handler = open(self.save_file, "w", encoding="utf-8")
+        print(f"{self.__class__.__name__}: Weights will be saved to {self.save_file.absolute()}.")
+
+    def on_train_batch_end(self, trainer, pl_module, outputs, batch, batch_idx: int) -> None:
+        if batch_idx % self.log_every_steps == 0:
+            line = {"epoch": trainer.current_epoch, "step": trainer.global_step, "weights": pl_module.merged_model.serialize_weights()}
+            self._file_handler.write(f"{line}\n")
+
+    def on_train_epoch_end(self, trainer, pl_module):
+        self._file_handler.flush()
+
+    def teardown(self, trainer, pl_module, stage: str):
+        if self._file_handler:
+            self._file_handler.close()
+            self._file_handler = None

@@ -1,0 +1,155 @@
+"""Mirror of rec_retrieval/module/distiller/sequence/module.py:16-100 (DistillSequenceModule) and of the teacher-matrix
+set-up of merge_train.py:116-126, on the HIP path.
+
+The reference loops over the batch in Python (one (num_items,) matvec + one loss call per sample).  Here the samples are
+grouped by dataset: one fp32 GEMM ``reps_g @ E_ds.T`` per dataset (the ascending-k FMA-chain kernel of the scoring path), the
+teacher rows ``S_ds[sequence_id]`` gathered on the device, and ONE fused loss launch per group that returns the per-row
+losses and d loss / d logits; the batch loss is the mean over all samples, as in module.py:72.
+
+Scope: the loss value, d loss / d logits and d loss / d representations are computed on the device.  The encoder backward
+(representations -> merged parameters -> alpha) is not built, so ``training_step`` cannot
+update alpha yet; ``validation_step`` and the loss path are complete and parity-tested."""
+from __future__ import annotations
+
+from typing import List, Literal, Optional, Sequence
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..model_batch import BatchDistillationSequence, BatchItem, BatchSequenceWithNegative
+from .loss_fn import DistillLossBase
+
+__all__ = ["DistillSequenceModule", "teacher_scores"]
+
+
+def teacher_scores(sequence_embedding: torch.Tensor, item_embedding: torch.Tensor) -> torch.Tensor:
+    """merge_train.py:120-126: S = normalise(seq) @ normalise(item).T, rows normalised by x / ||x|| (no eps, as there)."""
+    item = (item_embedding / item_embedding.norm(dim=-1, keepdim=True)).contiguous()
+    seq = (sequence_embedding / sequence_embedding.norm(dim=-1, keepdim=True)).contiguous()
+    return ops.gemm_nt(seq, [item])
+
+
+def _pad16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+class _GroupLossFn(torch.autograd.Function):
+    """sum over the group's rows of (row loss / batch size), with d / d reps through logits = reps @ E.T."""
+
+    @staticmethod
+    def forward(ctx, reps, E, Et_pad, teacher_rows, loss_fn: DistillLossBase, batch_size: int):
+        logits = ops.gemm_nt(reps.contiguous(), [E])
+        n, M = logits.shape
+        dz_pad = None
+        if reps.requires_grad:
+            dz_pad = torch.zeros(n, _pad16(M), dtype=torch.float32, device=reps.device)  # K of the backward GEMM: multiple of 16
+        rows, _ = ops.distill_loss_rows(logits, teacher_rows, grad_scale=1.0 / batch_size, dz=None if dz_pad is None else dz_pad[:, :M],
+                                        **loss_fn.spec())
+        ctx.dz_pad, ctx.Et_pad = dz_pad, Et_pad
+        return rows.sum() / batch_size
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.dz_pad is None:
+            return None, None, None, None, None, None
+        d_reps = ops.gemm_nt(ctx.dz_pad, [ctx.Et_pad])  # (n, Mpad) @ (d, Mpad).T
+        return d_reps * grad_out, None, None, None, None, None
+
+
+class DistillSequenceModule(nn.Module):
+    def __init__(self, merged_model, score_embeddings: List[torch.Tensor], loss_fn: DistillLossBase, similarity: Literal["dot", "cosine"],
+                 learning_rate: float = 5e-5, trainable_args_kwargs: Optional[dict] = None, device: str = "cuda:0"):
+        super().__init__()
+        self.merged_model = merged_model
+        self.loss_fn = loss_fn
+        self.similarity = similarity
+        self.learning_rate = learning_rate
+        self.trainable_args_kwargs = trainable_args_kwargs or {}
+        self.device = torch.device(device)
+        # teacher matrices live in HBM (the reference keeps up to 18k x 18k fp32 per domain on the host and ships one row
+        # per sample); 288 GB makes the gather a device-side row copy
+        self.score_embeddings = [s.to(self.device, torch.float32).contiguous() for s in score_embeddings]
+        self._items: Optional[List[torch.Tensor]] = None
+        self._items_t: Optional[List[torch.Tensor]] = None
+        self._valid_metrics: list = []
+        self.logged: dict = {}
+
+    # -- item embeddings (set by the item-encoding callback in the reference) -------------------------
+    @property
+    def item_embeddings(self):
+        return self._items
+
+    @item_embeddings.setter
+    def item_embeddings(self, value: Optional[Sequence[torch.Tensor]]):
+        if value is None:
+            self._items = self._items_t = None
+            return
+        self._items = [e.detach().to(self.device, torch.float32).contiguous() for e in value]
+        self._items_t = []
+        for e in self._items:  # E^T with the catalog dimension zero-padded to a multiple of 16 (backward GEMM's K)
+            M, d = e.shape
+            et = torch.zeros(d, _pad16(M), dtype=torch.float32, device=self.device)
+            et[:, :M] = e.T
+            self._items_t.append(et)
+
+    def _maybe_normalize(self, matrix: torch.Tensor):
+        if self.similarity == "cosine":
+            return nn.functional.normalize(matrix, p=2, dim=-1)
+        return matrix
+
+    def forward(self, batch):
+        if isinstance(batch, BatchSequenceWithNegative):
+            return self._forward_sequence_encoding(batch.sequence)
+        elif isinstance(batch, BatchDistillationSequence):
+            return self._forward_distill(batch)
+        elif isinstance(batch, BatchItem):
+            return self._forward_sequence_encoding(batch.items)
+        raise ValueError(f"Invalid batch type {type(batch)}")
+
+    def _forward_sequence_encoding(self, sequence_batch):
+        return self._maybe_normalize(self.merged_model.forward(sequence_batch))
+
+    def distill_loss(self, representations: torch.Tensor, dataset_indexes: Sequence[int], sequence_ids: Sequence[int]) -> torch.Tensor:
+        """module.py:62-72 for already-encoded (and normalised) representations."""
+        assert self._items is not None, "item_embeddings must be set (ItemEncodingCallback) before the distillation loss"
+        B = representations.shape[0]
+        ds = torch.as_tensor(list(dataset_indexes), dtype=torch.int64)
+        sid = torch.as_tensor(list(sequence_ids), dtype=torch.int64)
+        total = None
+        for d_i in sorted(set(ds.tolist())):
+            sel = (ds == d_i).nonzero(as_tuple=True)[0]
+            reps_g = representations.index_select(0, sel.to(representations.device))
+            rows = ops.gather_rows(self.score_embeddings[d_i], sid[sel].to(torch.int32).to(self.device))
+            part = _GroupLossFn.apply(reps_g, self._items[d_i], self._items_t[d_i], rows, self.loss_fn, B)
+            total = part if total is None else total + part
+        return total
+
+    def _forward_distill(self, batch: BatchDistillationSequence):
+        reps = self._forward_sequence_encoding(batch.sequence)
+        return self.distill_loss(reps, batch.dataset_indexes, batch.sequence_ids)
+
+    def log(self, name, value, **kwargs):
+        self.logged[name] = float(value)
+
+    def training_step(self, batch: BatchDistillationSequence, batch_idx: int):
+        loss = self._forward_distill(batch)
+        self.log("train/loss", loss)
+        return loss
+
+    def on_validation_epoch_start(self) -> None:
+        self._valid_metrics = []
+
+    @torch.no_grad()
+    def validation_step(self, batch: BatchDistillationSequence, batch_idx: int, dataloader_idx: int = 0):
+        loss = self._forward_distill(batch)
+        self.log("val/loss", loss)
+        self._valid_metrics.append(loss.item())
+        return loss
+
+    def on_validation_epoch_end(self) -> None:
+        self.log("val/average_loss_epoch", torch.tensor(self._valid_metrics).mean())
+        self._valid_metrics = []
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.merged_model.trainable_parameters(**self.trainable_args_kwargs), lr=self.learning_rate, weight_decay=0.0)

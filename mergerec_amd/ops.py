@@ -416,3 +416,30 @@ def score_topk(U: torch.Tensor, E: torch.Tensor, k: int, labels: Optional[torch.
     check(lib.mr_score_topk_f32(ptr(U), ptr(E), nU, M, d, k, ptr(val), ptr(idx), ptr(scores), ptr(labels), inv_temp, ptr(lse), ptr(lab), ptr(rank), ptr(ws), nbytes, _stream(U)), "mr_score_topk_f32")
     PROF.end(ev, dev, "score_topk", flops=2.0 * nU * M * d, nbytes=4.0 * (nU + M) * d + nU * k * 12)
     return val, idx, lse, lab, rank, scores
+
+
+# ------------------------------------------------------------------------------------------ distillation losses (next-row 2)
+def distill_loss_rows(z: torch.Tensor, t: Optional[torch.Tensor], *, label_src: int = 0, w_ce: float = 0.0, w_kd: float = 0.0,
+                      temperature: float = 1.0, w_ent: float = 0.0, w_mse: float = 0.0, w_pair: float = 0.0, margin: float = 0.0,
+                      w_listnet: float = 0.0, want_grad: bool = False, grad_scale: float = 1.0, dz: Optional[torch.Tensor] = None):
+    """Per-row loss (rows,) and, if asked, grad_scale * d loss_row / d z (rows, M); see mr_distill_loss_rows_f32.
+    ``dz`` may be a caller-owned (rows, M) view with a padded leading dimension."""
+    _dev(z, "z", torch.float32)
+    if z.dim() != 2 or z.stride(1) != 1:
+        raise ValueError("z must be a (rows, M) matrix with unit column stride")
+    rows, M = z.shape
+    if t is not None:
+        _dev(t, "t", torch.float32)
+        if t.shape != z.shape or t.stride(1) != 1:
+            raise ValueError("t must match z")
+    loss_row = torch.empty(rows, dtype=torch.float32, device=z.device)
+    if dz is None and want_grad:
+        dz = torch.empty(rows, M, dtype=torch.float32, device=z.device)
+    if dz is not None and (dz.shape != z.shape or dz.stride(1) != 1):
+        raise ValueError("dz must match z")
+    ev = PROF.begin(z.device)
+    check(_lib.load().mr_distill_loss_rows_f32(ptr(z), z.stride(0), ptr(t), t.stride(0) if t is not None else 0, rows, M, label_src, w_ce,
+                                               w_kd, temperature, w_ent, w_mse, w_pair, margin, w_listnet, ptr(loss_row), ptr(dz),
+                                               dz.stride(0) if dz is not None else 0, grad_scale, _stream(z)), "mr_distill_loss_rows_f32")
+    PROF.end(ev, z.device, "distill_loss_rows", flops=0.0, nbytes=4.0 * rows * M * (2 + (1 if dz is not None else 0)))
+    return loss_row, dz

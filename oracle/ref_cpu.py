@@ -535,3 +535,85 @@ def perturbed_state_dict(base: StateDict, seed: int, std: float = 1e-3) -> State
     for k, v in base.items():
         out[k] = v.clone() if not v.is_floating_point() else v + std * torch.randn(v.shape, generator=g)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# next-row 2: distillation losses (rec_retrieval/module/recommender/loss_fn.py) and the teacher
+# matrix (merge_train.py:116-126).  Every loss is "mean over rows of a per-row value", which is
+# what the fused row kernel computes; the per-row forms below follow the reference line by line.
+# ---------------------------------------------------------------------------------------------
+DISTILL_LOSSES = (
+    "CE", "KD", "MSE", "ADAMERGING", "ADAMERGING_KD", "MERGED_PSEUDO_LABEL", "SINGLE_PSEUDO_LABEL",
+    "MERGED_PSEUDO_LABEL_KD", "SINGLE_PSEUDO_LABEL_KD", "PAIRWISE", "LISTNET",
+)
+
+
+def distill_kd(z: torch.Tensor, t: torch.Tensor, temperature: float) -> torch.Tensor:
+    """loss_fn.py:52-60 (DistillKDLoss): batchmean KL(softmax(t/T) || softmax(z/T)) * T^2."""
+    return F.kl_div(F.log_softmax(z / temperature, dim=-1), F.softmax(t / temperature, dim=-1), reduction="batchmean") * (
+        temperature * temperature
+    )
+
+
+def distill_entropy(z: torch.Tensor) -> torch.Tensor:
+    """loss_fn.py:64-69 (DistillAdaMergingLoss): mean row entropy with log(p + 1e-8)."""
+    p = F.softmax(z, dim=-1)
+    return (-torch.sum(p * torch.log(p + 1e-8), dim=-1)).mean()
+
+
+def distill_pairwise(z: torch.Tensor, t: torch.Tensor, margin: float) -> torch.Tensor:
+    """loss_fn.py:183-199 (DistillPairwiseLoss): teacher's best = positive, second best = negative."""
+    pos = torch.argmax(t, dim=-1)
+    masked = t.clone()
+    masked.scatter_(1, pos.unsqueeze(1), float("-inf"))
+    neg = torch.argmax(masked, dim=-1)
+    ps = z.gather(1, pos.unsqueeze(1)).squeeze(1)
+    ns = z.gather(1, neg.unsqueeze(1)).squeeze(1)
+    return F.relu(margin - (ps - ns)).mean()
+
+
+def distill_listnet(z: torch.Tensor, t: torch.Tensor, temperature: float) -> torch.Tensor:
+    """loss_fn.py:208-215 (DistillListNetLoss)."""
+    return -(F.softmax(t / temperature, dim=-1) * F.log_softmax(z / temperature, dim=-1)).sum(dim=-1).mean()
+
+
+def distill_loss(name: str, z: torch.Tensor, t: torch.Tensor, temperature: float = 0.05, coefficient: float = 1000.0,
+                 margin: float = 0.1) -> torch.Tensor:
+    """The reference's loss classes by LossType name (loss_fn.py:37-215; factory :217-267)."""
+    if name == "CE" or name == "SINGLE_PSEUDO_LABEL":  # :40-44, :135-142 -- teacher argmax is the label
+        return F.cross_entropy(z, torch.argmax(t, dim=-1))
+    if name == "KD":
+        return distill_kd(z, t, temperature)
+    if name == "MSE":  # :171-175
+        return F.mse_loss(z, t, reduction="mean")
+    if name == "ADAMERGING":
+        return distill_entropy(z)
+    if name == "ADAMERGING_KD":  # :82-88
+        return distill_entropy(z) + coefficient * distill_kd(z, t, temperature)
+    if name == "MERGED_PSEUDO_LABEL":  # :95-104 -- the student's own argmax is the label
+        return F.cross_entropy(z, torch.argmax(z, dim=-1))
+    if name == "MERGED_PSEUDO_LABEL_KD":  # :112-125
+        return F.cross_entropy(z, torch.argmax(z, dim=-1)) + coefficient * distill_kd(z, t, temperature)
+    if name == "SINGLE_PSEUDO_LABEL_KD":  # :150-163 (cfg5's loss: T = 0.05, coefficient = 1000)
+        return F.cross_entropy(z, torch.argmax(t, dim=-1)) + coefficient * distill_kd(z, t, temperature)
+    if name == "PAIRWISE":
+        return distill_pairwise(z, t, margin)
+    if name == "LISTNET":
+        return distill_listnet(z, t, temperature)
+    raise ValueError(name)
+
+
+def teacher_scores(sequence_embedding: torch.Tensor, item_embedding: torch.Tensor) -> torch.Tensor:
+    """merge_train.py:120-126: rows normalised by x / x.norm(dim=-1, keepdim=True), then S = seq @ item.T."""
+    item = item_embedding / item_embedding.norm(dim=-1, keepdim=True)
+    seq = sequence_embedding / sequence_embedding.norm(dim=-1, keepdim=True)
+    return seq @ item.T
+
+
+def forward_distill(reps: torch.Tensor, item_embeddings, score_embeddings, dataset_indexes, sequence_ids, loss) -> torch.Tensor:
+    """distiller/sequence/module.py:59-74: per-sample logits rep_i @ E_ds.T against the teacher row, mean over the batch."""
+    losses = []
+    for i, (ds, sid) in enumerate(zip(dataset_indexes, sequence_ids)):
+        logit = reps[i] @ item_embeddings[ds].T
+        losses.append(loss(logit.unsqueeze(0), score_embeddings[ds][sid].unsqueeze(0)))
+    return torch.stack(losses).mean()

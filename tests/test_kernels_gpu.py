@@ -215,6 +215,8 @@ def test_layernorm_and_cls_pool(ops, d):
     assert torch.equal(got, x[cu[:-1].long()])
     idx = torch.tensor([300, 0, 17], dtype=torch.int32)
     assert torch.equal(ops.gather_rows(x.to(DEV), idx.to(DEV)).cpu(), x[idx.long()])
+    y = torch.randn(9, 333)  # unaligned width: scalar path
+    assert torch.equal(ops.gather_rows(y.to(DEV), idx.to(DEV) % 9).cpu(), y[(idx % 9).long()])
 
 
 # ------------------------------------------------------------------ K4 attention

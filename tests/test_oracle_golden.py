@@ -144,3 +144,27 @@ def test_taskvector_algorithms_match_reference():
         assert torch.equal(O.localize_and_stitch_vectors(base, models, dens), case["lns"])
         got = O.pcb_vectors(base, models, dens)
         assert torch.allclose(got, case["pcb"], rtol=1e-5, atol=1e-9), (got - case["pcb"]).abs().max()
+
+
+def test_distill_losses_match_reference():
+    """oracle restatement of loss_fn.py vs the values and autograd gradients the reference's own classes produced"""
+    g7 = load_golden("g7_distill_losses.pt")
+    seen = set()
+    for c in g7["cases"]:
+        z = c["z"].clone().requires_grad_(True)
+        loss = O.distill_loss(c["loss"], z, c["t"], c["temperature"], c["coefficient"], c["margin"])
+        (grad,) = torch.autograd.grad(loss, z)
+        assert torch.allclose(loss, c["value"], rtol=1e-6, atol=1e-7), (c["loss"], loss, c["value"])
+        assert torch.allclose(grad, c["grad"], rtol=1e-5, atol=1e-9), (c["loss"], (grad - c["grad"]).abs().max())
+        seen.add(c["loss"])
+    assert seen == set(O.DISTILL_LOSSES)
+
+
+def test_forward_distill_matches_reference():
+    f = load_golden("g7_distill_losses.pt")["forward_distill"]
+    reps = f["reps"].clone().requires_grad_(True)
+    loss = O.forward_distill(reps, f["item_embeddings"], f["score_embeddings"], f["dataset_indexes"], f["sequence_ids"],
+                             lambda z, t: O.distill_loss(f["loss"], z, t, f["temperature"], f["coefficient"]))
+    (g,) = torch.autograd.grad(loss, reps)
+    assert torch.allclose(loss, f["value"], rtol=1e-6)
+    assert torch.allclose(g, f["rep_grad"], rtol=1e-5, atol=1e-8)

@@ -7,7 +7,7 @@ Only the dispatches of the timed region are used: the last `launches_per_step * 
 import collections, csv, glob, json, sys
 
 # kernel-name substring -> (family name used by bench.py's LaunchProfiler, launches per bench step)
-FAMILIES = {"gemm_nt_bf16x6_kernel": ("gemm_nt_bf16x", 48), "gemm_nt_kernel": ("gemm_nt", 48), "attn_kernel": ("attention", 12),
+FAMILIES = {"gemm_nt_bf16x6_kernel": ("gemm_nt_bf16x", 48), "gemm_nt_kernel": ("gemm_nt", 48), "attn_kernel": ("attention", 12), "attn_split_kernel": ("attention_bf16x", 12),
             "merge_nway_kernel": ("merge_nway", 1), "split_weights_kblock_kernel": ("split_weights", 1),
             "embed_gather_ln_kernel": ("embed_gather_ln", 1), "layernorm_kernel": ("layernorm", 24), "topk_rows_kernel": ("topk_rows", 1)}
 
