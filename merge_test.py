@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Drop-in for the reference's merge_test.py (merge_test.py:16-110) on MI355X: same flag names (TestMergeConfig,
 configs/base.py:22-108, configs/test.py:34-43), argparse instead of tyro.  Flags of subsystems outside the path
-(--lora.*, --sequence_prompt/--item_prompt/--max_attribute_len/--max_items/--reverse_sequence: text side) are
-accepted and ignored with a note; --precision must be 32-true (parity configuration).
+(--lora.*) are accepted and ignored with a note; --data_paths may be dataset directories in the reference's JSON format
+(then --tokenizer_path must be a local tokenizer directory) or the pre-tokenised / synthetic specs of mergerec_amd/data.py; --precision must be 32-true (parity configuration).
 
 Example (synthetic weights + data, 2-domain merge):
   python merge_test.py --model_type BLAIR_BASE --model_kwargs init_seed 7 \
@@ -141,6 +141,25 @@ def main(argv=None):
     )
     model.load_state_dict(state_dict)
     module = RecModule(model=model, evaluator=Evaluator(metrics=config.metric_names, ks=config.ks), negative_sample=None, similarity=config.similarity)
+
+    if all((Path(p) / "train.json").exists() for p in config.test_data_paths):
+        # dataset directories in the reference's JSON format: the datamodule route (needs a local tokenizer directory)
+        from mergerec_amd.datamodule import load_tokenizer
+        from mergerec_amd.utils import test_model_from_paths
+
+        if not config.tokenizer_path:
+            raise SystemExit("--tokenizer_path <local tokenizer directory> is required for JSON dataset directories (the box is offline)")
+        tokenizer = load_tokenizer(config.tokenizer_path)
+        _, metrics, scores, labels = test_model_from_paths(
+            module, ModelType[config.model_type], [Path(p) for p in config.test_data_paths], tokenizer, config.batch_size, config.max_seq_len,
+            config.max_attribute_len, config.max_items, config.num_workers, config.sequence_prompt, config.item_prompt,
+            str(config.reverse_sequence).lower() in ("1", "true", "yes"), config.precision, config.test_data_split,
+            metrics_path=config.metrics_path, predictions_path=config.predictions_path, item_embeddings_path=config.item_embeddings_path,
+            user_embeddings_path=config.user_embeddings_path,
+        )
+        for p, m in zip(config.test_data_paths, metrics):
+            print(Path(p).name, {k: round(v, 5) for k, v in m.items()})
+        return metrics
 
     kind = "recformer" if config.model_type.startswith("RECFORMER") else "roberta"
     domains = [load_domain(p, kind=kind, vocab=model.spec.vocab) for p in config.test_data_paths]

@@ -1,0 +1,348 @@
+"""Input pipeline of the path: dataset JSON -> item / sequence batches.
+
+Mirrors, without Lightning:
+  * ``load_json_files``            rec_retrieval/datamodule/recommender/utils.py:7-37
+  * ``RecItemDataset`` / ``RecDataset``   rec_retrieval/datamodule/dataset.py:9-53
+  * ``SingleItemCollator`` / ``ItemSequenceCollator``     datamodule/collator/recommender/recommender.py:14-128
+  * ``RecDataModule``              datamodule/recommender/datamodule.py:17-151 (text flattening :101-114)
+  * ``tokenize_item`` / ``concat_tokenized_items`` / ``pad_tokenized_sequences``   datamodule/utils/recformer_utils.py:12-118
+  * ``RecformerSingleItemCollator`` / ``RecformerItemSequenceCollator``    datamodule/collator/recommender/recformer.py:14-97
+  * ``RecDataModuleForRecformer``  datamodule/recommender/recformer.py:28-140
+
+File formats (one directory per domain): ``train/val/test.json`` user-id -> item-id list (val / test hold only the new
+interaction; the full sequences are train + val (+ test)), ``smap.json`` asin -> item id in id order, ``umap.json``,
+``meta_data.json`` asin -> {attribute: text}.  Item ids are catalog rows: the item dataloader walks ``smap`` values in order,
+so row r of the item-embedding matrix is item id r (callbacks.py:18-38).
+
+The tokenizer is any *local* ``transformers`` tokenizer directory (``load_tokenizer``; the box is offline).  Batches are the
+dataclasses of ``model_batch.py`` holding int64 (B, L) tensors -- exactly what ``EncoderRunner.pack`` consumes.  Parity: the
+reference's own collators were run on a synthetic dataset with a local tokenizer (tests/golden/g8_datamodule.pt)."""
+from __future__ import annotations
+
+import json
+import random
+from collections import namedtuple
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from .model_batch import BatchItem, BatchSequence, BatchSequenceWithNegative
+
+__all__ = [
+    "load_json_files", "load_tokenizer", "RecItemDataset", "RecDataset", "SingleItemCollator", "ItemSequenceCollator", "RecDataModule",
+    "TokenizedItem", "TokenizedSequence", "tokenize_item", "concat_tokenized_items", "pad_tokenized_sequences",
+    "RecformerSingleItemCollator", "RecformerItemSequenceCollator", "RecDataModuleForRecformer",
+]
+
+TokenizedItem = namedtuple("TokenizedItem", ["input_ids", "token_type_ids", "attr_type_ids"])
+TokenizedSequence = namedtuple(
+    "TokenizedSequence", ["input_ids", "token_type_ids", "attr_type_ids", "item_position_ids", "attention_mask", "global_attention_mask"]
+)
+
+
+def load_tokenizer(path):
+    """A tokenizer from a local directory (no hub access on the box)."""
+    from transformers import AutoTokenizer
+
+    p = Path(path)
+    if not p.is_dir():
+        raise FileNotFoundError(f"tokenizer directory {p} not found: the box is offline, pass a local tokenizer directory")
+    return AutoTokenizer.from_pretrained(str(p), local_files_only=True)
+
+
+# ------------------------------------------------------------------------------------------------ files and datasets
+def _read(path: Path):
+    with open(path, "r") as f:
+        return json.load(f)
+
+
+def load_json_files(dataset_path: Path, max_items: int):
+    """utils.py:7-37.  Returns (item_dataset, train, val, test, metadata by item id, umap, smap)."""
+    dataset_path = Path(dataset_path)
+    train_seq, val_seq, test_seq = ({int(k): v for k, v in _read(dataset_path / f"{s}.json").items()} for s in ("train", "val", "test"))
+    metadata, umap, smap = _read(dataset_path / "meta_data.json"), _read(dataset_path / "umap.json"), _read(dataset_path / "smap.json")
+    # the evaluation sequences are cumulative: val = train + val, test = train + val + test (utils.py:23-26)
+    for k in val_seq:
+        val_seq[k] = train_seq.get(k, []) + val_seq[k]
+    for k in test_seq:
+        test_seq[k] = val_seq.get(k, []) + test_seq[k]
+    by_id = {smap[asin]: meta for asin, meta in metadata.items() if asin in smap}
+    return (RecItemDataset(list(smap.values())), RecDataset(train_seq, False, max_items), RecDataset(val_seq, False, max_items),
+            RecDataset(test_seq, False, max_items), by_id, umap, smap)
+
+
+class RecItemDataset(Dataset):
+    """dataset.py:9-17."""
+
+    def __init__(self, items: List[int]):
+        self.items = items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, index) -> int:
+        return self.items[index]
+
+
+class RecDataset(Dataset):
+    """dataset.py:31-53: (index, last max_items + 1 interactions); ``sample`` draws a random prefix (training only)."""
+
+    def __init__(self, sequence: Dict[int, List[int]], sample: bool, max_items: int):
+        self.sequence = list(sequence.values())
+        self.sample = sample
+        self.max_items = max_items
+
+    def __len__(self):
+        return len(self.sequence)
+
+    def __getitem__(self, index) -> Tuple[int, List[int]]:
+        seq = self.sequence[index]
+        if self.sample:
+            if len(seq) < 2:
+                return seq  # (as the reference: a bare list for degenerate sequences)
+            seq = seq[: random.randint(2, len(seq))]
+        return index, seq[-(self.max_items + 1):]
+
+
+def _split_sequences(batch, reverse: bool):
+    """recommender.py:62-74 / recformer.py:47-59: inputs = all but the last interaction (most recent first when reversed)."""
+    inputs, targets = [], []
+    for _, seq in batch:
+        head = seq[:-1]
+        inputs.append(head[::-1] if reverse else head)
+        targets.append(seq[-1])
+    return inputs, targets
+
+
+# ------------------------------------------------------------------------------------------------ text (BLaIR) collators
+class SingleItemCollator:
+    """recommender.py:14-35."""
+
+    def __init__(self, tokenizer, item_text: Dict[int, str], max_seq_len: int, item_prompt: str = ""):
+        self.tokenizer, self.item_text, self.max_seq_len, self.item_prompt = tokenizer, item_text, max_seq_len, item_prompt
+
+    def _encode(self, texts):
+        return self.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=self.max_seq_len)
+
+    def __call__(self, batch: List[int]) -> BatchItem:
+        return BatchItem(items=self._encode([self.item_prompt + self.item_text[i] for i in batch]))
+
+
+class ItemSequenceCollator(SingleItemCollator):
+    """recommender.py:38-128."""
+
+    def __init__(self, tokenizer, item_text: Dict[int, str], max_seq_len: int, num_negative: Optional[int], in_batch_negative: bool,
+                 separator: str = "; ", sequence_prompt: str = "", item_prompt: str = "", reverse_sequence: bool = True):
+        super().__init__(tokenizer, item_text, max_seq_len, item_prompt)
+        self.num_negative, self.in_batch_negative = num_negative, in_batch_negative
+        self.separator, self.sequence_prompt, self.reverse_sequence = separator, sequence_prompt, reverse_sequence
+        self._all_items = set(item_text.keys())
+
+    def _text(self, items: Sequence[int]) -> str:
+        return self.sequence_prompt + self.separator.join(self.item_text[i] for i in items)
+
+    def __call__(self, batch):
+        inputs, targets = _split_sequences(batch, self.reverse_sequence)
+        if not self.reverse_sequence:
+            # oldest-first sequences are cut from the front until they fit (recommender.py:79-92); reversed ones rely on the
+            # tokenizer's right truncation, which drops the oldest items
+            cut = []
+            for items in inputs:
+                items = list(items)
+                while len(self.tokenizer.tokenize(self._text(items))) > self.max_seq_len:
+                    items.pop(0)
+                cut.append(items)
+            inputs = cut
+        sequence = self._encode([self._text(items) for items in inputs])
+        if self.num_negative is None and not self.in_batch_negative:
+            return BatchSequence(sequence=sequence, labels=torch.tensor(targets, dtype=torch.long))
+        target = self._encode([self.item_prompt + self.item_text[t] for t in targets])
+        negatives = None
+        if self.num_negative is not None:
+            neg = []
+            for seq in batch:  # as the reference: set() of the (index, items) tuple -- raises TypeError there too (sampled negatives
+                # are a fine-tuning option, not on the inference path)
+                neg.extend(random.sample(list(self._all_items - set(seq)), self.num_negative))
+            negatives = self._encode([self.item_prompt + self.item_text[n] for n in neg])
+        return BatchSequenceWithNegative(sequence=sequence, target=target, negatives=negatives)
+
+
+class _DataModuleBase:
+    """The dataloader surface shared by both datamodules (datamodule.py:116-151, recformer.py:106-140)."""
+
+    batch_size: int
+    num_workers: int
+
+    def _loader(self, dataset, collate, shuffle=False, drop_last=False):
+        return DataLoader(dataset, batch_size=self.batch_size, collate_fn=collate, shuffle=shuffle, num_workers=self.num_workers,
+                          drop_last=drop_last)
+
+    def item_dataloader(self):
+        return self._loader(self.item_dataset, self.item_collator)
+
+    def train_dataloader(self):
+        return self._loader(self.train_dataset, self.sequence_train_collator, shuffle=True, drop_last=True)
+
+    def val_dataloader(self):
+        return self._loader(self.val_dataset, self.sequence_eval_collator)
+
+    def test_dataloader(self):
+        return self._loader(self.test_dataset, self.sequence_eval_collator)
+
+
+class RecDataModule(_DataModuleBase):
+    """datamodule.py:17-151.  ``negative_sample`` needs ``.k`` and ``.in_batch`` (NegativeSampleConfig); None = full catalog."""
+
+    def __init__(self, dataset_path, tokenizer, batch_size: int, max_seq_len: int, max_attribute_len: int, max_items: int,
+                 negative_sample=None, num_workers: int = 0, sequence_prompt: Optional[str] = None, item_prompt: Optional[str] = None,
+                 reverse_sequence: bool = True):
+        self.dataset_path, self.tokenizer = Path(dataset_path), tokenizer
+        self.batch_size, self.max_seq_len, self.max_attribute_len, self.max_items = batch_size, max_seq_len, max_attribute_len, max_items
+        self.negative_sample, self.num_workers, self.reverse_sequence = negative_sample, num_workers, reverse_sequence
+        self.sequence_prompt = sequence_prompt or ""
+        self.item_prompt = item_prompt or ""
+        self.item_dataset = self.train_dataset = self.val_dataset = self.test_dataset = None
+        self.metadata = self.item_text = None
+        self.item_collator = self.sequence_train_collator = self.sequence_eval_collator = None
+
+    def setup(self, stage: str = "test"):
+        self.item_dataset, self.train_dataset, self.val_dataset, self.test_dataset, self.metadata, _, _ = load_json_files(
+            self.dataset_path, self.max_items)
+        self.item_text = {item_id: self._flatten_key_value(meta) for item_id, meta in self.metadata.items()}
+        self.item_collator = SingleItemCollator(self.tokenizer, self.item_text, self.max_seq_len, self.item_prompt)
+        k = getattr(self.negative_sample, "k", None)
+        in_batch = getattr(self.negative_sample, "in_batch", False)
+        common = dict(sequence_prompt=self.sequence_prompt, item_prompt=self.item_prompt, reverse_sequence=self.reverse_sequence)
+        self.sequence_train_collator = ItemSequenceCollator(self.tokenizer, self.item_text, self.max_seq_len, k, in_batch, **common)
+        self.sequence_eval_collator = ItemSequenceCollator(self.tokenizer, self.item_text, self.max_seq_len, None, False, **common)
+
+    def _flatten_key_value(self, item_metadata: Dict[str, str]) -> str:
+        """datamodule.py:101-114: "key: value" per attribute, the value cut to max_attribute_len TOKENS and detokenised."""
+        parts = []
+        for key, value in item_metadata.items():
+            assert isinstance(value, str), "Item metadata value must be a string"
+            tokens = self.tokenizer.tokenize(value)[: self.max_attribute_len]
+            parts.append(f"{key}: {self.tokenizer.convert_tokens_to_string(tokens)}")
+        return " ".join(parts)
+
+
+# ------------------------------------------------------------------------------------------------ Recformer (pre-tokenised items)
+def tokenize_item(item_metadata: Dict[str, str], tokenizer, attr_name_id_map, max_attribute_len: int) -> TokenizedItem:
+    """recformer_utils.py:12-42: per attribute, key tokens (type 1) + value tokens cut to max_attribute_len (type 2); the
+    attribute id comes from ``attr_name_id_map`` (first-seen order, starting at 1)."""
+    ids, types, attrs = [], [], []
+    for key, value in item_metadata.items():
+        assert isinstance(value, str), "Item metadata value must be a string"
+        k_ids = tokenizer.convert_tokens_to_ids(tokenizer.tokenize(key))
+        v_ids = tokenizer.convert_tokens_to_ids(tokenizer.tokenize(value)[:max_attribute_len])
+        ids += k_ids + v_ids
+        types += [1] * len(k_ids) + [2] * len(v_ids)
+        attrs += [attr_name_id_map[key]] * (len(k_ids) + len(v_ids))
+    return TokenizedItem(input_ids=ids, token_type_ids=types, attr_type_ids=attrs)
+
+
+def concat_tokenized_items(tokenized_items: List[TokenizedItem], bos_token_id: int) -> TokenizedSequence:
+    """recformer_utils.py:45-69: <s> (type 0, position 0, global attention) then the items, item position = 1, 2, ..."""
+    ids, types, attrs, pos = [bos_token_id], [0], [0], [0]
+    for p, item in enumerate(tokenized_items, start=1):
+        ids += item.input_ids
+        types += item.token_type_ids
+        attrs += item.attr_type_ids
+        pos += [p] * len(item.input_ids)
+    n = len(ids)
+    return TokenizedSequence(ids, types, attrs, pos, [1] * n, [1] + [0] * (n - 1))
+
+
+def pad_tokenized_sequences(tokenized_sequences: List[TokenizedSequence], pad_token_id: int, max_length: int,
+                            pad_to_multiple_of: Optional[int] = None):
+    """recformer_utils.py:72-118: right-truncate to min(longest, max_length), pad with (pad id, type 3, 0, 0, 0, 0)."""
+    from transformers import BatchEncoding
+
+    width = min(max(len(s.input_ids) for s in tokenized_sequences), max_length)
+    if pad_to_multiple_of and pad_to_multiple_of > 0 and width % pad_to_multiple_of:
+        width = min(-(-width // pad_to_multiple_of) * pad_to_multiple_of, max_length)
+    fills = dict(input_ids=pad_token_id, token_type_ids=3, attr_type_ids=0, item_position_ids=0, attention_mask=0, global_attention_mask=0)
+    data = {}
+    for name, fill in fills.items():
+        rows = []
+        for seq in tokenized_sequences:
+            v = getattr(seq, name)[:width]
+            rows.append(v + [fill] * (width - len(v)))
+        data[name] = rows
+    return BatchEncoding(data=data, tensor_type="pt")
+
+
+class RecformerSingleItemCollator:
+    """recformer.py:14-33 (collator)."""
+
+    def __init__(self, bos_token_id: int, pad_token_id: int, tokenized_items: Dict[int, TokenizedItem], max_seq_len: int):
+        self.bos_token_id, self.pad_token_id = bos_token_id, pad_token_id
+        self.tokenized_items, self.max_seq_len = tokenized_items, max_seq_len
+
+    def _encode(self, groups: List[List[int]]):
+        seqs = [concat_tokenized_items([self.tokenized_items[i] for i in g], self.bos_token_id) for g in groups]
+        return pad_tokenized_sequences(seqs, self.pad_token_id, self.max_seq_len)
+
+    def __call__(self, batch: List[int]) -> BatchItem:
+        return BatchItem(items=self._encode([[i] for i in batch]))
+
+
+class RecformerItemSequenceCollator(RecformerSingleItemCollator):
+    """recformer.py:36-97 (collator): always most-recent-first."""
+
+    def __init__(self, bos_token_id: int, pad_token_id: int, tokenized_items, max_seq_len: int, num_negative: Optional[int],
+                 in_batch_negative: bool):
+        super().__init__(bos_token_id, pad_token_id, tokenized_items, max_seq_len)
+        self.num_negative, self.in_batch_negative = num_negative, in_batch_negative
+        self._all_items = set(tokenized_items.keys())
+
+    def __call__(self, batch):
+        inputs, targets = _split_sequences(batch, True)
+        sequence = self._encode(inputs)
+        if self.num_negative is None and not self.in_batch_negative:
+            return BatchSequence(sequence=sequence, labels=torch.tensor(targets, dtype=torch.long))
+        target = self._encode([[t] for t in targets])
+        negatives = None
+        if self.num_negative is not None:
+            neg = []
+            for seq in batch:
+                neg.extend(random.sample(list(self._all_items - set(seq)), self.num_negative))
+            negatives = self._encode([[n] for n in neg])
+        return BatchSequenceWithNegative(sequence=sequence, target=target, negatives=negatives)
+
+
+class _FirstSeenIds(dict):
+    """attribute name -> 1, 2, 3, ... in first-seen order (recformer.py:19-25's counter behind a defaultdict)."""
+
+    def __missing__(self, key):
+        self[key] = len(self) + 1
+        return self[key]
+
+
+class RecDataModuleForRecformer(_DataModuleBase):
+    """recformer.py:28-140 (datamodule)."""
+
+    def __init__(self, dataset_path, tokenizer, batch_size: int, max_seq_len: int, max_attribute_len: int, max_items: int,
+                 negative_sample=None, num_workers: int = 0):
+        self.dataset_path, self.tokenizer = Path(dataset_path), tokenizer
+        self.batch_size, self.max_seq_len, self.max_attribute_len, self.max_items = batch_size, max_seq_len, max_attribute_len, max_items
+        self.negative_sample, self.num_workers = negative_sample, num_workers
+        self.bos_token_id, self.pad_token_id = tokenizer.bos_token_id, tokenizer.pad_token_id
+        self._attr_name_id_map = _FirstSeenIds()
+        self.item_dataset = self.train_dataset = self.val_dataset = self.test_dataset = None
+        self.metadata = self.tokenized_items = None
+        self.item_collator = self.sequence_train_collator = self.sequence_eval_collator = None
+
+    def setup(self, stage: str = "test"):
+        self.item_dataset, self.train_dataset, self.val_dataset, self.test_dataset, self.metadata, _, _ = load_json_files(
+            self.dataset_path, self.max_items)
+        self.tokenized_items = {
+            item_id: tokenize_item(meta, self.tokenizer, self._attr_name_id_map, self.max_attribute_len) for item_id, meta in self.metadata.items()
+        }
+        args = (self.bos_token_id, self.pad_token_id, self.tokenized_items, self.max_seq_len)
+        self.item_collator = RecformerSingleItemCollator(*args)
+        self.sequence_train_collator = RecformerItemSequenceCollator(*args, getattr(self.negative_sample, "k", None),
+                                                                    getattr(self.negative_sample, "in_batch", False))
+        self.sequence_eval_collator = RecformerItemSequenceCollator(*args, None, False)

