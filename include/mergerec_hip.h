@@ -272,6 +272,35 @@ int mr_distill_loss_rows_f32(const float* z, int64_t ldz, const float* t, int64_
                              float w_ce, float w_kd, float temperature, float w_ent, float w_mse, float w_pair, float margin,
                              float w_listnet, float* loss_row, float* dz, int64_t lddz, float grad_scale, mr_stream_t stream);
 
+/* ---- encoder backward (collaborative-merging optimisation loop, BLaIR / RoBERTa): d loss / d merged parameters.
+ * Every matrix product of the backward pass runs on mr_gemm_nt_bias_act_f32 after an operand re-layout:
+ *   dX = dY W        -> gemm_nt(dY, W^T)          dW = dY^T X -> gemm_nt(dY^T, X^T)   (token dimension zero-padded to 16)
+ * replaces: torch autograd through transformers' RobertaLayer (reached via module/models/encoder/_base.py:37) in
+ * module/distiller/sequence/module.py:76-79 (training_step). */
+
+/* out[c][r] = in[r][c] (r < R, c < C); columns R .. R_pad - 1 of every output row are zero-filled (ldo >= R_pad). */
+int mr_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int64_t ldo, int R_pad, mr_stream_t stream);
+
+/* out[c] = sum_r x[r][c], rows in ascending order (bias gradients). */
+int mr_colsum_f32(const float* x, int64_t ldx, int R, int C, float* out, mr_stream_t stream);
+
+/* du = dh * d/du gelu_erf(u). */
+int mr_gelu_bwd_f32(const float* u, const float* dh, int64_t n, float* du, mr_stream_t stream);
+
+/* LayerNorm backward over the last dimension: dx (T, d); stats (T, 2) receives (mean, rstd) of x; dgamma / dbeta (d) may both
+ * be NULL.  x is the LayerNorm INPUT. */
+int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ldy, const float* gamma, float eps, int T, int d,
+                         float* dx, int64_t lddx, float* stats, float* dgamma, float* dbeta, mr_stream_t stream);
+
+/* Softmax self-attention backward on packed sequences: qkv (T, 3 H dh) = [Q | K | V] and ctx (T, H dh) as in mr_attn_f32,
+ * dctx = d loss / d ctx; rowstat (T, H, 2) is workspace; dqkv (T, 3 H dh) receives [dQ | dK | dV].  dh must be 64. */
+int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, int B, int H, int dh, float scale,
+                    float* rowstat, float* dqkv, mr_stream_t stream);
+
+/* table[idx[t]][:] += src[t][:] (atomic adds: embedding-table gradients; with unique indices a plain row scatter). */
+int mr_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int T, int d, float* table, int64_t ldt,
+                            mr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

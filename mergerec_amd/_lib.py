@@ -45,6 +45,12 @@ SIGNATURES = {
     "mr_pcb_stage1_f32": (c_i, [c_p, c_i64, c_i, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "mr_pcb_stage2_f32": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_p, c_p, c_p]),
     "mr_distill_loss_rows_f32": (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_i64, c_f, c_p]),
+    "mr_transpose_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_i64, c_i, c_p]),
+    "mr_colsum_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
+    "mr_gelu_bwd_f32": (c_i, [c_p, c_p, c_i64, c_p, c_p]),
+    "mr_layernorm_bwd_f32": (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_f, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "mr_attn_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "mr_scatter_add_rows_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_p, c_i64, c_p]),
     "mr_pack_tokens": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mr_embed_gather_ln_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p]),
     "mr_gemm_nt_bias_act_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p]),

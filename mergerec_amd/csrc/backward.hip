@@ -1,0 +1,338 @@
+// K8: backward kernels of the BLaIR (RoBERTa) encoder for the collaborative-merging optimisation loop (merge_train.py,
+// BASELINE config 5 / scripts/3_mergerec/blair_base_taskvector_taskwise.sh): d loss / d merged parameters, which
+// mr_merge_bwd_alpha_f32 reduces to d loss / d alpha.
+//
+// A training step there is 16 short pseudo-user sequences (item texts, ~40 tokens): a few hundred tokens against 125 M
+// parameters, so the step is bound by the parameter-sized streams (merge forward / backward, weight gradients), not by the
+// token-sized math.  These kernels are therefore plain fp32 (exact, deterministic except for the embedding scatter):
+//   transpose          operand re-layout so every backward product runs on the forward's NT GEMM kernel
+//                      (dX = dY W: W^T; dW = dY^T X: dY^T and X^T, the token dimension zero-padded to the GEMM's k-tile)
+//   colsum             bias gradients
+//   gelu_bwd           d pre-activation of the FFN
+//   layernorm_bwd      dx per row (+ saved mean / rstd), dgamma / dbeta by a column pass
+//   attn_bwd           softmax attention backward per (sequence, head): row statistics, dQ (query-owned), dK / dV (key-owned)
+//   scatter_add_rows   embedding-table gradients (atomic adds), CLS-row scatter
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kDh = 64;
+
+// ------------------------------------------------------------------------------------------------ transpose
+// out[c][r] = in[r][c] for r < R, c < C; out rows have ldo >= R_pad columns and columns R .. R_pad - 1 are zero-filled
+__global__ __launch_bounds__(kThreads) void transpose_kernel(const float* __restrict__ in, int64_t ldi, int R, int C,
+                                                            float* __restrict__ out, int64_t ldo, int R_pad) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < R && c < C) ? in[(int64_t)r * ldi + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < C && r < R_pad) out[(int64_t)c * ldo + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// out[c] = sum_r x[r][c]; one thread per column, rows in ascending order (deterministic)
+__global__ __launch_bounds__(kThreads) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int R, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += x[(int64_t)r * ldx + c];
+    out[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ GELU(erf) backward
+__global__ __launch_bounds__(kThreads) void gelu_bwd_kernel(const float* __restrict__ u, const float* __restrict__ dh, int64_t n,
+                                                           float* __restrict__ du) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const float x = u[i];
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+        du[i] = dh[i] * (cdf + x * pdf);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// one wave per row: stats[row] = (mean, rstd) of x; dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma
+__global__ __launch_bounds__(kThreads) void layernorm_bwd_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                                     int64_t ldy, const float* __restrict__ gamma, float eps, int T, int d,
+                                                                     float* __restrict__ dx, int64_t lddx, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const float* xr = x + (int64_t)row * ldx;
+    const float* gr = dy + (int64_t)row * ldy;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += xr[c];
+    const float mean = mr::wave_sum(s) / (float)d;
+    float v = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float t = xr[c] - mean;
+        v += t * t;
+    }
+    const float rstd = rsqrtf(mr::wave_sum(v) / (float)d + eps);
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float g = gr[c] * gamma[c];
+        a += g;
+        b += g * (xr[c] - mean) * rstd;
+    }
+    a = mr::wave_sum(a) / (float)d;
+    b = mr::wave_sum(b) / (float)d;
+    float* o = dx + (int64_t)row * lddx;
+    for (int c = lane; c < d; c += 64) {
+        const float xh = (xr[c] - mean) * rstd;
+        o[c] = rstd * (gr[c] * gamma[c] - a - xh * b);
+    }
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+// dgamma[c] = sum_t dy[t][c] * xhat[t][c], dbeta[c] = sum_t dy[t][c]; one thread per column, ascending rows
+__global__ __launch_bounds__(kThreads) void layernorm_bwd_params_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                                       int64_t ldy, const float* __restrict__ stats, int T, int d,
+                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= d) return;
+    float g = 0.f, b = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float dyv = dy[(int64_t)t * ldy + c];
+        g += dyv * (x[(int64_t)t * ldx + c] - stats[2 * t]) * stats[2 * t + 1];
+        b += dyv;
+    }
+    dgamma[c] = g;
+    dbeta[c] = b;
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward
+// qkv (T, 3 H 64) = [Q | K | V] as the forward; ctx, dctx (T, H 64); rowstat (T, H, 2) = (logsumexp of the scaled scores, delta)
+// One workgroup per (sequence, head).  Scores s_ij = scale * q_i . k_j, p_ij = exp(s_ij - lse_i), delta_i = dO_i . O_i,
+// dS_ij = p_ij (dO_i . v_j - delta_i):  dQ_i = scale sum_j dS_ij k_j;  dK_j = scale sum_i dS_ij q_i;  dV_j = sum_i p_ij dO_i.
+__global__ __launch_bounds__(kThreads) void attn_bwd_stats_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                                 const float* __restrict__ dctx, const int32_t* __restrict__ cu, int H,
+                                                                 float scale, float* __restrict__ rowstat) {
+    const int b = blockIdx.x, h = blockIdx.y;
+    const int t0 = cu[b], len = cu[b + 1] - t0;
+    const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
+    for (int i = threadIdx.x; i < len; i += kThreads) {
+        const float* q = qkv + (int64_t)(t0 + i) * ld + h * kDh;
+        float qr[kDh];
+#pragma unroll
+        for (int d = 0; d < kDh; ++d) qr[d] = q[d];
+        float m = -INFINITY, l = 0.f;
+        for (int j = 0; j < len; ++j) {
+            const float* k = qkv + (int64_t)(t0 + j) * ld + (H + h) * kDh;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < kDh; ++d) s = fmaf(qr[d], k[d], s);
+            s *= scale;
+            const float mn = fmaxf(m, s);
+            l = l * expf(m - mn) + expf(s - mn);
+            m = mn;
+        }
+        const float* o = ctx + (int64_t)(t0 + i) * ldc + h * kDh;
+        const float* g = dctx + (int64_t)(t0 + i) * ldc + h * kDh;
+        float dl = 0.f;
+#pragma unroll
+        for (int d = 0; d < kDh; ++d) dl = fmaf(o[d], g[d], dl);
+        rowstat[((int64_t)(t0 + i) * H + h) * 2] = m + logf(l);
+        rowstat[((int64_t)(t0 + i) * H + h) * 2 + 1] = dl;
+    }
+}
+
+// query-owned pass: thread i holds q_i, dO_i and accumulates dQ_i over all keys (keys / values staged through LDS in tiles of 32)
+__global__ __launch_bounds__(kThreads) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                              const float* __restrict__ rowstat, const int32_t* __restrict__ cu, int H,
+                                                              float scale, float* __restrict__ dqkv) {
+    __shared__ float ks[32][kDh], vs[32][kDh];
+    const int b = blockIdx.x, h = blockIdx.y;
+    const int t0 = cu[b], len = cu[b + 1] - t0;
+    const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
+    for (int i0 = 0; i0 < len; i0 += kThreads) {
+        const int i = i0 + threadIdx.x;
+        const bool on = i < len;
+        const int ic = on ? i : len - 1;
+        float qr[kDh], gr[kDh], acc[kDh];
+        const float* q = qkv + (int64_t)(t0 + ic) * ld + h * kDh;
+        const float* g = dctx + (int64_t)(t0 + ic) * ldc + h * kDh;
+#pragma unroll
+        for (int d = 0; d < kDh; ++d) { qr[d] = q[d]; gr[d] = g[d]; acc[d] = 0.f; }
+        const float lse = rowstat[((int64_t)(t0 + ic) * H + h) * 2], dl = rowstat[((int64_t)(t0 + ic) * H + h) * 2 + 1];
+        for (int j0 = 0; j0 < len; j0 += 32) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < 32 * kDh; e += kThreads) {
+                const int jr = e / kDh, d = e % kDh;
+                const int j = j0 + jr < len ? j0 + jr : len - 1;
+                ks[jr][d] = qkv[(int64_t)(t0 + j) * ld + (H + h) * kDh + d];
+                vs[jr][d] = qkv[(int64_t)(t0 + j) * ld + (2 * H + h) * kDh + d];
+            }
+            __syncthreads();
+            const int nj = (len - j0) < 32 ? (len - j0) : 32;
+            for (int jr = 0; jr < nj; ++jr) {
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < kDh; ++d) {
+                    s = fmaf(qr[d], ks[jr][d], s);
+                    dp = fmaf(gr[d], vs[jr][d], dp);
+                }
+                const float ds = expf(s * scale - lse) * (dp - dl) * scale;
+#pragma unroll
+                for (int d = 0; d < kDh; ++d) acc[d] = fmaf(ds, ks[jr][d], acc[d]);
+            }
+        }
+        if (on) {
+            float* o = dqkv + (int64_t)(t0 + i) * ld + h * kDh;
+#pragma unroll
+            for (int d = 0; d < kDh; ++d) o[d] = acc[d];
+        }
+    }
+}
+
+// key-owned pass: a lane pair (2 j, 2 j + 1) owns key j, each lane one 32-wide half of d; queries staged through LDS
+__global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                               const float* __restrict__ rowstat, const int32_t* __restrict__ cu, int H,
+                                                               float scale, float* __restrict__ dqkv) {
+    __shared__ float qs[32][kDh], gs[32][kDh], st[32][2];
+    const int b = blockIdx.x, h = blockIdx.y;
+    const int t0 = cu[b], len = cu[b + 1] - t0;
+    const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
+    const int half = threadIdx.x & 1, d0 = half * 32;
+    for (int jb = 0; jb < len; jb += kThreads / 2) {
+        const int j = jb + (threadIdx.x >> 1);
+        const bool on = j < len;
+        const int jc = on ? j : len - 1;
+        float kr[32], vr[32], dk[32], dv[32];
+        const float* k = qkv + (int64_t)(t0 + jc) * ld + (H + h) * kDh + d0;
+        const float* v = qkv + (int64_t)(t0 + jc) * ld + (2 * H + h) * kDh + d0;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { kr[d] = k[d]; vr[d] = v[d]; dk[d] = 0.f; dv[d] = 0.f; }
+        for (int i0 = 0; i0 < len; i0 += 32) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < 32 * kDh; e += kThreads) {
+                const int ir = e / kDh, d = e % kDh;
+                const int i = i0 + ir < len ? i0 + ir : len - 1;
+                qs[ir][d] = qkv[(int64_t)(t0 + i) * ld + h * kDh + d];
+                gs[ir][d] = dctx[(int64_t)(t0 + i) * ldc + h * kDh + d];
+            }
+            if (threadIdx.x < 64) {
+                const int ir = threadIdx.x >> 1, i = i0 + ir < len ? i0 + ir : len - 1;
+                st[ir][threadIdx.x & 1] = rowstat[((int64_t)(t0 + i) * H + h) * 2 + (threadIdx.x & 1)];
+            }
+            __syncthreads();
+            const int ni = (len - i0) < 32 ? (len - i0) : 32;
+            for (int ir = 0; ir < ni; ++ir) {
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) {
+                    s = fmaf(qs[ir][d0 + d], kr[d], s);
+                    dp = fmaf(gs[ir][d0 + d], vr[d], dp);
+                }
+                s += __shfl_xor(s, 1, 64);   // the pair's two halves of the dot products (same order in both lanes)
+                dp += __shfl_xor(dp, 1, 64);
+                const float p = expf(s * scale - st[ir][0]);
+                const float ds = p * (dp - st[ir][1]) * scale;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) {
+                    dk[d] = fmaf(ds, qs[ir][d0 + d], dk[d]);
+                    dv[d] = fmaf(p, gs[ir][d0 + d], dv[d]);
+                }
+            }
+        }
+        if (on) {
+            float* ok = dqkv + (int64_t)(t0 + j) * ld + (H + h) * kDh + d0;
+            float* ov = dqkv + (int64_t)(t0 + j) * ld + (2 * H + h) * kDh + d0;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { ok[d] = dk[d]; ov[d] = dv[d]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scatter-add of rows
+// table[idx[t]][:] += src[t][:]  (atomic: several tokens may share a row)
+__global__ __launch_bounds__(kThreads) void scatter_add_rows_kernel(const float* __restrict__ src, int64_t lds_, const int32_t* __restrict__ idx,
+                                                                   int T, int d, float* __restrict__ table, int64_t ldt) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (t >= T) return;
+    float* row = table + (int64_t)idx[t] * ldt;
+    const float* s = src + (int64_t)t * lds_;
+    for (int c = lane; c < d; c += 64) atomicAdd(row + c, s[c]);
+}
+
+}  // namespace
+
+extern "C" int mr_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int64_t ldo, int R_pad, mr_stream_t stream) {
+    if (!in || !out || R < 0 || C < 0 || R_pad < R || ldi < C || ldo < R_pad) return MR_EINVAL;
+    if (R_pad == 0 || C == 0) return MR_OK;
+    const dim3 grid((C + 31) / 32, (R_pad + 31) / 32);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, in, ldi, R, C, out, ldo, R_pad);
+    return mr::check_launch();
+}
+
+extern "C" int mr_colsum_f32(const float* x, int64_t ldx, int R, int C, float* out, mr_stream_t stream) {
+    if (!x || !out || R < 0 || C < 0 || ldx < C) return MR_EINVAL;
+    if (C == 0) return MR_OK;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, R, C, out);
+    return mr::check_launch();
+}
+
+extern "C" int mr_gelu_bwd_f32(const float* u, const float* dh, int64_t n, float* du, mr_stream_t stream) {
+    if (!u || !dh || !du || n < 0) return MR_EINVAL;
+    if (n == 0) return MR_OK;
+    int64_t blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, u, dh, n, du);
+    return mr::check_launch();
+}
+
+extern "C" int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ldy, const float* gamma, float eps, int T, int d,
+                                    float* dx, int64_t lddx, float* stats, float* dgamma, float* dbeta, mr_stream_t stream) {
+    if (!x || !dy || !gamma || !dx || !stats || T < 0 || d < 1 || ldx < d || ldy < d || lddx < d) return MR_EINVAL;
+    if ((dgamma == nullptr) != (dbeta == nullptr)) return MR_EINVAL;
+    if (T == 0) {
+        if (dgamma) {
+            hipMemsetAsync(dgamma, 0, (size_t)d * 4, (hipStream_t)stream);
+            hipMemsetAsync(dbeta, 0, (size_t)d * 4, (hipStream_t)stream);
+        }
+        return mr::check_launch();
+    }
+    hipLaunchKernelGGL(layernorm_bwd_rows_kernel, dim3((T + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, (hipStream_t)stream, x,
+                       ldx, dy, ldy, gamma, eps, T, d, dx, lddx, stats);
+    if (dgamma)
+        hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3((d + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, dy,
+                           ldy, stats, T, d, dgamma, dbeta);
+    return mr::check_launch();
+}
+
+extern "C" int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, int B, int H, int dh,
+                               float scale, float* rowstat, float* dqkv, mr_stream_t stream) {
+    if (!qkv || !ctx || !dctx || !cu_seqlens || !rowstat || !dqkv || B < 0 || H < 1) return MR_EINVAL;
+    if (dh != kDh) return MR_EUNSUPPORTED;
+    if (B == 0) return MR_OK;
+    const dim3 grid(B, H);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_bwd_stats_kernel, grid, dim3(kThreads), 0, st, qkv, ctx, dctx, cu_seqlens, H, scale, rowstat);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(kThreads), 0, st, qkv, dctx, rowstat, cu_seqlens, H, scale, dqkv);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(kThreads), 0, st, qkv, dctx, rowstat, cu_seqlens, H, scale, dqkv);
+    return mr::check_launch();
+}
+
+extern "C" int mr_scatter_add_rows_f32(const float* src, int64_t lds_, const int32_t* idx, int T, int d, float* table, int64_t ldt,
+                                       mr_stream_t stream) {
+    if (!src || !idx || !table || T < 0 || d < 1 || lds_ < d || ldt < d) return MR_EINVAL;
+    if (T == 0) return MR_OK;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((T + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, (hipStream_t)stream, src,
+                       lds_, idx, T, d, table, ldt);
+    return mr::check_launch();
+}

@@ -452,3 +452,67 @@ def distill_loss_rows(z: torch.Tensor, t: Optional[torch.Tensor], *, label_src: 
                                                dz.stride(0) if dz is not None else 0, grad_scale, _stream(z)), "mr_distill_loss_rows_f32")
     PROF.end(ev, z.device, "distill_loss_rows", flops=0.0, nbytes=4.0 * rows * M * (2 + (1 if dz is not None else 0)))
     return loss_row, dz
+
+
+# ------------------------------------------------------------------------------------------ encoder backward (merge_train)
+def _pad16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def transpose_pad(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(R, C) -> (C, pad16(R)) with the pad columns zeroed: the K-contiguous operand layout of the NT GEMM."""
+    _dev(x, "x", torch.float32)
+    R, C = x.shape
+    Rp = _pad16(R)
+    out = torch.empty(C, Rp, dtype=torch.float32, device=x.device) if out is None else out
+    check(_lib.load().mr_transpose_f32(ptr(x), x.stride(0), R, C, ptr(out), out.stride(0), Rp, _stream(x)), "mr_transpose_f32")
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(x, "x", torch.float32)
+    R, C = x.shape
+    out = torch.empty(C, dtype=torch.float32, device=x.device) if out is None else out
+    check(_lib.load().mr_colsum_f32(ptr(x), x.stride(0), R, C, ptr(out), _stream(x)), "mr_colsum_f32")
+    return out
+
+
+def gelu_bwd(u: torch.Tensor, dh: torch.Tensor) -> torch.Tensor:
+    _dev(u, "u", torch.float32), _dev(dh, "dh", torch.float32)
+    if not (u.is_contiguous() and dh.is_contiguous() and u.shape == dh.shape):
+        raise ValueError("u and dh must be contiguous and equally shaped")
+    du = torch.empty_like(u)
+    check(_lib.load().mr_gelu_bwd_f32(ptr(u), ptr(dh), u.numel(), ptr(du), _stream(u)), "mr_gelu_bwd_f32")
+    return du
+
+
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float, dgamma: Optional[torch.Tensor] = None,
+                  dbeta: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx of LayerNorm(x) given dy; writes the parameter gradients into dgamma / dbeta when given."""
+    _dev(x, "x", torch.float32), _dev(dy, "dy", torch.float32)
+    T, d = x.shape
+    dx = torch.empty(T, d, dtype=torch.float32, device=x.device)
+    stats = torch.empty(max(T, 1), 2, dtype=torch.float32, device=x.device)
+    check(_lib.load().mr_layernorm_bwd_f32(ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(gamma), eps, T, d, ptr(dx), dx.stride(0), ptr(stats),
+                                           ptr(dgamma), ptr(dbeta), _stream(x)), "mr_layernorm_bwd_f32")
+    return dx
+
+
+def attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, scale: Optional[float] = None):
+    _dev(qkv, "qkv", torch.float32), _dev(ctx, "ctx", torch.float32), _dev(dctx, "dctx", torch.float32)
+    T = qkv.shape[0]
+    if not (qkv.is_contiguous() and ctx.is_contiguous() and dctx.is_contiguous()) or qkv.shape[1] != 3 * H * 64:
+        raise ValueError("qkv (T, 3 H 64), ctx / dctx (T, H 64) must be contiguous")
+    dqkv = torch.empty_like(qkv)
+    rowstat = torch.empty(max(T, 1), H, 2, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().mr_attn_bwd_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), B, H, 64, 0.125 if scale is None else scale, ptr(rowstat),
+                                      ptr(dqkv), _stream(qkv)), "mr_attn_bwd_f32")
+    return dqkv
+
+
+def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, table: torch.Tensor):
+    _dev(src, "src", torch.float32), _dev(idx, "idx", torch.int32), _dev(table, "table", torch.float32)
+    T, d = src.shape
+    check(_lib.load().mr_scatter_add_rows_f32(ptr(src), src.stride(0), ptr(idx), T, d, ptr(table), table.stride(0), _stream(src)),
+          "mr_scatter_add_rows_f32")
+    return table
