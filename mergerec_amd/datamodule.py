@@ -8,6 +8,8 @@ Mirrors, without Lightning:
   * ``tokenize_item`` / ``concat_tokenized_items`` / ``pad_tokenized_sequences``   datamodule/utils/recformer_utils.py:12-118
   * ``RecformerSingleItemCollator`` / ``RecformerItemSequenceCollator``    datamodule/collator/recommender/recformer.py:14-97
   * ``RecDataModuleForRecformer``  datamodule/recommender/recformer.py:28-140
+  * ``DistillSequenceDataModule`` / ``DistillSequenceCollator`` / ``ChainedDataset`` / ``RecItemAsSequenceDataset`` (merge_train.py's data:
+    datamodule/distiller/sequence/datamodule.py:20-184, collator/distiller/collator.py:42-91, dataset.py:20-28,56-88)
 
 File formats (one directory per domain): ``train/val/test.json`` user-id -> item-id list (val / test hold only the new
 interaction; the full sequences are train + val (+ test)), ``smap.json`` asin -> item id in id order, ``umap.json``,
@@ -34,6 +36,8 @@ __all__ = [
     "load_json_files", "load_tokenizer", "RecItemDataset", "RecDataset", "SingleItemCollator", "ItemSequenceCollator", "RecDataModule",
     "TokenizedItem", "TokenizedSequence", "tokenize_item", "concat_tokenized_items", "pad_tokenized_sequences",
     "RecformerSingleItemCollator", "RecformerItemSequenceCollator", "RecDataModuleForRecformer",
+    "RecItemAsSequenceDataset", "ChainedDataset", "split_sequences", "sample_popular", "sample_centroid", "DistillSequenceCollator",
+    "DistillSequenceDataModule",
 ]
 
 TokenizedItem = namedtuple("TokenizedItem", ["input_ids", "token_type_ids", "attr_type_ids"])
@@ -346,3 +350,173 @@ class RecDataModuleForRecformer(_DataModuleBase):
         self.sequence_train_collator = RecformerItemSequenceCollator(*args, getattr(self.negative_sample, "k", None),
                                                                     getattr(self.negative_sample, "in_batch", False))
         self.sequence_eval_collator = RecformerItemSequenceCollator(*args, None, False)
+
+
+# ------------------------------------------------------------------------------------------------ collaborative-merging data (merge_train.py)
+class RecItemAsSequenceDataset(Dataset):
+    """dataset.py:20-28: every catalog item as a one-item pseudo-user sequence ``(index, [item, -1])`` (train_data_split "item")."""
+
+    def __init__(self, items: List[int]):
+        self.items = items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, index):
+        return index, [self.items[index], -1]
+
+
+class ChainedDataset(Dataset):
+    """dataset.py:56-88: concatenation that also yields which dataset a sample came from: (dataset index, sample)."""
+
+    def __init__(self, datasets: list, start_dataset_idx: int = 0):
+        self.datasets = datasets
+        self.cumulative_sizes = []
+        total = 0
+        for d in datasets:
+            total += len(d)
+            self.cumulative_sizes.append(total)
+        self.start_dataset_idx = start_dataset_idx
+
+    def __len__(self):
+        return self.cumulative_sizes[-1]
+
+    def __getitem__(self, idx):
+        if idx < 0:
+            if -idx > len(self):
+                raise ValueError("Index out of range")
+            idx += len(self)
+        from bisect import bisect_right
+
+        k = bisect_right(self.cumulative_sizes, idx)
+        local = idx if k == 0 else idx - self.cumulative_sizes[k - 1]
+        return k + self.start_dataset_idx, self.datasets[k][local]
+
+
+def split_sequences(score_dataset, valid_ratio: Optional[float] = None):
+    """distiller/sequence/utils.py:32-46 (one torch.randperm draw when a validation share is asked for)."""
+    from torch.utils.data import Subset
+
+    if valid_ratio is None:
+        return score_dataset, None
+    perm = torch.randperm(len(score_dataset))
+    cut = int(len(score_dataset) * (1 - valid_ratio))
+    return Subset(score_dataset, perm[:cut]), Subset(score_dataset, perm[cut:])
+
+
+def sample_popular(test_sequence, num_sequences: int):
+    """distiller/sequence/utils.py:14-29: the most frequent items of the test sequences."""
+    from collections import Counter
+
+    counter = Counter()
+    for seq in test_sequence:
+        counter.update(seq)
+    return [item for item, _ in counter.most_common(num_sequences)]
+
+
+def sample_centroid(item_embedding: torch.Tensor, item_per_dataset: int) -> List[int]:
+    """distiller/item/utils.py:42-65: k-means (scikit-learn defaults), the member nearest to each centre."""
+    import numpy as np
+    from sklearn.cluster import KMeans
+
+    assert isinstance(item_embedding, torch.Tensor) and item_embedding.ndim == 2, "item_embedding must be a 2-dimensional torch.Tensor"
+    assert 1 <= item_per_dataset <= item_embedding.shape[0], "item_per_dataset must be between 1 and N"
+    X = item_embedding.cpu().detach().numpy()
+    km = KMeans(n_clusters=item_per_dataset).fit(X)
+    picked = []
+    for c, centre in enumerate(km.cluster_centers_):
+        members = np.where(km.labels_ == c)[0]
+        assert members.size > 0, f"Cluster {c} has no members"
+        picked.append(int(members[int(np.argmin(np.linalg.norm(X[members] - centre, axis=1)))]))
+    assert len(set(picked)) == item_per_dataset, "Duplicate indices found"
+    return picked
+
+
+class DistillSequenceCollator:
+    """collator/distiller/collator.py:42-91: (dataset index, (sequence id, items)) samples -> BatchDistillationSequence."""
+
+    def __init__(self, tokenizer, item_texts: List[Dict[int, str]], max_seq_len: int, separator: str = "; ", sequence_prompt: str = "",
+                 reverse_sequence: bool = True):
+        self.tokenizer, self.item_texts, self.max_seq_len = tokenizer, item_texts, max_seq_len
+        self.separator, self.sequence_prompt, self.reverse_sequence = separator, sequence_prompt, reverse_sequence
+
+    def __call__(self, batch):
+        from .model_batch import BatchDistillationSequence
+
+        ds_idx, seq_ids, texts = [], [], []
+        for d, (sid, seq) in batch:
+            if self.reverse_sequence:  # the last entry is the held-out target (or the -1 marker of item pseudo-sequences)
+                seq = seq[:-1][::-1]
+            ds_idx.append(d)
+            seq_ids.append(sid)
+            texts.append(self.sequence_prompt + self.separator.join(self.item_texts[d][i] for i in seq))
+        enc = self.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=self.max_seq_len)
+        return BatchDistillationSequence(dataset_indexes=ds_idx, sequence_ids=torch.tensor(seq_ids, device=torch.device("cpu")), sequence=enc)
+
+
+class DistillSequenceDataModule:
+    """datamodule/distiller/sequence/datamodule.py:20-184: per domain an item dataloader (catalog encoding) and the pseudo-user
+    sequences whose teacher rows are ``sequence_embeddings[d] @ item_embeddings[d].T``; training batches mix all domains."""
+
+    def __init__(self, dataset_paths, tokenizer, batch_size: int, max_seq_len: int, max_attribute_len: int, max_items: int,
+                 sequence_embeddings: List[torch.Tensor], train_data_split: str, sequence_per_dataset: Optional[int] = None, num_workers: int = 0,
+                 item_prompt: Optional[str] = None, sequence_prompt: Optional[str] = None, valid_ratio: Optional[float] = None,
+                 reverse_sequence: bool = True, num_sequences_per_dataset: Optional[int] = None, sample_method: str = "random"):
+        assert valid_ratio is None or 0 <= valid_ratio <= 1, "valid_ratio must be between 0 and 1 or None"
+        assert len(dataset_paths) == len(sequence_embeddings), "dataset_paths and user_embeddings must have the same length"
+        self.dataset_paths, self.tokenizer = [Path(p) for p in dataset_paths], tokenizer
+        self.batch_size, self.max_seq_len, self.max_attribute_len, self.max_items = batch_size, max_seq_len, max_attribute_len, max_items
+        self.sequence_embeddings, self.train_data_split, self.sequence_per_dataset = sequence_embeddings, train_data_split, sequence_per_dataset
+        self.num_workers, self.valid_ratio, self.reverse_sequence = num_workers, valid_ratio, reverse_sequence
+        self.num_sequences_per_dataset, self.sample_method = num_sequences_per_dataset, sample_method
+        self.item_prompt, self.sequence_prompt = item_prompt or "", sequence_prompt or ""
+        self.score_train_datasets, self.score_valid_datasets = [], []
+        self.item_datasets, self.item_collators, self.item_dataloaders, self.item_texts = [], [], [], []
+        self.distill_collator = None
+
+    _flatten_key_value = RecDataModule._flatten_key_value
+
+    def setup(self, stage: str = "fit"):
+        from torch.utils.data import Subset
+
+        for path, seq_emb in zip(self.dataset_paths, self.sequence_embeddings):
+            item_dataset, train, val, test, metadata, _, _ = load_json_files(path, self.max_items)
+            if self.train_data_split == "item":
+                dataset = RecItemAsSequenceDataset(item_dataset.items)
+            elif self.train_data_split in ("train", "val", "test"):
+                dataset = dict(train=train, val=val, test=test)[self.train_data_split]
+            else:
+                raise ValueError(f"Unknown train_data_split: {self.train_data_split}")
+            assert len(dataset) == len(seq_emb), "item_dataset and sequence_embedding must have the same length"
+            if self.num_sequences_per_dataset is not None:
+                print(f"Sampling {self.num_sequences_per_dataset} sequences per dataset from {len(dataset)} total sequences")
+                if self.sample_method == "random":
+                    indices = torch.randperm(len(dataset))[: self.num_sequences_per_dataset].tolist()
+                elif self.sample_method == "centroid":
+                    indices = sample_centroid(seq_emb, self.num_sequences_per_dataset)
+                elif self.sample_method == "popular":
+                    indices = sample_popular(test.sequence, self.num_sequences_per_dataset)
+                else:
+                    raise ValueError(f"Unknown sample_method: {self.sample_method}")
+                dataset = Subset(dataset, indices)
+            item_text = {i: self._flatten_key_value(m) for i, m in metadata.items()}
+            collator = SingleItemCollator(self.tokenizer, item_text, self.max_seq_len, self.item_prompt)
+            tr, va = split_sequences(dataset, self.valid_ratio)
+            self.item_datasets.append(item_dataset)
+            self.item_collators.append(collator)
+            self.item_dataloaders.append(DataLoader(item_dataset, batch_size=self.batch_size, collate_fn=collator, shuffle=False,
+                                                    num_workers=self.num_workers))
+            self.score_train_datasets.append(tr)
+            self.score_valid_datasets.append(va)
+            self.item_texts.append(item_text)
+        self.distill_collator = DistillSequenceCollator(self.tokenizer, self.item_texts, self.max_seq_len, "; ", self.sequence_prompt,
+                                                        self.reverse_sequence)
+
+    def train_dataloader(self):
+        return DataLoader(ChainedDataset(self.score_train_datasets), batch_size=self.batch_size, collate_fn=self.distill_collator,
+                          num_workers=self.num_workers, shuffle=True)
+
+    def val_dataloader(self):
+        return [DataLoader(ChainedDataset([v], start_dataset_idx=i), batch_size=self.batch_size, collate_fn=self.distill_collator,
+                           num_workers=self.num_workers, shuffle=False)
+                for i, v in enumerate(self.score_valid_datasets) if v is not None]

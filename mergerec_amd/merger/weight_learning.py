@@ -108,8 +108,21 @@ class TaskVectorMergingModuleBase(nn.Module):
                 table[k].data = v.to(dev)
 
     def forward(self, batch):
+        """_base.py:78-81.  Under autograd (alpha requires grad and grad mode is on) the merge AND the encoder are differentiable:
+        merged_params() -> RobertaTrainGraph, whose backward hands d loss / d merged parameters to the alpha-gradient kernel.
+        Otherwise the merged weights are written into the model's arena and the inference path runs."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self.forward_with_grad(batch)
         self.load_weights()
         return self.model(batch)
+
+    def forward_with_grad(self, batch):
+        from ..engine_train import RobertaTrainGraph, encode_with_grad
+
+        if getattr(self, "_train_graph", None) is None:
+            self._train_graph = RobertaTrainGraph(self.model.spec, self.layout, prefix=self.model.runner.prefix)
+        pb = self.model.runner.pack(batch, self.base_model_tensor.device)
+        return encode_with_grad(self._train_graph, self.merged_params(), pb)
 
     # -- merge -----------------------------------------------------------------------------------
     def effective_alpha(self) -> torch.Tensor:
@@ -137,7 +150,14 @@ class TaskVectorMergingModuleBase(nn.Module):
                                     self._seg_off, torch.empty_like(self._merged))
 
     def load_weights(self):
+        """Re-merge into the model's arena -- skipped when alpha is bit-identical to the one the arena was merged with (the
+        reference re-merges on every forward; a catalog encode is hundreds of forwards with the same alpha)."""
+        alpha = self.effective_alpha().detach()
+        cached = getattr(self, "_merged_alpha", None)
+        if cached is not None and cached.shape == alpha.shape and torch.equal(cached, alpha):
+            return self.model
         self._merge_task_vectors()
+        self._merged_alpha = alpha.clone()
         if hasattr(self.model, "weights_updated"):
             self.model.weights_updated()
         return self.model

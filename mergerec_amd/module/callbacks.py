@@ -41,6 +41,33 @@ class ItemEncodingCallback(ItemEncoderMixin):
             self.inject_item_embeddings(self.item_dataloader, pl_module)
 
 
+class MultiDatasetItemEncodingCallback(ItemEncoderMixin):
+    """callbacks.py:81-109: one catalog per domain, encoded with the CURRENT merged model at the first training epoch (later
+    epochs keep them: 'Item embeddings already exist') and treated as constants by the distillation loss."""
+
+    def __init__(self, item_dataloaders):
+        self.item_dataloaders = item_dataloaders
+
+    def inject_item_embeddings(self, item_dataloaders, pl_module, requires_grad: bool = False):
+        if pl_module.item_embeddings is not None:
+            print("Item embeddings already exist in the model. Skipping encoding.")
+            return
+        embs = []
+        for idx, dl in enumerate(item_dataloaders, start=1):
+            print(f"Encoding {idx} / {len(item_dataloaders)} datasets.")
+            embs.append(self.encode_items(dl, pl_module))
+        pl_module.item_embeddings = embs
+
+    def on_train_epoch_start(self, trainer, pl_module):
+        print(f"[Train - epoch {trainer.current_epoch} start] Encoding items.")
+        self.inject_item_embeddings(self.item_dataloaders, pl_module)
+
+    def on_test_epoch_start(self, trainer, pl_module):
+        if pl_module.item_embeddings is None:
+            print("[Test - epoch start] Encoding items as no item embeddings are found.")
+            self.inject_item_embeddings(self.item_dataloaders, pl_module)
+
+
 class SaveWeightsCallback:
     """callbacks.py:139-174: one line per logged step, ``str(dict)`` of {"epoch", "step", "weights"} -- the file format
     ``merge_test.py --weight_file`` reads back (merge_test.py:67-68; use ``mergerec_amd.utils.load_alpha_file``)."""

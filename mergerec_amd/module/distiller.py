@@ -6,9 +6,9 @@ grouped by dataset: one fp32 GEMM ``reps_g @ E_ds.T`` per dataset (the ascending
 teacher rows ``S_ds[sequence_id]`` gathered on the device, and ONE fused loss launch per group that returns the per-row
 losses and d loss / d logits; the batch loss is the mean over all samples, as in module.py:72.
 
-Scope: the loss value, d loss / d logits and d loss / d representations are computed on the device.  The encoder backward
-(representations -> merged parameters -> alpha) is not built, so ``training_step`` cannot
-update alpha yet; ``validation_step`` and the loss path are complete and parity-tested."""
+The whole chain is on the device: loss value, d loss / d logits, d loss / d representations here; representations -> merged
+parameters through ``engine_train.RobertaTrainGraph`` (BLaIR / RoBERTa; Recformer's windowed attention backward is not built) and
+merged parameters -> alpha through ``mr_merge_bwd_alpha_f32``."""
 from __future__ import annotations
 
 from typing import List, Literal, Optional, Sequence
@@ -115,7 +115,7 @@ class DistillSequenceModule(nn.Module):
         assert self._items is not None, "item_embeddings must be set (ItemEncodingCallback) before the distillation loss"
         B = representations.shape[0]
         ds = torch.as_tensor(list(dataset_indexes), dtype=torch.int64)
-        sid = torch.as_tensor(list(sequence_ids), dtype=torch.int64)
+        sid = sequence_ids.detach().to("cpu", torch.int64) if isinstance(sequence_ids, torch.Tensor) else torch.as_tensor(list(sequence_ids), dtype=torch.int64)
         total = None
         for d_i in sorted(set(ds.tolist())):
             sel = (ds == d_i).nonzero(as_tuple=True)[0]
@@ -130,7 +130,7 @@ class DistillSequenceModule(nn.Module):
         return self.distill_loss(reps, batch.dataset_indexes, batch.sequence_ids)
 
     def log(self, name, value, **kwargs):
-        self.logged[name] = float(value)
+        self.logged[name] = float(value.detach()) if isinstance(value, torch.Tensor) else float(value)
 
     def training_step(self, batch: BatchDistillationSequence, batch_idx: int):
         loss = self._forward_distill(batch)

@@ -83,6 +83,65 @@ def test_model(module: RecModule, item_dataloaders: Sequence[Iterable], sequence
     return metric_dict, metrics, scores, labels
 
 
+class DistillTrainer:
+    """The slice of ``lightning.Trainer.fit`` that merge_train.py uses (merge_train.py:178-196): epochs over the training
+    dataloader until max_steps / max_epochs, optimizer from ``configure_optimizers``, callback hooks on_train_epoch_start /
+    on_train_batch_end / on_train_epoch_end / teardown, optional validation dataloaders after every epoch."""
+
+    def __init__(self, max_epochs: Optional[int] = None, max_steps: Optional[int] = None, callbacks: Sequence = (), precision: str = "32-true",
+                 coalesce_tokens: int = 65536, log_every_n_steps: int = 1, verbose: bool = True):
+        if precision not in ("32-true", "32", 32):
+            raise NotImplementedError("the HIP path computes in fp32 (parity configuration); bf16-mixed is not built")
+        if max_epochs is None and (max_steps is None or max_steps < 0):
+            raise ValueError("max_steps or max_epochs is required")
+        self.max_epochs, self.max_steps, self.callbacks = max_epochs, max_steps, list(callbacks)
+        self.coalesce_tokens, self.log_every_n_steps, self.verbose = coalesce_tokens, log_every_n_steps, verbose
+        self.current_epoch = 0
+        self.global_step = 0
+        self.history: List[float] = []
+
+    def _hook(self, name, *args):
+        for cb in self.callbacks:
+            if hasattr(cb, name):
+                getattr(cb, name)(self, *args)
+
+    def fit(self, module, datamodule):
+        module.trainer = self
+        datamodule.setup("fit")
+        opt = module.configure_optimizers()
+        done = False
+        while not done:
+            module.train()
+            self._hook("on_train_epoch_start", module)
+            for batch_idx, batch in enumerate(datamodule.train_dataloader()):  # reload_dataloaders_every_n_epochs=1
+                opt.zero_grad(set_to_none=True)
+                loss = module.training_step(batch.to(module.device), batch_idx)
+                loss.backward()
+                opt.step()
+                self.global_step += 1
+                self.history.append(float(loss.detach()))
+                if self.verbose and self.global_step % self.log_every_n_steps == 0:
+                    print(f"step {self.global_step}: train/loss {self.history[-1]:.6f}")
+                self._hook("on_train_batch_end", module, loss, batch, batch_idx)
+                if self.max_steps is not None and self.max_steps >= 0 and self.global_step >= self.max_steps:
+                    done = True
+                    break
+            self._hook("on_train_epoch_end", module)
+            vals = datamodule.val_dataloader() if hasattr(datamodule, "val_dataloader") else []
+            if vals:
+                module.eval()
+                module.on_validation_epoch_start()
+                for di, dl in enumerate(vals):
+                    for bi, batch in enumerate(dl):
+                        module.validation_step(batch.to(module.device), bi, di)
+                module.on_validation_epoch_end()
+            self.current_epoch += 1
+            if self.max_epochs is not None and self.current_epoch >= self.max_epochs:
+                done = True
+        self._hook("teardown", module, "fit")
+        return self.history
+
+
 def get_data_module(model_type, batch_size, data_path, item_prompt, max_attribute_len, max_items, max_seq_len, model_tokenizer,
                     negative_sample_config, num_workers, reverse_sequence, sequence_prompt):
     """utils.py:137-175 (_get_data_module): the Recformer datamodule for the RECFORMER* model types, the text one otherwise."""

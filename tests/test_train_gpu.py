@@ -105,3 +105,89 @@ def test_encoder_backward_matches_oracle_autograd():
         worst = max(worst, err)
         assert err <= 2e-3, (k, err, scale)
     assert worst > 0.0
+
+
+@pytest.mark.parametrize("learn", ["TASK_WISE", "LAYER_WISE"])
+def test_alpha_gradient_end_to_end_matches_oracle_autograd(learn):
+    """alpha -> merge -> encoder -> cosine logits -> SINGLE_PSEUDO_LABEL_KD, all on the device, against torch autograd through
+    the CPU oracle of every stage (the reference's merge_train.py step, module/distiller/sequence/module.py:59-79)"""
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchDistillationSequence
+    from mergerec_amd.module import DistillSequenceModule
+    from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
+    from tests.test_path_gpu import _tiny_model
+
+    g2 = load_golden("g2_merger.pt")
+    cfgd = g2["cfg"]
+    cfg = O.EncoderConfig(**{k: cfgd[k] for k in cfgd if k in O.EncoderConfig.__dataclass_fields__})
+    ids, mask = g2["input_ids"], g2["attention_mask"]
+    B = ids.shape[0]
+    gen = torch.Generator().manual_seed(9)
+    items = [torch.nn.functional.normalize(torch.randn(m, cfgd["hidden"], generator=gen), dim=-1) for m in (50, 77)]
+    teachers = [torch.randn(B, m, generator=gen).clamp(-1, 1) for m in (50, 77)]
+    ds_idx = [i % 2 for i in range(B)]
+    seq_ids = list(range(B))
+    T, COEF = 0.05, 1000.0
+
+    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[learn], _tiny_model(cfgd), g2["pretrain"], [dict(f) for f in g2["finetunes"]], set(),
+                             disable_softmax=True, initial_per_weight=0.3)
+    mod = DistillSequenceModule(mm, teachers, SinglePseudoLabelKDLoss(T, COEF), "cosine",
+                                trainable_args_kwargs={"freeze_global_weight": True, "freeze_global_bias": True})
+    mod.item_embeddings = items
+    batch = BatchDistillationSequence(dataset_indexes=ds_idx, sequence_ids=torch.tensor(seq_ids), sequence={"input_ids": ids, "attention_mask": mask})
+    mod.train()
+    loss = mod.training_step(batch.to(DEV), 0)
+    loss.backward()
+
+    # ---- CPU: the same chain with torch autograd through the oracle
+    pre, fts = O.align_state_dicts(g2["pretrain"], g2["finetunes"])
+    base, shapes = O.flatten_model(pre)
+    tv = O.get_task_vectors(base, [O.flatten_model(f)[0] for f in fts])
+    n = tv.shape[0]
+    if learn == "TASK_WISE":  # alpha = gw * per + gb with gw = 1, gb = 0 (task_wise.py:37-42)
+        per = {"all": torch.full((n,), 0.3, requires_grad=True)}
+        merged = O.merge_task_wise(base, tv, 1.0 * per["all"] + 0.0)
+    else:
+        groups = O.group_parameters_by_layer(shapes)
+        per = {k: torch.full((n,), 0.3, requires_grad=True) for k in groups}
+        merged = O.merge_layer_wise(base, tv, groups, {k: 1.0 * v + 0.0 for k, v in per.items()})
+    sd = O.get_state_dict(merged, shapes)
+    reps = O.maybe_normalize(O.roberta_encode(sd, ids, mask, cfg, prefix="model."))
+    ref = O.forward_distill(reps, items, teachers, ds_idx, seq_ids, lambda z, t: O.distill_loss("SINGLE_PSEUDO_LABEL_KD", z, t, T, COEF))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
+    for k, p in per.items():
+        got = mm.per_weights[k].grad.cpu()
+        scale = max(float(p.grad.abs().max()), 1e-6)
+        assert float((got - p.grad).abs().max()) <= 5e-3 * scale, (k, got, p.grad)
+
+
+def test_merge_train_cli_runs_and_moves_alpha(tmp_path):
+    import sys
+
+    root = __import__("pathlib").Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    import merge_train
+    from mergerec_amd.engine import EncoderSpec
+    from mergerec_amd.module import models
+    from mergerec_amd.utils import load_alpha_file
+    from tests.conftest import GOLDEN
+
+    old = models.BLaIRBase.SPEC
+    models.BLaIRBase.SPEC = staticmethod(lambda: EncoderSpec(hidden=128, heads=2, layers=2, intermediate=256, vocab=50265, max_pos=514))
+    try:
+        res = merge_train.main([
+            "--model_type", "blair_base", "--model_kwargs", "init_seed", "7", "--finetune_checkpoint_paths", "synthetic:1", "synthetic:2",
+            "--data_paths", str(GOLDEN / "mini_dataset"), str(GOLDEN / "mini_dataset"), "--tokenizer_path", str(GOLDEN / "mini_tokenizer"),
+            "--item_embeddings_paths", "auto", "--sequence_embeddings_paths", "auto", "--train_data_split", "item", "--test_data_split", "test",
+            "--merge_type", "task_vector", "--learn_type", "task_wise", "--loss_type", "SINGLE_PSEUDO_LABEL_KD", "--coefficient", "1000",
+            "--learning_rate", "0.01", "--max_steps", "12", "--batch_size", "16", "--max_seq_len", "96", "--max_attribute_len", "12", "--max_items", "20",
+            "--weights_dir", str(tmp_path)])
+    finally:
+        models.BLaIRBase.SPEC = staticmethod(old)
+    hist = res["history"]
+    assert len(hist) == 12 and all(h == h and abs(h) < 1e6 for h in hist)
+    per = res["weights"]["per_weights"]["all"]
+    assert any(abs(w - 0.2) > 1e-3 for w in per), per          # Adam moved alpha away from initial_per_weight
+    assert load_alpha_file(res["weights_file"], -1)["per_weights"]["all"] != [0.2, 0.2]
+    assert "test/dataset_0/test/NDCG@10" in res["test_metrics"]
