@@ -278,13 +278,21 @@ int mr_distill_loss_rows_f32(const float* z, int64_t ldz, const float* t, int64_
  * replaces: torch autograd through transformers' RobertaLayer (reached via module/models/encoder/_base.py:37) in
  * module/distiller/sequence/module.py:76-79 (training_step). */
 
+/* C = A W^T (+ bias) (+ R), one weight segment, the k range cut into `splits` slices run by separate workgroups and summed in
+ * ascending slice order (deterministic; not the single ascending-k chain of mr_gemm_nt_bias_act_f32 -- training graph only).
+ * ws: mr_gemm_nt_splitk_ws_bytes(M, N, splits) bytes. */
+size_t mr_gemm_nt_splitk_ws_bytes(int M, int N, int splits);
+int mr_gemm_nt_splitk_f32(const float* A, int64_t lda, const float* W, const float* bias, int M, int N, int K, const float* R, int64_t ldr,
+                          float* C, int64_t ldc, int splits, void* ws, size_t ws_bytes, mr_stream_t stream);
+
 /* out[c][r] = in[r][c] (r < R, c < C); columns R .. R_pad - 1 of every output row are zero-filled (ldo >= R_pad). */
 int mr_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int64_t ldo, int R_pad, mr_stream_t stream);
 
 /* out[c] = sum_r x[r][c], rows in ascending order (bias gradients). */
 int mr_colsum_f32(const float* x, int64_t ldx, int R, int C, float* out, mr_stream_t stream);
 
-/* du = dh * d/du gelu_erf(u). */
+/* h = gelu_erf(u) (the training forward keeps the pre-activation u);  du = dh * d/du gelu_erf(u). */
+int mr_gelu_fwd_f32(const float* u, int64_t n, float* h, mr_stream_t stream);
 int mr_gelu_bwd_f32(const float* u, const float* dh, int64_t n, float* du, mr_stream_t stream);
 
 /* LayerNorm backward over the last dimension: dx (T, d); stats (T, 2) receives (mean, rstd) of x; dgamma / dbeta (d) may both

@@ -45,8 +45,11 @@ SIGNATURES = {
     "mr_pcb_stage1_f32": (c_i, [c_p, c_i64, c_i, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "mr_pcb_stage2_f32": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_p, c_p, c_p]),
     "mr_distill_loss_rows_f32": (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_i64, c_f, c_p]),
+    "mr_gemm_nt_splitk_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "mr_gemm_nt_splitk_f32": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_i, c_p, c_sz, c_p]),
     "mr_transpose_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_i64, c_i, c_p]),
     "mr_colsum_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
+    "mr_gelu_fwd_f32": (c_i, [c_p, c_i64, c_p, c_p]),
     "mr_gelu_bwd_f32": (c_i, [c_p, c_p, c_i64, c_p, c_p]),
     "mr_layernorm_bwd_f32": (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_f, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p]),
     "mr_attn_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),

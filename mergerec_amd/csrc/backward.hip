@@ -41,13 +41,32 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
-// out[c] = sum_r x[r][c]; one thread per column, rows in ascending order (deterministic)
+// out[c] = sum_r x[r][c].  Workgroup = 32 columns x 8 row lanes (rows r = lane, lane + 8, ...), partials combined in a fixed
+// order through LDS: deterministic, with 8 x shorter serial loops on 8 x more workgroups than one thread per column.
+constexpr int kColW = 32, kRowL = kThreads / kColW;
 __global__ __launch_bounds__(kThreads) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int R, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float part[kRowL][kColW];
+    const int cl = threadIdx.x % kColW, rl = threadIdx.x / kColW;
+    const int c = blockIdx.x * kColW + cl;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += x[(int64_t)r * ldx + c];
-    out[c] = s;
+    if (c < C)
+        for (int r = rl; r < R; r += kRowL) s += x[(int64_t)r * ldx + c];
+    part[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float t = part[0][cl];
+#pragma unroll
+        for (int k = 1; k < kRowL; ++k) t += part[k][cl];
+        out[c] = t;
+    }
+}
+
+// h = gelu_erf(u) (the forward of the training graph keeps the pre-activation, so the GEMM epilogue's fused GELU is not used)
+__global__ __launch_bounds__(kThreads) void gelu_fwd_kernel(const float* __restrict__ u, int64_t n, float* __restrict__ h) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const float x = u[i];
+        h[i] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ GELU(erf) backward
@@ -99,20 +118,30 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_rows_kernel(const floa
     }
 }
 
-// dgamma[c] = sum_t dy[t][c] * xhat[t][c], dbeta[c] = sum_t dy[t][c]; one thread per column, ascending rows
+// dgamma[c] = sum_t dy[t][c] * xhat[t][c], dbeta[c] = sum_t dy[t][c]; 32 columns x 8 row lanes per workgroup, fixed-order LDS combine
 __global__ __launch_bounds__(kThreads) void layernorm_bwd_params_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
                                                                        int64_t ldy, const float* __restrict__ stats, int T, int d,
                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= d) return;
+    __shared__ float pg[kRowL][kColW], pb[kRowL][kColW];
+    const int cl = threadIdx.x % kColW, rl = threadIdx.x / kColW;
+    const int c = blockIdx.x * kColW + cl;
     float g = 0.f, b = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const float dyv = dy[(int64_t)t * ldy + c];
-        g += dyv * (x[(int64_t)t * ldx + c] - stats[2 * t]) * stats[2 * t + 1];
-        b += dyv;
+    if (c < d)
+        for (int t = rl; t < T; t += kRowL) {
+            const float dyv = dy[(int64_t)t * ldy + c];
+            g += dyv * (x[(int64_t)t * ldx + c] - stats[2 * t]) * stats[2 * t + 1];
+            b += dyv;
+        }
+    pg[rl][cl] = g;
+    pb[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < d) {
+        float tg = pg[0][cl], tb = pb[0][cl];
+#pragma unroll
+        for (int k = 1; k < kRowL; ++k) { tg += pg[k][cl]; tb += pb[k][cl]; }
+        dgamma[c] = tg;
+        dbeta[c] = tb;
     }
-    dgamma[c] = g;
-    dbeta[c] = b;
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward
@@ -122,32 +151,47 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_params_kernel(const fl
 __global__ __launch_bounds__(kThreads) void attn_bwd_stats_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
                                                                  const float* __restrict__ dctx, const int32_t* __restrict__ cu, int H,
                                                                  float scale, float* __restrict__ rowstat) {
+    __shared__ float ks[32][kDh];
     const int b = blockIdx.x, h = blockIdx.y;
     const int t0 = cu[b], len = cu[b + 1] - t0;
     const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
-    for (int i = threadIdx.x; i < len; i += kThreads) {
-        const float* q = qkv + (int64_t)(t0 + i) * ld + h * kDh;
+    for (int i0 = 0; i0 < len; i0 += kThreads) {
+        const int i = i0 + threadIdx.x;
+        const bool on = i < len;
+        const int ic = on ? i : len - 1;
+        const float* q = qkv + (int64_t)(t0 + ic) * ld + h * kDh;
         float qr[kDh];
 #pragma unroll
         for (int d = 0; d < kDh; ++d) qr[d] = q[d];
         float m = -INFINITY, l = 0.f;
-        for (int j = 0; j < len; ++j) {
-            const float* k = qkv + (int64_t)(t0 + j) * ld + (H + h) * kDh;
-            float s = 0.f;
+        for (int j0 = 0; j0 < len; j0 += 32) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < 32 * kDh; e += kThreads) {
+                const int jr = e / kDh, d = e % kDh;
+                const int j = j0 + jr < len ? j0 + jr : len - 1;
+                ks[jr][d] = qkv[(int64_t)(t0 + j) * ld + (H + h) * kDh + d];
+            }
+            __syncthreads();
+            const int nj = (len - j0) < 32 ? (len - j0) : 32;
+            for (int jr = 0; jr < nj; ++jr) {
+                float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < kDh; ++d) s = fmaf(qr[d], k[d], s);
-            s *= scale;
-            const float mn = fmaxf(m, s);
-            l = l * expf(m - mn) + expf(s - mn);
-            m = mn;
+                for (int d = 0; d < kDh; ++d) s = fmaf(qr[d], ks[jr][d], s);
+                s *= scale;
+                const float mn = fmaxf(m, s);
+                l = l * expf(m - mn) + expf(s - mn);
+                m = mn;
+            }
         }
-        const float* o = ctx + (int64_t)(t0 + i) * ldc + h * kDh;
-        const float* g = dctx + (int64_t)(t0 + i) * ldc + h * kDh;
-        float dl = 0.f;
+        if (on) {
+            const float* o = ctx + (int64_t)(t0 + i) * ldc + h * kDh;
+            const float* g = dctx + (int64_t)(t0 + i) * ldc + h * kDh;
+            float dl = 0.f;
 #pragma unroll
-        for (int d = 0; d < kDh; ++d) dl = fmaf(o[d], g[d], dl);
-        rowstat[((int64_t)(t0 + i) * H + h) * 2] = m + logf(l);
-        rowstat[((int64_t)(t0 + i) * H + h) * 2 + 1] = dl;
+            for (int d = 0; d < kDh; ++d) dl = fmaf(o[d], g[d], dl);
+            rowstat[((int64_t)(t0 + i) * H + h) * 2] = m + logf(l);
+            rowstat[((int64_t)(t0 + i) * H + h) * 2 + 1] = dl;
+        }
     }
 }
 
@@ -283,7 +327,16 @@ extern "C" int mr_transpose_f32(const float* in, int64_t ldi, int R, int C, floa
 extern "C" int mr_colsum_f32(const float* x, int64_t ldx, int R, int C, float* out, mr_stream_t stream) {
     if (!x || !out || R < 0 || C < 0 || ldx < C) return MR_EINVAL;
     if (C == 0) return MR_OK;
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, R, C, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + kColW - 1) / kColW), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, R, C, out);
+    return mr::check_launch();
+}
+
+extern "C" int mr_gelu_fwd_f32(const float* u, int64_t n, float* h, mr_stream_t stream) {
+    if (!u || !h || n < 0) return MR_EINVAL;
+    if (n == 0) return MR_OK;
+    int64_t blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, u, n, h);
     return mr::check_launch();
 }
 
@@ -310,7 +363,7 @@ extern "C" int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy
     hipLaunchKernelGGL(layernorm_bwd_rows_kernel, dim3((T + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, (hipStream_t)stream, x,
                        ldx, dy, ldy, gamma, eps, T, d, dx, lddx, stats);
     if (dgamma)
-        hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3((d + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, dy,
+        hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3((d + kColW - 1) / kColW), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, dy,
                            ldy, stats, T, d, dgamma, dbeta);
     return mr::check_launch();
 }

@@ -27,8 +27,13 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ w0, const float* __restrict__ w1,
     const float* __restrict__ w2, const float* __restrict__ b0, const float* __restrict__ b1,
     const float* __restrict__ b2, int M, int seg_n, int K, const float* __restrict__ R, int64_t ldr,
-    float* __restrict__ C, int64_t ldc, int tiles_n_seg, int tiles_n, int nwg) {
+    float* __restrict__ C, int64_t ldc, int tiles_n_seg, int tiles_n, int nwg, int kchunk, int64_t split_stride) {
     __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_STRIDE];
+    // split-K (mr_gemm_nt_splitk_f32 only; every other caller passes kchunk = K, gridDim.y = 1): slice blockIdx.y of the k range,
+    // raw partial sums to C + blockIdx.y * split_stride
+    const int k_begin = blockIdx.y * kchunk;
+    const int k_len = (K - k_begin) < kchunk ? (K - k_begin) : kchunk;
+    C += (int64_t)blockIdx.y * split_stride;
 
     const int pid = mr::xcd_remap(blockIdx.x, nwg);
     const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
@@ -50,10 +55,10 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
     int br0 = n0 + sr, br1 = n0 + sr + 64;
     br0 = br0 < seg_n ? br0 : seg_n - 1;
     br1 = br1 < seg_n ? br1 : seg_n - 1;
-    const float* ga0 = A + (int64_t)ar0 * lda + kq * 4;
-    const float* ga1 = A + (int64_t)ar1 * lda + kq * 4;
-    const float* gb0 = W + (int64_t)br0 * K + kq * 4;
-    const float* gb1 = W + (int64_t)br1 * K + kq * 4;
+    const float* ga0 = A + (int64_t)ar0 * lda + kq * 4 + k_begin;
+    const float* ga1 = A + (int64_t)ar1 * lda + kq * 4 + k_begin;
+    const float* gb0 = W + (int64_t)br0 * K + kq * 4 + k_begin;
+    const float* gb1 = W + (int64_t)br1 * K + kq * 4 + k_begin;
     // LDS write offsets (floats): even half at 2*kq, odd half at 8 + 2*kq
     const int wa0 = sr * LDS_STRIDE + 2 * kq, wa1 = (sr + 64) * LDS_STRIDE + 2 * kq;
     const int wb0 = (BM + sr) * LDS_STRIDE + 2 * kq, wb1 = (BM + sr + 64) * LDS_STRIDE + 2 * kq;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
         *reinterpret_cast<float2*>(buf + wb1 + 8) = make_float2(sb1.y, sb1.w);
     };
 
-    const int nk = K / BK;
+    const int nk = k_len / BK;
     gload(0);
     lstore(lds[0]);
     __syncthreads();
@@ -183,7 +188,54 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
     }
 }
 
+// C[m][n] = sum_z ws[z][m][n] (ascending z) + bias[n] + R[m][n]
+__global__ __launch_bounds__(kThreads) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t split_stride, int M, int N,
+                                                                const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
+                                                                float* __restrict__ C, int64_t ldc) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
+        float s = ws[e];
+        for (int z = 1; z < splits; ++z) s += ws[(int64_t)z * split_stride + e];
+        if (bias) s += bias[n];
+        if (R) s += R[(int64_t)m * ldr + n];
+        C[(int64_t)m * ldc + n] = s;
+    }
+}
+
 }  // namespace
+
+extern "C" size_t mr_gemm_nt_splitk_ws_bytes(int M, int N, int splits) { return (size_t)M * N * 4 * (splits > 1 ? splits : 0); }
+
+// C = A W^T (+ bias) (+ R) with the k range cut into `splits` slices computed by separate workgroups (a product with few output
+// tiles and a long k loop -- the training graph's token-sized GEMMs -- otherwise leaves most of the chip idle).  Partial sums are
+// combined in ascending slice order: deterministic, but NOT the single ascending-k FMA chain of mr_gemm_nt_bias_act_f32.
+extern "C" int mr_gemm_nt_splitk_f32(const float* A, int64_t lda, const float* W, const float* bias, int M, int N, int K, const float* R,
+                                     int64_t ldr, float* C, int64_t ldc, int splits, void* ws, size_t ws_bytes, mr_stream_t stream) {
+    if (splits <= 1) return mr_gemm_nt_bias_act_f32(A, lda, W, nullptr, nullptr, bias, nullptr, nullptr, 1, M, N, K, MR_ACT_NONE, R, ldr, C, ldc, stream);
+    if (!A || !W || !C || !ws || M < 0 || N < 1 || K < 1) return MR_EINVAL;
+    if (K % BK) return MR_EUNSUPPORTED;
+    if ((lda & 3) || !mr::aligned16(A) || !mr::aligned16(W) || !mr::aligned16(ws)) return MR_EALIGN;
+    if (ws_bytes < mr_gemm_nt_splitk_ws_bytes(M, N, splits)) return MR_EWS;
+    if (M == 0) return MR_OK;
+    const int nk = K / BK;
+    if (splits > nk) splits = nk;
+    const int kchunk = ((nk + splits - 1) / splits) * BK;
+    splits = (K + kchunk - 1) / kchunk;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int64_t nwg64 = (int64_t)tiles_m * tiles_n;
+    if (nwg64 > 0x7fffffff || (int64_t)M * N > 0x7fffffff) return MR_EUNSUPPORTED;
+    const int nwg = (int)nwg64;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = reinterpret_cast<float*>(ws);
+    const int64_t stride = (int64_t)M * N;
+    hipLaunchKernelGGL((gemm_nt_kernel<MR_ACT_NONE, false>), dim3(nwg, splits), dim3(kThreads), 0, st, A, lda, W, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, M, N, K, nullptr, (int64_t)0, part, (int64_t)N, tiles_n, tiles_n, nwg, kchunk, stride);
+    int64_t blocks = (stride + kThreads - 1) / kThreads;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, part, splits, stride, M, N, bias, R, ldr, C, ldc);
+    return mr::check_launch();
+}
 
 extern "C" int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float* w0, const float* w1, const float* w2,
                                        const float* b0, const float* b1, const float* b2, int nseg, int M, int seg_n,
@@ -208,7 +260,7 @@ extern "C" int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float*
     hipStream_t st = (hipStream_t)stream;
 #define MR_GEMM_LAUNCH(ACT_, HASR_)                                                                                   \
     hipLaunchKernelGGL((gemm_nt_kernel<ACT_, HASR_>), dim3(nwg), dim3(kThreads), 0, st, A, lda, w0, w1, w2, b0, b1, b2, \
-                       M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg)
+                       M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg, K, (int64_t)0)
     if (act == MR_ACT_GELU_ERF) {
         if (R) MR_GEMM_LAUNCH(MR_ACT_GELU_ERF, true); else MR_GEMM_LAUNCH(MR_ACT_GELU_ERF, false);
     } else {

@@ -46,13 +46,13 @@ class RobertaTrainGraph:
             names = [f"{lp}attention.self.{n}" for n in ("query", "key", "value")]
             qkv = torch.empty(pb.T, 3 * sp.hidden, dtype=torch.float32, device=x.device)
             for s, n in enumerate(names):
-                ops.gemm_nt(x, [w[n + ".weight"]], [w[n + ".bias"]], out=qkv[:, s * sp.hidden:(s + 1) * sp.hidden])
+                ops.gemm_nt_train(x, w[n + ".weight"], w[n + ".bias"], out=qkv[:, s * sp.hidden:(s + 1) * sp.hidden])
             ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=-1, seq_order=pb.seq_order, products=0)
-            a = ops.gemm_nt(ctx, [w[lp + "attention.output.dense.weight"]], [w[lp + "attention.output.dense.bias"]], residual=x)
+            a = ops.gemm_nt_train(ctx, w[lp + "attention.output.dense.weight"], w[lp + "attention.output.dense.bias"], residual=x)
             h = ops.layernorm(a, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps)
-            u = ops.gemm_nt(h, [w[lp + "intermediate.dense.weight"]], [w[lp + "intermediate.dense.bias"]])
-            i = ops.gemm_nt(h, [w[lp + "intermediate.dense.weight"]], [w[lp + "intermediate.dense.bias"]], act=ops.ACT_GELU)
-            o = ops.gemm_nt(i, [w[lp + "output.dense.weight"]], [w[lp + "output.dense.bias"]], residual=h)
+            u = ops.gemm_nt_train(h, w[lp + "intermediate.dense.weight"], w[lp + "intermediate.dense.bias"])
+            i = ops.gelu_fwd(u)
+            o = ops.gemm_nt_train(i, w[lp + "output.dense.weight"], w[lp + "output.dense.bias"], residual=h)
             x_next = ops.layernorm(o, w[lp + "output.LayerNorm.weight"], w[lp + "output.LayerNorm.bias"], sp.ln_eps)
             saved["layers"].append(dict(x=x, qkv=qkv, ctx=ctx, a=a, h=h, u=u, i=i, o=o))
             x = x_next
@@ -63,12 +63,12 @@ class RobertaTrainGraph:
     @staticmethod
     def _dgrad(dy: torch.Tensor, W: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """dX = dY @ W (+ residual): the NT kernel on W^T."""
-        return ops.gemm_nt(dy, [ops.transpose_pad(W)], residual=residual)
+        return ops.gemm_nt_train(dy, ops.transpose_pad(W), residual=residual)
 
     @staticmethod
     def _wgrad(dy_t: torch.Tensor, x_t: torch.Tensor, out: torch.Tensor):
         """dW = dY^T @ X written into ``out`` (a view of the gradient arena): both operands token-major transposed."""
-        ops.gemm_nt(dy_t, [x_t], out=out)
+        ops.gemm_nt_train(dy_t, x_t, out=out)
 
     def backward(self, d_cls: torch.Tensor) -> torch.Tensor:
         """d loss / d CLS rows (B, d) -> d loss / d parameters, flat, arena layout (pads zero)."""
@@ -117,7 +117,7 @@ class RobertaTrainGraph:
                 g[name + ".bias"].copy_(bsum[k * d:(k + 1) * d])
                 self._wgrad(dqkv_t[k * d:(k + 1) * d], x_t, g[name + ".weight"])
                 ops.transpose_pad(w[name + ".weight"], out=wt[:, k * d:(k + 1) * d])
-            dx = ops.gemm_nt(dqkv, [wt], residual=da)  # + the residual path of a
+            dx = ops.gemm_nt_train(dqkv, wt, residual=da)  # + the residual path of a
         # x0 = LN(emb), emb = word[ids] + pos[pos_ids] + type[0]
         e = p + "embeddings."
         de = ops.layernorm_bwd(sv["emb"], dx, w[e + "LayerNorm.weight"], sp.ln_eps, g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"])

@@ -53,7 +53,7 @@ class _GroupLossFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         if ctx.dz_pad is None:
             return None, None, None, None, None, None
-        d_reps = ops.gemm_nt(ctx.dz_pad, [ctx.Et_pad])  # (n, Mpad) @ (d, Mpad).T
+        d_reps = ops.gemm_nt_train(ctx.dz_pad, ctx.Et_pad)  # (n, Mpad) @ (d, Mpad).T: a handful of rows, k = catalog size -> split-K
         return d_reps * grad_out, None, None, None, None, None
 
 

@@ -459,6 +459,27 @@ def _pad16(n: int) -> int:
     return (n + 15) // 16 * 16
 
 
+def gemm_nt_train(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A @ W.T (+ bias) (+ residual) for the training graph: split-K when the output has too few tiles to fill the chip."""
+    _dev(A, "A", torch.float32), _dev(W, "W", torch.float32)
+    M, K = A.shape
+    N = W.shape[0]
+    if W.shape[1] != K or not W.is_contiguous() or A.stride(1) != 1:
+        raise ValueError("A (M, K) with unit inner stride and contiguous W (N, K) expected")
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device) if out is None else out
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    splits = max(1, min(K // 16, 16, 512 // max(tiles, 1)))
+    lib = _lib.load()
+    nbytes = lib.mr_gemm_nt_splitk_ws_bytes(M, N, splits)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=A.device) if splits > 1 else None
+    ev = PROF.begin(A.device)
+    check(lib.mr_gemm_nt_splitk_f32(ptr(A), A.stride(0), ptr(W), ptr(bias), M, N, K, ptr(residual), 0 if residual is None else residual.stride(0),
+                                    ptr(out), out.stride(0), splits, ptr(ws), nbytes, _stream(A)), "mr_gemm_nt_splitk_f32")
+    PROF.end(ev, A.device, "gemm_nt_train", flops=2.0 * M * N * K, nbytes=4.0 * (M * K + N * K + M * N))
+    return out
+
+
 def transpose_pad(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(R, C) -> (C, pad16(R)) with the pad columns zeroed: the K-contiguous operand layout of the NT GEMM."""
     _dev(x, "x", torch.float32)
@@ -475,6 +496,15 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     out = torch.empty(C, dtype=torch.float32, device=x.device) if out is None else out
     check(_lib.load().mr_colsum_f32(ptr(x), x.stride(0), R, C, ptr(out), _stream(x)), "mr_colsum_f32")
     return out
+
+
+def gelu_fwd(u: torch.Tensor) -> torch.Tensor:
+    _dev(u, "u", torch.float32)
+    if not u.is_contiguous():
+        raise ValueError("u must be contiguous")
+    h = torch.empty_like(u)
+    check(_lib.load().mr_gelu_fwd_f32(ptr(u), u.numel(), ptr(h), _stream(u)), "mr_gelu_fwd_f32")
+    return h
 
 
 def gelu_bwd(u: torch.Tensor, dh: torch.Tensor) -> torch.Tensor:
