@@ -301,9 +301,16 @@ int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t l
                          float* dx, int64_t lddx, float* stats, float* dgamma, float* dbeta, mr_stream_t stream);
 
 /* Softmax self-attention backward on packed sequences: qkv (T, 3 H dh) = [Q | K | V] and ctx (T, H dh) as in mr_attn_f32,
- * dctx = d loss / d ctx; rowstat (T, H, 2) is workspace; dqkv (T, 3 H dh) receives [dQ | dK | dV].  dh must be 64. */
+ * dctx = d loss / d ctx; rowstat (T, H, 2) is workspace; dqkv (T, 3 H dh) receives [dQ | dK | dV].  dh must be 64.
+ * window < 0: full attention; window >= 0: Longformer band |i - j| <= window plus the global key 0, query row 0 excluded (it
+ * belongs to the global-row kernel). */
 int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, int B, int H, int dh, float scale,
-                    float* rowstat, float* dqkv, mr_stream_t stream);
+                    int window, float* rowstat, float* dqkv, mr_stream_t stream);
+
+/* Longformer global row (mr_attn_global_row_f32) backward: qg (B, H dh), kvg (T, 2 H dh) = [Kg | Vg], ctx_cls / dctx_cls (B, H dh) the
+ * forward output and its gradient at the CLS rows; dqg (B, H dh), dkvg (T, 2 H dh). */
+int mr_attn_global_row_bwd_f32(const float* qg, const float* kvg, const float* ctx_cls, const float* dctx_cls, const int32_t* cu_seqlens,
+                               int B, int H, int dh, float scale, float* dqg, float* dkvg, mr_stream_t stream);
 
 /* table[idx[t]][:] += src[t][:] (atomic adds: embedding-table gradients; with unique indices a plain row scatter). */
 int mr_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int T, int d, float* table, int64_t ldt,

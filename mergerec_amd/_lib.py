@@ -52,7 +52,8 @@ SIGNATURES = {
     "mr_gelu_fwd_f32": (c_i, [c_p, c_i64, c_p, c_p]),
     "mr_gelu_bwd_f32": (c_i, [c_p, c_p, c_i64, c_p, c_p]),
     "mr_layernorm_bwd_f32": (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_f, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p]),
-    "mr_attn_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "mr_attn_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p]),
+    "mr_attn_global_row_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
     "mr_scatter_add_rows_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_p, c_i64, c_p]),
     "mr_pack_tokens": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mr_embed_gather_ln_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p]),

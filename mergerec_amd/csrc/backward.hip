@@ -146,11 +146,20 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_params_kernel(const fl
 
 // ------------------------------------------------------------------------------------------------ attention backward
 // qkv (T, 3 H 64) = [Q | K | V] as the forward; ctx, dctx (T, H 64); rowstat (T, H, 2) = (logsumexp of the scaled scores, delta)
+// Longformer mode (window >= 0): query i sees key j iff j == 0 (global key) or |i - j| <= window, and query row 0 belongs to the
+// global-row kernel (its regular output is overwritten in the forward), so it sees nothing here.
+__device__ __forceinline__ bool attn_allowed(int i, int j, int window) {
+    if (window < 0) return true;
+    if (i == 0) return false;
+    const int dlt = i - j;
+    return j == 0 || (dlt <= window && dlt >= -window);
+}
+
 // One workgroup per (sequence, head).  Scores s_ij = scale * q_i . k_j, p_ij = exp(s_ij - lse_i), delta_i = dO_i . O_i,
 // dS_ij = p_ij (dO_i . v_j - delta_i):  dQ_i = scale sum_j dS_ij k_j;  dK_j = scale sum_i dS_ij q_i;  dV_j = sum_i p_ij dO_i.
 __global__ __launch_bounds__(kThreads) void attn_bwd_stats_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
                                                                  const float* __restrict__ dctx, const int32_t* __restrict__ cu, int H,
-                                                                 float scale, float* __restrict__ rowstat) {
+                                                                 float scale, int window, float* __restrict__ rowstat) {
     __shared__ float ks[32][kDh];
     const int b = blockIdx.x, h = blockIdx.y;
     const int t0 = cu[b], len = cu[b + 1] - t0;
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_stats_kernel(const float* _
             __syncthreads();
             const int nj = (len - j0) < 32 ? (len - j0) : 32;
             for (int jr = 0; jr < nj; ++jr) {
+                if (!attn_allowed(ic, j0 + jr, window)) continue;
                 float s = 0.f;
 #pragma unroll
                 for (int d = 0; d < kDh; ++d) s = fmaf(qr[d], ks[jr][d], s);
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_stats_kernel(const float* _
             float dl = 0.f;
 #pragma unroll
             for (int d = 0; d < kDh; ++d) dl = fmaf(o[d], g[d], dl);
-            rowstat[((int64_t)(t0 + i) * H + h) * 2] = m + logf(l);
+            rowstat[((int64_t)(t0 + i) * H + h) * 2] = (l > 0.f) ? m + logf(l) : 0.f;  // (no allowed key: the windowed mode's row 0)
             rowstat[((int64_t)(t0 + i) * H + h) * 2 + 1] = dl;
         }
     }
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_stats_kernel(const float* _
 // query-owned pass: thread i holds q_i, dO_i and accumulates dQ_i over all keys (keys / values staged through LDS in tiles of 32)
 __global__ __launch_bounds__(kThreads) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                               const float* __restrict__ rowstat, const int32_t* __restrict__ cu, int H,
-                                                              float scale, float* __restrict__ dqkv) {
+                                                              float scale, int window, float* __restrict__ dqkv) {
     __shared__ float ks[32][kDh], vs[32][kDh];
     const int b = blockIdx.x, h = blockIdx.y;
     const int t0 = cu[b], len = cu[b + 1] - t0;
@@ -224,6 +234,7 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dq_kernel(const float* __re
             __syncthreads();
             const int nj = (len - j0) < 32 ? (len - j0) : 32;
             for (int jr = 0; jr < nj; ++jr) {
+                if (!attn_allowed(ic, j0 + jr, window)) continue;
                 float s = 0.f, dp = 0.f;
 #pragma unroll
                 for (int d = 0; d < kDh; ++d) {
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dq_kernel(const float* __re
 // key-owned pass: a lane pair (2 j, 2 j + 1) owns key j, each lane one 32-wide half of d; queries staged through LDS
 __global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                                const float* __restrict__ rowstat, const int32_t* __restrict__ cu, int H,
-                                                               float scale, float* __restrict__ dqkv) {
+                                                               float scale, int window, float* __restrict__ dqkv) {
     __shared__ float qs[32][kDh], gs[32][kDh], st[32][2];
     const int b = blockIdx.x, h = blockIdx.y;
     const int t0 = cu[b], len = cu[b + 1] - t0;
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(const float* __r
                 }
                 s += __shfl_xor(s, 1, 64);   // the pair's two halves of the dot products (same order in both lanes)
                 dp += __shfl_xor(dp, 1, 64);
-                const float p = expf(s * scale - st[ir][0]);
+                const float p = attn_allowed(i0 + ir, jc, window) ? expf(s * scale - st[ir][0]) : 0.f;
                 const float ds = p * (dp - st[ir][1]) * scale;
 #pragma unroll
                 for (int d = 0; d < 32; ++d) {
@@ -299,6 +310,94 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(const float* __r
 #pragma unroll
             for (int d = 0; d < 32; ++d) { ok[d] = dk[d]; ov[d] = dv[d]; }
         }
+    }
+}
+
+// Longformer global row backward: per (sequence, head) ONE query (qg, from query_global(x_cls)) against all keys / values of the
+// sequence (kvg = [key_global(x) | value_global(x)]).  dctx_cls (B, H 64) = d loss / d ctx[cls rows], ctx_cls the forward output.
+// Outputs dqg (B, H 64) and dkvg (T, 2 H 64).  One workgroup per (sequence, head), threads over keys.
+__global__ __launch_bounds__(kThreads) void attn_global_row_bwd_kernel(const float* __restrict__ qg, const float* __restrict__ kvg,
+                                                                      const float* __restrict__ ctx_cls, const float* __restrict__ dctx_cls,
+                                                                      const int32_t* __restrict__ cu, int H, float scale,
+                                                                      float* __restrict__ dqg, float* __restrict__ dkvg) {
+    __shared__ float red[kThreads / 64][kDh + 1];
+    __shared__ float bc[2];
+    const int b = blockIdx.x, h = blockIdx.y;
+    const int t0 = cu[b], len = cu[b + 1] - t0;
+    const int64_t ld = (int64_t)2 * H * kDh, ldq = (int64_t)H * kDh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float q[kDh], g[kDh];
+    float dl = 0.f;
+#pragma unroll
+    for (int d = 0; d < kDh; ++d) {
+        q[d] = qg[(int64_t)b * ldq + h * kDh + d];
+        g[d] = dctx_cls[(int64_t)b * ldq + h * kDh + d];
+        dl = fmaf(g[d], ctx_cls[(int64_t)b * ldq + h * kDh + d], dl);
+    }
+    // pass 1: max and sum of exp over the keys
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < len; j += kThreads) {
+        const float* k = kvg + (int64_t)(t0 + j) * ld + h * kDh;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < kDh; ++d) s = fmaf(q[d], k[d], s);
+        m = fmaxf(m, s * scale);
+    }
+    m = mr::wave_max(m);
+    if (lane == 0) red[wave][0] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) bc[0] = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    __syncthreads();
+    m = bc[0];
+    float l = 0.f;
+    for (int j = threadIdx.x; j < len; j += kThreads) {
+        const float* k = kvg + (int64_t)(t0 + j) * ld + h * kDh;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < kDh; ++d) s = fmaf(q[d], k[d], s);
+        l += expf(s * scale - m);
+    }
+    l = mr::wave_sum(l);
+    __syncthreads();
+    if (lane == 0) red[wave][0] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) bc[1] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+    __syncthreads();
+    const float lse = m + logf(bc[1]);
+    // pass 2: per key dK, dV; dq accumulated per thread, then combined in a fixed order
+    float dq[kDh];
+#pragma unroll
+    for (int d = 0; d < kDh; ++d) dq[d] = 0.f;
+    for (int j = threadIdx.x; j < len; j += kThreads) {
+        const float* k = kvg + (int64_t)(t0 + j) * ld + h * kDh;
+        const float* v = k + H * kDh;
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < kDh; ++d) {
+            s = fmaf(q[d], k[d], s);
+            dp = fmaf(g[d], v[d], dp);
+        }
+        const float p = expf(s * scale - lse);
+        const float ds = p * (dp - dl) * scale;
+        float* ok = dkvg + (int64_t)(t0 + j) * ld + h * kDh;
+        float* ov = ok + H * kDh;
+#pragma unroll
+        for (int d = 0; d < kDh; ++d) {
+            ok[d] = ds * q[d];
+            ov[d] = p * g[d];
+            dq[d] = fmaf(ds, k[d], dq[d]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < kDh; ++d) {
+        const float t = mr::wave_sum(dq[d]);
+        if (lane == 0) red[wave][d] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < kDh) {
+        const int d = threadIdx.x;
+        dqg[(int64_t)b * ldq + h * kDh + d] = ((red[0][d] + red[1][d]) + red[2][d]) + red[3][d];
     }
 }
 
@@ -369,15 +468,26 @@ extern "C" int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy
 }
 
 extern "C" int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, int B, int H, int dh,
-                               float scale, float* rowstat, float* dqkv, mr_stream_t stream) {
+                               float scale, int window, float* rowstat, float* dqkv, mr_stream_t stream) {
     if (!qkv || !ctx || !dctx || !cu_seqlens || !rowstat || !dqkv || B < 0 || H < 1) return MR_EINVAL;
     if (dh != kDh) return MR_EUNSUPPORTED;
     if (B == 0) return MR_OK;
     const dim3 grid(B, H);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_stats_kernel, grid, dim3(kThreads), 0, st, qkv, ctx, dctx, cu_seqlens, H, scale, rowstat);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(kThreads), 0, st, qkv, dctx, rowstat, cu_seqlens, H, scale, dqkv);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(kThreads), 0, st, qkv, dctx, rowstat, cu_seqlens, H, scale, dqkv);
+    hipLaunchKernelGGL(attn_bwd_stats_kernel, grid, dim3(kThreads), 0, st, qkv, ctx, dctx, cu_seqlens, H, scale, window, rowstat);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(kThreads), 0, st, qkv, dctx, rowstat, cu_seqlens, H, scale, window, dqkv);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(kThreads), 0, st, qkv, dctx, rowstat, cu_seqlens, H, scale, window, dqkv);
+    return mr::check_launch();
+}
+
+extern "C" int mr_attn_global_row_bwd_f32(const float* qg, const float* kvg, const float* ctx_cls, const float* dctx_cls,
+                                          const int32_t* cu_seqlens, int B, int H, int dh, float scale, float* dqg, float* dkvg,
+                                          mr_stream_t stream) {
+    if (!qg || !kvg || !ctx_cls || !dctx_cls || !cu_seqlens || !dqg || !dkvg || B < 0 || H < 1) return MR_EINVAL;
+    if (dh != kDh) return MR_EUNSUPPORTED;
+    if (B == 0) return MR_OK;
+    hipLaunchKernelGGL(attn_global_row_bwd_kernel, dim3(B, H), dim3(kThreads), 0, (hipStream_t)stream, qg, kvg, ctx_cls, dctx_cls, cu_seqlens,
+                       H, scale, dqg, dkvg);
     return mr::check_launch();
 }
 

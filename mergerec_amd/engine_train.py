@@ -1,4 +1,4 @@
-"""Differentiable BLaIR (RoBERTa) encoder for the collaborative-merging optimisation loop (merge_train.py, HOT LOOP 3 of
+"""Differentiable BLaIR (RoBERTa) / Recformer (Longformer) encoder for the collaborative-merging optimisation loop (merge_train.py, HOT LOOP 3 of
 SURVEY.md §3.2): forward on packed tokens with the activations kept, backward producing d loss / d merged parameters as ONE
 flat vector in the parameter arena's layout -- exactly the ``g`` that ``mr_merge_bwd_alpha_f32`` contracts with the task vectors.
 
@@ -8,7 +8,8 @@ GEMM of the inference path (gemm.hip) after an operand re-layout (csrc/backward.
 query-owned / key-owned kernels, LayerNorm / GELU / bias gradients are row and column kernels.  Batches are tiny (16 pseudo-user
 sequences of item text), so the step is bound by the parameter-sized streams, not by token math.
 
-Recformer (sliding-window + global attention) backward is not built yet."""
+Recformer: the band + global-key attention backward is the same pair of kernels with the Longformer mask; the global CLS row
+(query_global / key_global / value_global projections) has its own one-query backward kernel; four embedding tables."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -18,16 +19,16 @@ import torch
 from . import ops
 from .engine import ArenaLayout, EncoderSpec, PackedBatch
 
-__all__ = ["RobertaTrainGraph", "encode_with_grad"]
+__all__ = ["EncoderTrainGraph", "RobertaTrainGraph", "encode_with_grad"]
 
 
-class RobertaTrainGraph:
+class EncoderTrainGraph:
     def __init__(self, spec: EncoderSpec, layout: ArenaLayout, prefix: str = "model."):
-        if spec.kind == "recformer":
-            raise NotImplementedError("the encoder backward is built for BLaIR / RoBERTa; Recformer's windowed + global attention backward is not")
         if spec.hidden // spec.heads != 64:
             raise ValueError("attention kernels are built for head_dim == 64")
         self.spec, self.layout, self.prefix = spec, layout, prefix
+        self.rec = spec.kind == "recformer"
+        self.window = spec.one_sided_window if self.rec else -1
         self._saved = None
 
     # ---------------------------------------------------------------------------------------------- forward
@@ -37,8 +38,11 @@ class RobertaTrainGraph:
         w = self.layout.views(flat)
         e = p + "embeddings."
         # pre-LayerNorm embedding sum (the fused inference kernel does not expose it): three row gathers
-        emb = ops.gather_rows(w[e + "word_embeddings.weight"], pb.tok_word) + ops.gather_rows(w[e + "position_embeddings.weight"], pb.tok_pos) \
-            + w[e + "token_type_embeddings.weight"][0]
+        emb = ops.gather_rows(w[e + "word_embeddings.weight"], pb.tok_word) + ops.gather_rows(w[e + "position_embeddings.weight"], pb.tok_pos)
+        if self.rec:  # recformer/models.py:104-136: + token_type[tt] + item_position[ip]
+            emb = emb + ops.gather_rows(w[e + "token_type_embeddings.weight"], pb.tok_tt) + ops.gather_rows(w[e + "item_position_embeddings.weight"], pb.tok_ip)
+        else:
+            emb = emb + w[e + "token_type_embeddings.weight"][0]
         x = ops.layernorm(emb, w[e + "LayerNorm.weight"], w[e + "LayerNorm.bias"], sp.ln_eps)
         saved = dict(pb=pb, flat=flat, emb=emb, layers=[])
         for l in range(sp.layers):
@@ -47,14 +51,22 @@ class RobertaTrainGraph:
             qkv = torch.empty(pb.T, 3 * sp.hidden, dtype=torch.float32, device=x.device)
             for s, n in enumerate(names):
                 ops.gemm_nt_train(x, w[n + ".weight"], w[n + ".bias"], out=qkv[:, s * sp.hidden:(s + 1) * sp.hidden])
-            ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=-1, seq_order=pb.seq_order, products=0)
+            ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=self.window, seq_order=pb.seq_order, products=0)
+            qg = kvg = None
+            if self.rec:  # Longformer global row: CLS attends to every token through the *_global projections and overwrites ctx[cls]
+                x_cls = ops.gather_rows(x, pb.cls_rows)
+                qg = ops.gemm_nt_train(x_cls, w[f"{lp}attention.self.query_global.weight"], w[f"{lp}attention.self.query_global.bias"])
+                kvg = torch.empty(pb.T, 2 * sp.hidden, dtype=torch.float32, device=x.device)
+                for s, n in enumerate(("key_global", "value_global")):
+                    ops.gemm_nt_train(x, w[f"{lp}attention.self.{n}.weight"], w[f"{lp}attention.self.{n}.bias"], out=kvg[:, s * sp.hidden:(s + 1) * sp.hidden])
+                ops.attention_global_row(qg, kvg, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx)
             a = ops.gemm_nt_train(ctx, w[lp + "attention.output.dense.weight"], w[lp + "attention.output.dense.bias"], residual=x)
             h = ops.layernorm(a, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps)
             u = ops.gemm_nt_train(h, w[lp + "intermediate.dense.weight"], w[lp + "intermediate.dense.bias"])
             i = ops.gelu_fwd(u)
             o = ops.gemm_nt_train(i, w[lp + "output.dense.weight"], w[lp + "output.dense.bias"], residual=h)
             x_next = ops.layernorm(o, w[lp + "output.LayerNorm.weight"], w[lp + "output.LayerNorm.bias"], sp.ln_eps)
-            saved["layers"].append(dict(x=x, qkv=qkv, ctx=ctx, a=a, h=h, u=u, i=i, o=o))
+            saved["layers"].append(dict(x=x, qkv=qkv, ctx=ctx, a=a, h=h, u=u, i=i, o=o, qg=qg, kvg=kvg))
             x = x_next
         self._saved = saved
         return ops.gather_rows(x, pb.cls_rows)
@@ -106,10 +118,28 @@ class RobertaTrainGraph:
             ops.colsum(da, g[lp + "attention.output.dense.bias"])
             self._wgrad(ops.transpose_pad(da), ops.transpose_pad(s["ctx"]), g[lp + "attention.output.dense.weight"])
             dctx = self._dgrad(da, w[lp + "attention.output.dense.weight"])
-            dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads)
+            dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window)
+            x_t = ops.transpose_pad(s["x"])
+            if self.rec:
+                dqg, dkvg = ops.attention_global_row_bwd(s["qg"], s["kvg"], ops.gather_rows(s["ctx"], pb.cls_rows), ops.gather_rows(dctx, pb.cls_rows),
+                                                         pb.cu_seqlens, pb.B, sp.heads)
+                # key_global / value_global read every token
+                dkvg_t = ops.transpose_pad(dkvg)
+                bs2 = ops.colsum(dkvg)
+                wt2 = torch.empty(d, 2 * d, dtype=torch.float32, device=dx.device)
+                for k, n in enumerate(("key_global", "value_global")):
+                    name = f"{lp}attention.self.{n}"
+                    g[name + ".bias"].copy_(bs2[k * d:(k + 1) * d])
+                    self._wgrad(dkvg_t[k * d:(k + 1) * d], x_t, g[name + ".weight"])
+                    ops.transpose_pad(w[name + ".weight"], out=wt2[:, k * d:(k + 1) * d])
+                da = ops.gemm_nt_train(dkvg, wt2, residual=da)  # folded into the residual that the qkv d-grad below carries on
+                # query_global reads the CLS rows only
+                name = f"{lp}attention.self.query_global"
+                ops.colsum(dqg, g[name + ".bias"])
+                self._wgrad(ops.transpose_pad(dqg), ops.transpose_pad(ops.gather_rows(s["x"], pb.cls_rows)), g[name + ".weight"])
+                ops.scatter_add_rows(self._dgrad(dqg, w[name + ".weight"]), pb.cls_rows, da)
             # qkv = x [Wq; Wk; Wv]^T + b
             dqkv_t = ops.transpose_pad(dqkv)  # (3 d, T_pad)
-            x_t = ops.transpose_pad(s["x"])
             bsum = ops.colsum(dqkv)
             wt = torch.empty(d, 3 * d, dtype=torch.float32, device=dx.device)  # [Wq; Wk; Wv]^T
             for k, n in enumerate(("query", "key", "value")):
@@ -123,14 +153,21 @@ class RobertaTrainGraph:
         de = ops.layernorm_bwd(sv["emb"], dx, w[e + "LayerNorm.weight"], sp.ln_eps, g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"])
         ops.scatter_add_rows(de, pb.tok_word, g[e + "word_embeddings.weight"])
         ops.scatter_add_rows(de, pb.tok_pos, g[e + "position_embeddings.weight"])
-        ops.colsum(de, g[e + "token_type_embeddings.weight"][0])
+        if self.rec:
+            ops.scatter_add_rows(de, pb.tok_tt, g[e + "token_type_embeddings.weight"])
+            ops.scatter_add_rows(de, pb.tok_ip, g[e + "item_position_embeddings.weight"])
+        else:
+            ops.colsum(de, g[e + "token_type_embeddings.weight"][0])
         self._saved = None
         return g_flat
 
 
+RobertaTrainGraph = EncoderTrainGraph  # first name of the class (BLaIR only at the time)
+
+
 class _EncodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, flat, graph: RobertaTrainGraph, pb: PackedBatch):
+    def forward(ctx, flat, graph: EncoderTrainGraph, pb: PackedBatch):
         ctx.graph = graph
         return graph.forward(flat, pb)
 
@@ -139,6 +176,6 @@ class _EncodeFn(torch.autograd.Function):
         return ctx.graph.backward(d_cls.contiguous()), None, None
 
 
-def encode_with_grad(graph: RobertaTrainGraph, flat: torch.Tensor, pb: PackedBatch) -> torch.Tensor:
+def encode_with_grad(graph: EncoderTrainGraph, flat: torch.Tensor, pb: PackedBatch) -> torch.Tensor:
     """(B, d) CLS rows with an autograd edge to the flat parameter vector ``flat`` (arena layout)."""
     return _EncodeFn.apply(flat, graph, pb)

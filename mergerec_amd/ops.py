@@ -528,16 +528,29 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
     return dx
 
 
-def attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, scale: Optional[float] = None):
+def attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, scale: Optional[float] = None,
+                  window: int = -1):
     _dev(qkv, "qkv", torch.float32), _dev(ctx, "ctx", torch.float32), _dev(dctx, "dctx", torch.float32)
     T = qkv.shape[0]
     if not (qkv.is_contiguous() and ctx.is_contiguous() and dctx.is_contiguous()) or qkv.shape[1] != 3 * H * 64:
         raise ValueError("qkv (T, 3 H 64), ctx / dctx (T, H 64) must be contiguous")
     dqkv = torch.empty_like(qkv)
     rowstat = torch.empty(max(T, 1), H, 2, dtype=torch.float32, device=qkv.device)
-    check(_lib.load().mr_attn_bwd_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), B, H, 64, 0.125 if scale is None else scale, ptr(rowstat),
-                                      ptr(dqkv), _stream(qkv)), "mr_attn_bwd_f32")
+    check(_lib.load().mr_attn_bwd_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), B, H, 64, 0.125 if scale is None else scale, window,
+                                      ptr(rowstat), ptr(dqkv), _stream(qkv)), "mr_attn_bwd_f32")
     return dqkv
+
+
+def attention_global_row_bwd(qg: torch.Tensor, kvg: torch.Tensor, ctx_cls: torch.Tensor, dctx_cls: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int):
+    """-> (dqg (B, H 64), dkvg (T, 2 H 64)) of the Longformer global row."""
+    for t, n in ((qg, "qg"), (kvg, "kvg"), (ctx_cls, "ctx_cls"), (dctx_cls, "dctx_cls")):
+        _dev(t, n, torch.float32)
+        if not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous")
+    dqg, dkvg = torch.empty_like(qg), torch.empty_like(kvg)
+    check(_lib.load().mr_attn_global_row_bwd_f32(ptr(qg), ptr(kvg), ptr(ctx_cls), ptr(dctx_cls), ptr(cu_seqlens), B, H, 64, 0.125, ptr(dqg), ptr(dkvg),
+                                                 _stream(qg)), "mr_attn_global_row_bwd_f32")
+    return dqg, dkvg
 
 
 def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, table: torch.Tensor):

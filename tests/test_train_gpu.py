@@ -191,3 +191,62 @@ def test_merge_train_cli_runs_and_moves_alpha(tmp_path):
     assert any(abs(w - 0.2) > 1e-3 for w in per), per          # Adam moved alpha away from initial_per_weight
     assert load_alpha_file(res["weights_file"], -1)["per_weights"]["all"] != [0.2, 0.2]
     assert "test/dataset_0/test/NDCG@10" in res["test_metrics"]
+
+
+def test_global_row_backward_matches_torch():
+    from mergerec_amd import ops
+
+    H, lens, g = 2, [7, 300, 1], torch.Generator().manual_seed(21)
+    B, T = len(lens), sum(lens)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    qg = torch.randn(B, H * 64, generator=g).requires_grad_(True)
+    kvg = torch.randn(T, 2 * H * 64, generator=g).requires_grad_(True)
+    dctx = torch.randn(B, H * 64, generator=g)
+    outs = []
+    for b in range(B):
+        s, e = int(cu[b]), int(cu[b + 1])
+        q = qg[b].view(H, 1, 64)
+        K = kvg[s:e, :H * 64].view(e - s, H, 64).transpose(0, 1)
+        V = kvg[s:e, H * 64:].view(e - s, H, 64).transpose(0, 1)
+        outs.append((torch.softmax(q @ K.transpose(1, 2) * 0.125, dim=-1) @ V).reshape(H * 64))
+    ctx = torch.stack(outs)
+    ctx.backward(dctx)
+    full = torch.zeros(T, H * 64, device=DEV)
+    ops.attention_global_row(qg.detach().to(DEV), kvg.detach().to(DEV), cu.to(DEV), B, H, max(lens), full)
+    got_ctx = full[cu[:-1].long().to(DEV)]
+    assert torch.allclose(got_ctx.cpu(), ctx.detach(), atol=2e-5)
+    dq, dkv = ops.attention_global_row_bwd(qg.detach().to(DEV), kvg.detach().to(DEV), got_ctx.contiguous(), dctx.to(DEV), cu.to(DEV), B, H)
+    assert torch.allclose(dq.cpu(), qg.grad, atol=3e-5, rtol=1e-4) and torch.allclose(dkv.cpu(), kvg.grad, atol=3e-5, rtol=1e-4)
+
+
+def test_recformer_backward_matches_oracle_autograd():
+    """every parameter gradient of the Longformer-style encoder (band + global key, global CLS row, four embedding tables)"""
+    from mergerec_amd.engine import ArenaLayout, EncoderRunner
+    from mergerec_amd.engine_train import EncoderTrainGraph, encode_with_grad
+    from tests.test_path_gpu import _spec
+
+    for case in load_golden("g4_recformer.pt")["cases"]:
+        cfgd, sd, b = case["cfg"], case["state_dict"], case["batch"]
+        cfg = O.EncoderConfig(**{k: cfgd[k] for k in cfgd if k in O.EncoderConfig.__dataclass_fields__})
+        p = OrderedDict((k, v.clone().float().requires_grad_(v.is_floating_point())) for k, v in sd.items())
+        cls = O.recformer_encode(p, b["input_ids"], b["attention_mask"], b["global_attention_mask"], b["token_type_ids"], b["item_position_ids"], cfg,
+                                 prefix="model.")
+        R = torch.randn(cls.shape, generator=torch.Generator().manual_seed(5))
+        (O.maybe_normalize(cls) * R).sum().backward()
+        views = OrderedDict((k, v.to(torch.float32)) for k, v in sd.items())
+        layout = ArenaLayout(OrderedDict((k, tuple(v.shape)) for k, v in views.items()))
+        flat = layout.pack(views, DEV).requires_grad_(True)
+        spec = _spec(cfgd, "recformer")
+        pb = EncoderRunner(spec).pack(b, DEV)
+        out = encode_with_grad(EncoderTrainGraph(spec, layout), flat, pb)
+        assert torch.allclose(out.detach().cpu(), cls.detach(), atol=1e-4, rtol=1e-5)
+        (torch.nn.functional.normalize(out, dim=-1) * R.to(DEV)).sum().backward()
+        got = layout.views(flat.grad)
+        gmax = max(float(v.grad.abs().max()) for v in p.values() if v.requires_grad and v.grad is not None)
+        for k, v in p.items():
+            if not v.requires_grad or v.grad is None:
+                assert float(got[k].abs().max()) == 0.0, k
+                continue
+            scale = max(float(v.grad.abs().max()), 1e-3 * gmax)
+            err = float((got[k].cpu() - v.grad).abs().max()) / scale
+            assert err <= 3e-3, (k, err, scale)
