@@ -6,7 +6,7 @@ of the merge_test flags), argparse instead of tyro; wandb / Lightning loggers ar
 
 Per step: re-merge (differentiable) -> encode 16 pseudo-user sequences -> per-domain logits against the frozen catalog
 embeddings -> fused distillation loss vs the teacher rows -> encoder backward -> d loss / d alpha -> Adam on alpha.  BLaIR
-(RoBERTa) models only: Recformer's sliding-window attention backward is not built.
+(RoBERTa) and Recformer (Longformer) models.
 
 Teacher embeddings: ``--item_embeddings_paths`` / ``--sequence_embeddings_paths`` are the ``item_embedding.pt`` files of
 scripts/extract.py, or the single word ``auto`` to encode every domain's catalog with its own fine-tuned checkpoint first.
@@ -48,8 +48,25 @@ def _pop(argv, flag, default=None, cast=str, many=False):
     return cast(vals[0]) if vals else default
 
 
+def _init_distributed():
+    """Under torch.distributed.run (one process per GPU): pin this process to its GPU BEFORE the HIP runtime starts (so every rank
+    addresses its device as cuda:0) and join the process group (RCCL; ``MERGEREC_DIST_BACKEND=gloo`` + ``MERGEREC_SHARE_GPU=1`` for a
+    rehearsal with several ranks on one GPU).  Data parallelism here = each rank trains on its own shard of every epoch's pseudo
+    users and the ranks average d loss / d alpha (mergerec_amd.parallel.allreduce_mean_grads)."""
+    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return 0, 1
+    if os.environ.get("MERGEREC_SHARE_GPU", "0") != "1":
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+
+    dist.init_process_group(os.environ.get("MERGEREC_DIST_BACKEND", "nccl"))
+    return dist.get_rank(), dist.get_world_size()
+
+
 def main(argv=None):
     import merge_test as mt
+
+    rank, world = _init_distributed()
 
     argv = list(sys.argv[1:] if argv is None else argv)
     opt = dict(
@@ -69,7 +86,7 @@ def main(argv=None):
         skip_test=_pop(argv, "--skip_test", "false").lower() in ("1", "true", "yes"),
     )
     config = mt.parse(argv)
-    from mergerec_amd.datamodule import DistillSequenceDataModule, load_tokenizer
+    from mergerec_amd.datamodule import DistillSequenceDataModule, DistillSequenceDataModuleForRecformer, load_tokenizer
     from mergerec_amd.evaluator import Evaluator
     from mergerec_amd.merger import LearnType, LossType, MergeType, load_merging_module
     from mergerec_amd.module import (DistillSequenceModule, ModelType, MultiDatasetItemEncodingCallback, RecModule, SaveWeightsCallback,
@@ -78,8 +95,7 @@ def main(argv=None):
     from mergerec_amd.utils import DistillTrainer, remove_duplicate_prefix, test_model_from_paths
 
     torch.manual_seed(config.seed)
-    if config.model_type.startswith("RECFORMER"):
-        raise SystemExit("merge_train.py: the encoder backward is built for BLaIR / RoBERTa models; Recformer is not supported yet")
+    recformer = config.model_type.startswith("RECFORMER")
     if not config.tokenizer_path:
         raise SystemExit("--tokenizer_path <local tokenizer directory> is required (the box is offline)")
     tokenizer = load_tokenizer(config.tokenizer_path)
@@ -111,10 +127,10 @@ def main(argv=None):
         raise SystemExit("--item_embeddings_paths auto needs --train_data_split item (pseudo users = catalog items)")
     for d in range(n):
         if auto:
-            from mergerec_amd.datamodule import RecDataModule
+            from mergerec_amd.utils import get_data_module
 
-            dm = RecDataModule(config.data_paths[d], tokenizer, config.batch_size, config.max_seq_len, config.max_attribute_len, config.max_items,
-                               item_prompt=config.item_prompt, sequence_prompt=config.sequence_prompt, reverse_sequence=reverse)
+            dm = get_data_module(ModelType[config.model_type], config.batch_size, Path(config.data_paths[d]), config.item_prompt, config.max_attribute_len,
+                                 config.max_items, config.max_seq_len, tokenizer, None, config.num_workers, reverse, config.sequence_prompt)
             dm.setup("fit")
             single = new_model()
             single.load_state_dict({k: v for k, v in finetune_state_dicts[d].items() if k != "item_embeddings"})
@@ -137,7 +153,7 @@ def main(argv=None):
         loss_fn=distill_loss_factory(LossType[opt["loss_type"]], temperature=opt["temperature"], **kwargs), learning_rate=opt["learning_rate"],
         similarity=config.similarity,
         trainable_args_kwargs=({"freeze_global_weight": True, "freeze_global_bias": True} if not config.use_softmax else {}))
-    datamodule = DistillSequenceDataModule(
+    datamodule = (DistillSequenceDataModuleForRecformer if recformer else DistillSequenceDataModule)(
         config.data_paths, tokenizer, config.batch_size, config.max_seq_len, config.max_attribute_len, config.max_items,
         sequence_embeddings=score_embeddings, train_data_split=config.train_data_split, num_workers=config.num_workers,
         valid_ratio=opt["valid_ratio"], reverse_sequence=reverse, num_sequences_per_dataset=opt["num_sequences_per_dataset"],
@@ -150,14 +166,20 @@ def main(argv=None):
         def __len__(self):
             return len(datamodule.item_dataloaders)
 
-    save_cb = SaveWeightsCallback(save_dir=opt["weights_dir"], log_every_steps=len(config.data_paths))
-    trainer = DistillTrainer(max_epochs=opt["max_epochs"], max_steps=opt["max_steps"], precision=config.precision,
-                             callbacks=[save_cb, MultiDatasetItemEncodingCallback(_ItemLoaders())])
+    callbacks = [MultiDatasetItemEncodingCallback(_ItemLoaders())]
+    save_cb = None
+    if rank == 0:  # alpha is identical on every rank (same initial value, averaged gradients): one writer
+        save_cb = SaveWeightsCallback(save_dir=opt["weights_dir"], log_every_steps=len(config.data_paths))
+        callbacks.insert(0, save_cb)
+    trainer = DistillTrainer(max_epochs=opt["max_epochs"], max_steps=opt["max_steps"], precision=config.precision, callbacks=callbacks,
+                             verbose=rank == 0)
     history = trainer.fit(module, datamodule)
-    print(f"alpha after {trainer.global_step} steps: {merged_model.serialize_weights()['per_weights']}")
-    print(f"weights written to {save_cb.save_file}")
-    result = dict(history=history, weights=merged_model.serialize_weights(), weights_file=str(save_cb.save_file))
-    if not opt["skip_test"]:  # _test_after_train (merge_train.py:28-67)
+    result = dict(history=history, weights=merged_model.serialize_weights(), weights_file=str(save_cb.save_file) if save_cb else None,
+                  rank=rank, world_size=world)
+    if rank == 0:
+        print(f"alpha after {trainer.global_step} steps on {world} rank(s): {result['weights']['per_weights']}")
+        print(f"weights written to {save_cb.save_file}")
+    if not opt["skip_test"] and rank == 0:  # _test_after_train (merge_train.py:28-67)
         print("Running test after training...")
         final = new_model()
         final.load_state_dict({k: v.detach() for k, v in merged_model.get_state_dict().items()})
@@ -168,6 +190,11 @@ def main(argv=None):
             config.test_data_split, metrics_path=config.metrics_path, predictions_path=config.predictions_path)
         print(f"Test metrics after training: {metric_dict}")
         result["test_metrics"] = metric_dict
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
     return result
 
 

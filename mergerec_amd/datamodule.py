@@ -37,7 +37,7 @@ __all__ = [
     "TokenizedItem", "TokenizedSequence", "tokenize_item", "concat_tokenized_items", "pad_tokenized_sequences",
     "RecformerSingleItemCollator", "RecformerItemSequenceCollator", "RecDataModuleForRecformer",
     "RecItemAsSequenceDataset", "ChainedDataset", "split_sequences", "sample_popular", "sample_centroid", "DistillSequenceCollator",
-    "DistillSequenceDataModule",
+    "DistillSequenceDataModule", "RecformerDistillSequenceCollator", "DistillSequenceDataModuleForRecformer",
 ]
 
 TokenizedItem = namedtuple("TokenizedItem", ["input_ids", "token_type_ids", "attr_type_ids"])
@@ -499,8 +499,7 @@ class DistillSequenceDataModule:
                 else:
                     raise ValueError(f"Unknown sample_method: {self.sample_method}")
                 dataset = Subset(dataset, indices)
-            item_text = {i: self._flatten_key_value(m) for i, m in metadata.items()}
-            collator = SingleItemCollator(self.tokenizer, item_text, self.max_seq_len, self.item_prompt)
+            item_text, collator = self._item_side(metadata)
             tr, va = split_sequences(dataset, self.valid_ratio)
             self.item_datasets.append(item_dataset)
             self.item_collators.append(collator)
@@ -509,8 +508,15 @@ class DistillSequenceDataModule:
             self.score_train_datasets.append(tr)
             self.score_valid_datasets.append(va)
             self.item_texts.append(item_text)
-        self.distill_collator = DistillSequenceCollator(self.tokenizer, self.item_texts, self.max_seq_len, "; ", self.sequence_prompt,
-                                                        self.reverse_sequence)
+        self.distill_collator = self._distill_collator()
+
+    def _item_side(self, metadata):
+        """per domain: the item representation the collators index by item id, and the catalog collator"""
+        item_text = {i: self._flatten_key_value(m) for i, m in metadata.items()}
+        return item_text, SingleItemCollator(self.tokenizer, item_text, self.max_seq_len, self.item_prompt)
+
+    def _distill_collator(self):
+        return DistillSequenceCollator(self.tokenizer, self.item_texts, self.max_seq_len, "; ", self.sequence_prompt, self.reverse_sequence)
 
     def train_dataloader(self):
         return DataLoader(ChainedDataset(self.score_train_datasets), batch_size=self.batch_size, collate_fn=self.distill_collator,
@@ -520,3 +526,40 @@ class DistillSequenceDataModule:
         return [DataLoader(ChainedDataset([v], start_dataset_idx=i), batch_size=self.batch_size, collate_fn=self.distill_collator,
                            num_workers=self.num_workers, shuffle=False)
                 for i, v in enumerate(self.score_valid_datasets) if v is not None]
+
+
+class RecformerDistillSequenceCollator:
+    """collator/distiller/recformer.py:47-82: pseudo-user sequences from pre-tokenised items, all but the last entry, NOT
+    reversed (unlike the evaluation collator)."""
+
+    def __init__(self, bos_token_id: int, pad_token_id: int, tokenized_items: List[Dict[int, TokenizedItem]], max_seq_len: int):
+        self.bos_token_id, self.pad_token_id, self.tokenized_items, self.max_seq_len = bos_token_id, pad_token_id, tokenized_items, max_seq_len
+
+    def __call__(self, batch):
+        from .model_batch import BatchDistillationSequence
+
+        ds_idx, seq_ids, seqs = [], [], []
+        for d, (sid, seq) in batch:
+            ds_idx.append(d)
+            seq_ids.append(sid)
+            seqs.append(concat_tokenized_items([self.tokenized_items[d][i] for i in seq[:-1]], self.bos_token_id))
+        return BatchDistillationSequence(dataset_indexes=ds_idx, sequence_ids=seq_ids,
+                                         sequence=pad_tokenized_sequences(seqs, self.pad_token_id, self.max_seq_len))
+
+
+class DistillSequenceDataModuleForRecformer(DistillSequenceDataModule):
+    """datamodule/distiller/sequence/recformer.py:28-180: the same sampling / splitting with pre-tokenised items (one attribute-id
+    map shared by all domains) and the Recformer collators."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.bos_token_id, self.pad_token_id = self.tokenizer.bos_token_id, self.tokenizer.pad_token_id
+        self._attr_name_id_map = _FirstSeenIds()
+        self.tokenized_items = self.item_texts  # filled by setup(): per domain, item id -> TokenizedItem
+
+    def _item_side(self, metadata):
+        tok = {i: tokenize_item(metadata[i], self.tokenizer, self._attr_name_id_map, self.max_attribute_len) for i in metadata}
+        return tok, RecformerSingleItemCollator(self.bos_token_id, self.pad_token_id, tok, self.max_seq_len)
+
+    def _distill_collator(self):
+        return RecformerDistillSequenceCollator(self.bos_token_id, self.pad_token_id, self.tokenized_items, self.max_seq_len)

@@ -123,3 +123,40 @@ def all_gather_vector(local: torch.Tensor, group=None) -> torch.Tensor:
         blocks.append((lo, lo + s))
         lo += s
     return all_gather_rows(local.reshape(-1, 1), blocks, group=group).reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel alpha training
+def allreduce_mean_grads(params, group=None) -> None:
+    """Data-parallel collaborative merging (BASELINE config 5: pseudo-user batches split over the GPUs of a node): every rank runs
+    the step on its own batch shard; the only exchange is the mean of d loss / d alpha -- a few dozen floats -- in ONE all-reduce
+    (RCCL on GPUs; staged through the host for the gloo rehearsal).  A no-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    if dist.get_backend(group) == "gloo" and flat.is_cuda:
+        host = flat.cpu()
+        dist.all_reduce(host, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.all_reduce(flat, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def shard_indices(n: int, rank: int, world: int, epoch_seed: int, shuffle: bool = True):
+    """The sample indices of one rank for one epoch: a seeded permutation shared by all ranks, padded by wrap-around to a multiple
+    of the world size and dealt round-robin (torch's DistributedSampler rule), so every rank sees the same number of batches."""
+    if shuffle:
+        g = torch.Generator().manual_seed(epoch_seed)
+        order = torch.randperm(n, generator=g).tolist()
+    else:
+        order = list(range(n))
+    total = (n + world - 1) // world * world
+    order = order + order[: total - n]
+    return order[rank:total:world]

@@ -11,6 +11,7 @@ import torch
 
 from .module.callbacks import ItemEncodingCallback
 from .module.recommender import RecModule
+from .parallel import allreduce_mean_grads, shard_indices
 
 
 def remove_duplicate_prefix(state_dict):
@@ -100,6 +101,19 @@ class DistillTrainer:
         self.global_step = 0
         self.history: List[float] = []
 
+    def _train_loader(self, datamodule):
+        """One rank: the datamodule's own shuffled loader.  Several ranks (torch.distributed initialised): the same dataset and
+        collator, the epoch's permutation dealt round-robin over the ranks."""
+        import torch.distributed as dist
+        from torch.utils.data import DataLoader, Subset
+
+        loader = datamodule.train_dataloader()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return loader
+        idx = shard_indices(len(loader.dataset), dist.get_rank(), dist.get_world_size(), 1234 + self.current_epoch)
+        return DataLoader(Subset(loader.dataset, idx), batch_size=loader.batch_size, collate_fn=loader.collate_fn, shuffle=False,
+                          num_workers=loader.num_workers)
+
     def _hook(self, name, *args):
         for cb in self.callbacks:
             if hasattr(cb, name):
@@ -109,14 +123,16 @@ class DistillTrainer:
         module.trainer = self
         datamodule.setup("fit")
         opt = module.configure_optimizers()
+        trainable = [p for grp in opt.param_groups for p in grp["params"]]
         done = False
         while not done:
             module.train()
             self._hook("on_train_epoch_start", module)
-            for batch_idx, batch in enumerate(datamodule.train_dataloader()):  # reload_dataloaders_every_n_epochs=1
+            for batch_idx, batch in enumerate(self._train_loader(datamodule)):  # reload_dataloaders_every_n_epochs=1
                 opt.zero_grad(set_to_none=True)
                 loss = module.training_step(batch.to(module.device), batch_idx)
                 loss.backward()
+                allreduce_mean_grads(trainable)  # data parallel: the only exchange of the step (no-op on one rank)
                 opt.step()
                 self.global_step += 1
                 self.history.append(float(loss.detach()))

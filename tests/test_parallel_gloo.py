@@ -97,3 +97,24 @@ def test_slice_plan_covers_everything():
             assert [p.bounds(r) for r in range(w)][-1][1] == p.padded
     assert row_blocks(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert row_blocks(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+def _dp_grad_job(rank, world_size):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mergerec_amd.parallel import allreduce_mean_grads, shard_indices
+
+    ps = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2, 2)), torch.nn.Parameter(torch.zeros(1))]
+    ps[0].grad = torch.full((3,), float(rank + 1))
+    ps[1].grad = torch.arange(4.0).view(2, 2) * (rank + 1)
+    allreduce_mean_grads(ps)  # ps[2] has no gradient: skipped
+    idx = shard_indices(11, rank, world_size, epoch_seed=7)
+    return ps[0].grad.tolist(), ps[1].grad.tolist(), ps[2].grad, idx
+
+
+def test_data_parallel_alpha_gradients_and_sharding():
+    out = _run(_dp_grad_job)
+    for g0, g1, g2, _ in out:
+        assert g0 == [1.5, 1.5, 1.5] and g1 == [[0.0, 1.5], [3.0, 4.5]] and g2 is None
+    a, b = out[0][3], out[1][3]
+    assert len(a) == len(b) == 6 and set(a) | set(b) == set(range(11))  # every sample seen, equal batch counts (one wrap-around)

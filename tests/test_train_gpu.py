@@ -250,3 +250,33 @@ def test_recformer_backward_matches_oracle_autograd():
             scale = max(float(v.grad.abs().max()), 1e-3 * gmax)
             err = float((got[k].cpu() - v.grad).abs().max()) / scale
             assert err <= 3e-3, (k, err, scale)
+
+
+def test_merge_train_cli_recformer(tmp_path):
+    """the optimisation loop on a Recformer-shaped model: pre-tokenised item sequences, Longformer attention backward, layer-wise alpha"""
+    import sys
+
+    root = __import__("pathlib").Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    import merge_train
+    from mergerec_amd.engine import EncoderSpec
+    from mergerec_amd.module import models
+    from tests.conftest import GOLDEN
+
+    old = models.RecformerBase.SPEC
+    models.RecformerBase.SPEC = staticmethod(lambda: EncoderSpec(kind="recformer", hidden=128, heads=2, layers=2, intermediate=256, vocab=50265, max_pos=1026,
+                                                                 token_type_size=4, max_item_embeddings=51, one_sided_window=32))
+    try:
+        res = merge_train.main([
+            "--model_type", "recformer_base", "--model_kwargs", "init_seed", "7", "--finetune_checkpoint_paths", "synthetic:1", "synthetic:2",
+            "--data_paths", str(GOLDEN / "mini_dataset"), str(GOLDEN / "mini_dataset"), "--tokenizer_path", str(GOLDEN / "mini_tokenizer"),
+            "--item_embeddings_paths", "auto", "--sequence_embeddings_paths", "auto", "--train_data_split", "item", "--test_data_split", "test",
+            "--merge_type", "ties", "--learn_type", "layer_wise", "--loss_type", "SINGLE_PSEUDO_LABEL_KD", "--coefficient", "1000",
+            "--learning_rate", "0.01", "--max_steps", "6", "--batch_size", "16", "--max_seq_len", "128", "--max_attribute_len", "10", "--max_items", "20",
+            "--weights_dir", str(tmp_path)])
+    finally:
+        models.RecformerBase.SPEC = staticmethod(old)
+    assert len(res["history"]) == 6 and all(h == h and abs(h) < 1e6 for h in res["history"])
+    per = res["weights"]["per_weights"]
+    assert set(per) >= {"others", "0", "1"} and any(abs(w - 0.2) > 1e-4 for ws in per.values() for w in ws), per
+    assert "test/dataset_0/test/NDCG@10" in res["test_metrics"]
