@@ -141,7 +141,7 @@ def main(argv=None):
         else:
             item_emb = torch.load(opt["item_embeddings_paths"][d], map_location="cpu")
             seq_emb = torch.load(opt["sequence_embeddings_paths"][d], map_location="cpu")
-        score_embeddings.append(teacher_scores(seq_emb.to("cuda:0", torch.float32), item_emb.to("cuda:0", torch.float32)))
+        score_embeddings.append(teacher_scores(seq_emb.to(model.device, torch.float32), item_emb.to(model.device, torch.float32)))
 
     merged_model = load_merging_module(
         merge_type=MergeType[config.merge_type], learn_type=LearnType[config.learn_type], model=model, pretrain_state_dict=pretrain,

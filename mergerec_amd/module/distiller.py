@@ -59,14 +59,14 @@ class _GroupLossFn(torch.autograd.Function):
 
 class DistillSequenceModule(nn.Module):
     def __init__(self, merged_model, score_embeddings: List[torch.Tensor], loss_fn: DistillLossBase, similarity: Literal["dot", "cosine"],
-                 learning_rate: float = 5e-5, trainable_args_kwargs: Optional[dict] = None, device: str = "cuda:0"):
+                 learning_rate: float = 5e-5, trainable_args_kwargs: Optional[dict] = None, device=None):
         super().__init__()
         self.merged_model = merged_model
         self.loss_fn = loss_fn
         self.similarity = similarity
         self.learning_rate = learning_rate
         self.trainable_args_kwargs = trainable_args_kwargs or {}
-        self.device = torch.device(device)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         # teacher matrices live in HBM (the reference keeps up to 18k x 18k fp32 per domain on the host and ships one row
         # per sample); 288 GB makes the gather a device-side row copy
         self.score_embeddings = [s.to(self.device, torch.float32).contiguous() for s in score_embeddings]
