@@ -16,7 +16,9 @@ DEV = "cuda:0"
 N, B, M = int(os.environ.get("TB_N", 8)), int(os.environ.get("TB_B", 16)), int(os.environ.get("TB_M", 22855))
 learn = os.environ.get("TB_LEARN", "TASK_WISE")
 torch.manual_seed(0)
-model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 7})
+MODEL = os.environ.get("TB_MODEL", "BLAIR_BASE")
+model = ModelType[MODEL].value(model_kwargs={"init_seed": 7})
+REC = MODEL.startswith("RECFORMER")
 pre = OrderedDict((k, v.cpu().clone()) for k, v in model.state_dict().items())
 fts = []
 for i in range(N):
@@ -25,7 +27,8 @@ for i in range(N):
 mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[learn], model, pre, fts, set(), disable_softmax=True, initial_per_weight=0.2)
 del fts
 g = torch.Generator().manual_seed(1)
-items = [torch.nn.functional.normalize(torch.randn(M, 768, generator=g), dim=-1) for _ in range(N)]
+D = model.spec.hidden
+items = [torch.nn.functional.normalize(torch.randn(M, D, generator=g), dim=-1) for _ in range(N)]
 teachers = [torch.randn(64, M, generator=g).clamp(-1, 1) for _ in range(N)]  # 64 teacher rows per domain are enough for the step
 mod = DistillSequenceModule(mm, teachers, SinglePseudoLabelKDLoss(0.05, 1000.0), "cosine",
                             trainable_args_kwargs={"freeze_global_weight": True, "freeze_global_bias": True})
@@ -39,8 +42,13 @@ for b in range(B):
     ids[b, :n] = torch.randint(4, 50000, (n,), generator=g)
     ids[b, 0] = 0
     mask[b, :n] = 1
-batch = BatchDistillationSequence(dataset_indexes=[b % N for b in range(B)], sequence_ids=torch.arange(B) % 64,
-                                  sequence={"input_ids": ids, "attention_mask": mask}).to(DEV)
+enc = {"input_ids": ids, "attention_mask": mask}
+if REC:  # key/value tokens of one item after <s>: types 1 (attribute name) / 2 (value), item position 1, global attention on <s>
+    tt = torch.where(mask.bool(), torch.full_like(ids, 2), torch.full_like(ids, 3)); tt[:, 0] = 0; tt[:, 1:4] = torch.where(mask[:, 1:4].bool(), 1, 3)
+    ip = mask.clone(); ip[:, 0] = 0
+    ga = torch.zeros_like(ids); ga[:, 0] = 1
+    enc.update(token_type_ids=tt, item_position_ids=ip, global_attention_mask=ga)
+batch = BatchDistillationSequence(dataset_indexes=[b % N for b in range(B)], sequence_ids=torch.arange(B) % 64, sequence=enc).to(DEV)
 opt = mod.configure_optimizers()
 mod.train()
 
@@ -63,11 +71,11 @@ for _ in range(K):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 1e3 / K
 P = mm.layout.numel
-print(f"{learn}: N={N} domains, B={B} sequences ({int(lens.sum())} tokens), P={P/1e6:.1f} M parameters, M={M}: {ms:.2f} ms/step "
+print(f"{MODEL} {learn}: N={N} domains, B={B} sequences ({int(lens.sum())} tokens), P={P/1e6:.1f} M parameters, M={M}: {ms:.2f} ms/step "
       f"({1e3/ms:.1f} steps/s, {B*1e3/ms:.0f} sequences/s); loss {loss.item():.4f}")
 print(f"  parameter-sized streams per step: merge fwd {(N+2)*P*4/1e9:.2f} GB + alpha-gradient {(N+1)*P*4/1e9:.2f} GB "
       f"-> {((2*N+3)*P*4/1e9)/(ms/1e3)/1e3:.2f} TB/s of the step if nothing else moved")
-if os.environ.get("TB_CPU", "0") == "1":
+if os.environ.get("TB_CPU", "0") == "1" and not REC:
     # the same step through the CPU oracle (merge + encoder + loss restatements) with torch autograd, 16 threads
     from oracle import ref_cpu as O
     torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
