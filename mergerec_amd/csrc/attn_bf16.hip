@@ -206,16 +206,21 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
             }
             // ---- mask + online softmax (base 2); s[r] is key kb + (r&3) + 8*(r>>2) + 4*lh for query q0 + lr
             float mx = -INFINITY;
+            if (!WINDOWED && kb + 32 <= len) {  // interior tile of full attention: every key valid, no masking work
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                bool ok = key < len;
-                if (WINDOWED) {
-                    const int dlt = qi - key;
-                    ok = ok && (key == 0 || (dlt <= window && dlt >= -window));
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    bool ok = key < len;
+                    if (WINDOWED) {
+                        const int dlt = qi - key;
+                        ok = ok && (key == 0 || (dlt <= window && dlt >= -window));
+                    }
+                    s[r] = ok ? s[r] : -INFINITY;
+                    mx = fmaxf(mx, s[r]);
                 }
-                s[r] = ok ? s[r] : -INFINITY;
-                mx = fmaxf(mx, s[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m, mx);
