@@ -108,6 +108,31 @@ def main():
     bs = list(dm.test_dataloader())
     g["test_batches"] = [dict(sequence=enc(b.sequence), labels=b.labels.clone()) for b in (bs[:2] + bs[-1:])]
     out["recformer"] = g
+    # ---- collaborative-merging data (merge_train.py): the reference's distill datamodules on two copies of the domain
+    from rec_retrieval.datamodule.distiller.sequence.datamodule import DistillSequenceDataModule
+    from rec_retrieval.datamodule.distiller.sequence.recformer import DistillSequenceDataModuleForRecformer
+    from rec_retrieval.datamodule.distiller.sequence.utils import sample_popular
+
+    n_items, n_users = 60, 40
+    for name, cls, split, n_seq, kw in (("distill_text_item", DistillSequenceDataModule, "item", n_items, dict(sequence_prompt="Seq: ")),
+                                        ("distill_text_test", DistillSequenceDataModule, "test", n_users, dict()),
+                                        ("distill_recformer_item", DistillSequenceDataModuleForRecformer, "item", n_items, dict()),
+                                        ("distill_recformer_val", DistillSequenceDataModuleForRecformer, "val", n_users, dict())):
+        torch.manual_seed(123)
+        dm = cls(dataset_paths=[ds_root, ds_root], tokenizer=tok, batch_size=8, max_seq_len=96, max_attribute_len=12, max_items=20,
+                 sequence_embeddings=[torch.zeros(n_seq, 4), torch.zeros(n_seq, 4)], train_data_split=split, valid_ratio=0.25,
+                 num_sequences_per_dataset=30, sample_method="random", **kw)
+        dm.setup("fit")
+        chained = dm.train_dataloader().dataset
+        samples = [chained[i] for i in range(len(chained))]
+        batches = [dm.distill_collator(samples[i:i + 8]) for i in (0, 8, len(samples) - 5)]
+        val = [b for dl in dm.val_dataloader() for b in list(dl)[:1]]
+        out[name] = dict(n_train=len(chained), samples=[(d, (int(sid), list(seq))) for d, (sid, seq) in samples],
+                         batches=[dict(dataset_indexes=list(b.dataset_indexes), sequence_ids=[int(x) for x in b.sequence_ids], sequence=enc(b.sequence)) for b in batches],
+                         val_first=[dict(dataset_indexes=list(b.dataset_indexes), sequence_ids=[int(x) for x in b.sequence_ids], sequence=enc(b.sequence)) for b in val],
+                         item_batch0=[enc(next(iter(dl)).items) for dl in dm.item_dataloaders])
+    test_seqs = [json.loads((ds_root / "test.json").read_text())[str(u)] for u in range(n_users)]
+    out["sample_popular"] = dict(sequences=test_seqs, top=sample_popular(test_seqs, 7))
     torch.save(out, OUT / "g8_datamodule.pt")
     print("wrote", OUT / "g8_datamodule.pt")
 
