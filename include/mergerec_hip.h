@@ -219,9 +219,11 @@ int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t
 /* Global-token row of Longformer attention: for each sequence b, ctx[cu[b], :] =
  * softmax(qg_b kg^T * scale) vg over all tokens of b, where qg is (B, H*dh) (the global query of
  * each sequence's first token) and kvg is (T, 2*H*dh) = [k_global | v_global] per token.
+ * compact != 0: ctx is (B, H*dh) and row b is written instead.  The same kernel serves the LAST layer of both encoder kinds (only
+ * [:, 0] is pooled, encoder/_base.py:45): qg = the query projection of the CLS rows, kvg = [k | v] of all tokens.
  * replaces: LongformerSelfAttention._compute_global_attn_output_from_hidden. */
-int mr_attn_global_row_f32(const float* qg, const float* kvg, const int32_t* cu_seqlens, int B, int H, int dh,
-                           int max_len, float scale, float* ctx, mr_stream_t stream);
+int mr_attn_global_row_f32(const float* qg, const float* kvg, const int32_t* cu_seqlens, int B, int H, int dh, int max_len, float scale,
+                           float* ctx, int compact, mr_stream_t stream);
 
 /* out[b,:] = x[cu_seqlens[b], :]  (CLS pooling), then if normalize: out / max(||out||_2, 1e-12).
  * replaces: module/models/encoder/_base.py:44-45 (pool 'cls') + module/recommender/module.py:74-77. */

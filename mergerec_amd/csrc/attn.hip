@@ -180,18 +180,19 @@ __global__ __launch_bounds__(kThreads, 4) void attn_kernel(const float* __restri
 }
 
 // Longformer global row: one wave per (sequence, head); scores staged in LDS.
-__global__ __launch_bounds__(MR_WAVE) void attn_global_row_kernel(const float* __restrict__ qg,
-                                                                 const float* __restrict__ kvg,
+// kbase / vbase: column 0 of head 0 of the keys / values, row stride ld (kvg layout: vbase = kbase + H * 64, ld = 2 H 64; packed qkv:
+// kbase = qkv + H * 64, vbase = qkv + 2 H * 64, ld = 3 H 64).  compact: write row b of a (B, H 64) matrix instead of row cu[b] of ctx.
+__global__ __launch_bounds__(MR_WAVE) void attn_global_row_kernel(const float* __restrict__ qg, const float* __restrict__ kbase,
+                                                                 const float* __restrict__ vbase, int64_t ld,
                                                                  const int32_t* __restrict__ cu, int H, float scale,
-                                                                 float* __restrict__ ctx) {
+                                                                 float* __restrict__ ctx, int compact) {
     extern __shared__ __attribute__((aligned(16))) float sc[];
     const int b = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
     const int t0 = cu[b], len = cu[b + 1] - t0;
     if (len <= 0) return;
-    const int64_t ld = (int64_t)2 * H * kDh;
     const float* __restrict__ q = qg + (int64_t)b * H * kDh + h * kDh;
-    const float* __restrict__ Kg = kvg + (int64_t)t0 * ld + h * kDh;
-    const float* __restrict__ Vg = Kg + H * kDh;
+    const float* __restrict__ Kg = kbase + (int64_t)t0 * ld + h * kDh;
+    const float* __restrict__ Vg = vbase + (int64_t)t0 * ld + h * kDh;
     float qreg[kDh];
 #pragma unroll
     for (int d = 0; d < kDh; ++d) qreg[d] = q[d] * scale;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(MR_WAVE) void attn_global_row_kernel(const float* _
     __syncthreads();
     float out = 0.f;
     for (int j = 0; j < len; ++j) out = fmaf(sc[j], Vg[(int64_t)j * ld + lane], out);
-    ctx[(int64_t)t0 * ((int64_t)H * kDh) + h * kDh + lane] = out / sum;
+    ctx[(int64_t)(compact ? b : t0) * ((int64_t)H * kDh) + h * kDh + lane] = out / sum;
 }
 
 }  // namespace
@@ -242,13 +243,14 @@ extern "C" int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, const in
 }
 
 extern "C" int mr_attn_global_row_f32(const float* qg, const float* kvg, const int32_t* cu_seqlens, int B, int H, int dh,
-                                      int max_len, float scale, float* ctx, mr_stream_t stream) {
+                                      int max_len, float scale, float* ctx, int compact, mr_stream_t stream) {
     if (!qg || !kvg || !cu_seqlens || !ctx || B < 0 || H < 1 || max_len < 0) return MR_EINVAL;
     if (dh != kDh) return MR_EUNSUPPORTED;
     if (max_len > 16384) return MR_EUNSUPPORTED;  // scores of one row live in LDS
     if (!mr::aligned16(qg) || !mr::aligned16(kvg)) return MR_EALIGN;
     if (B == 0 || max_len == 0) return MR_OK;
     const size_t shm = ((size_t)max_len * sizeof(float) + 15) & ~(size_t)15;
-    hipLaunchKernelGGL(attn_global_row_kernel, dim3(H, B), dim3(MR_WAVE), shm, (hipStream_t)stream, qg, kvg, cu_seqlens, H, scale, ctx);
+    hipLaunchKernelGGL(attn_global_row_kernel, dim3(H, B), dim3(MR_WAVE), shm, (hipStream_t)stream, qg, kvg, kvg + H * kDh, (int64_t)2 * H * kDh,
+                       cu_seqlens, H, scale, ctx, compact);
     return mr::check_launch();
 }

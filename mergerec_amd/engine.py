@@ -344,20 +344,30 @@ class EncoderRunner:
         """One post-LN transformer block.  cls_only: after attention keep only each sequence's first row
         (a13: the last layer's output is read at [:, 0] only, encoder/_base.py:45)."""
         sp, lp = self.spec, f"{self.prefix}encoder.layer.{l}."
-        qkv = self._proj(w, lp, ("query", "key", "value"), x)
-        if ops.PROF.enabled:
-            w_ = sp.one_sided_window
-            ops.ATTN_FLOPS_HINT[0] = 4.0 * sp.hidden * (pb.sum_len_sq if sp.kind != "recformer" else pb.T * (2 * w_ + 2))
-        ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=sp.one_sided_window if sp.kind == "recformer" else -1,
-                            seq_order=pb.seq_order, products={"f32": 0, "bf16x6": 6, "bf16x3": 3}[w.mode])
-        if sp.kind == "recformer":
-            x_cls = ops.gather_rows(x, pb.cls_rows)
-            qg = self._proj(w, lp, ("query_global",), x_cls)
-            kvg = self._proj(w, lp, ("key_global", "value_global"), x)
-            ops.attention_global_row(qg, kvg, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx)
+        rec = sp.kind == "recformer"
         if cls_only:
-            ctx = ops.gather_rows(ctx, pb.cls_rows)
-            x = ops.gather_rows(x, pb.cls_rows)
+            # a13: only the first row of every sequence is read after this layer, so attention runs for those B queries alone: the
+            # query projection on the CLS rows, key / value projections on all tokens, one exact-fp32 attention row per (sequence, head).
+            # RoBERTa uses its query / key / value weights; Longformer's CLS row is the global row (*_global weights) and its windowed
+            # rows are not needed at all.
+            names = ("query_global", "key_global", "value_global") if rec else ("query", "key", "value")
+            x_cls = ops.gather_rows(x, pb.cls_rows)
+            q = self._proj(w, lp, names[:1], x_cls)
+            kv = self._proj(w, lp, names[1:], x)
+            ctx = torch.empty(pb.B, sp.hidden, dtype=torch.float32, device=x.device)
+            ops.attention_global_row(q, kv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx, compact=True)
+            x = x_cls
+        else:
+            qkv = self._proj(w, lp, ("query", "key", "value"), x)
+            if ops.PROF.enabled:
+                w_ = sp.one_sided_window
+                ops.ATTN_FLOPS_HINT[0] = 4.0 * sp.hidden * (pb.sum_len_sq if not rec else pb.T * (2 * w_ + 2))
+            ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=sp.one_sided_window if rec else -1,
+                                seq_order=pb.seq_order, products={"f32": 0, "bf16x6": 6, "bf16x3": 3}[w.mode])
+            if rec:
+                qg = self._proj(w, lp, ("query_global",), ops.gather_rows(x, pb.cls_rows))
+                kvg = self._proj(w, lp, ("key_global", "value_global"), x)
+                ops.attention_global_row(qg, kvg, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx)
         h = self._linear(w, ctx, [lp + "attention.output.dense.weight"], [lp + "attention.output.dense.bias"], residual=x)
         h = ops.layernorm(h, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps, out=h)
         i = self._linear(w, h, [lp + "intermediate.dense.weight"], [lp + "intermediate.dense.bias"], act=ops.ACT_GELU)

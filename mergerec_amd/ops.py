@@ -354,9 +354,12 @@ def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_l
     return out
 
 
-def attention_global_row(qg: torch.Tensor, kvg: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, ctx: torch.Tensor):
+def attention_global_row(qg: torch.Tensor, kvg: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, ctx: torch.Tensor,
+                         compact: bool = False):
+    """Longformer global row into ctx[cu[b]] (ctx (T, d)) or, compact, into row b of a (B, d) matrix."""
     dh = qg.shape[1] // H
-    check(_lib.load().mr_attn_global_row_f32(ptr(qg), ptr(kvg), ptr(cu_seqlens), B, H, dh, max_len, dh ** -0.5, ptr(ctx), _stream(qg)), "mr_attn_global_row_f32")
+    check(_lib.load().mr_attn_global_row_f32(ptr(qg), ptr(kvg), ptr(cu_seqlens), B, H, dh, max_len, dh ** -0.5, ptr(ctx), int(compact), _stream(qg)),
+          "mr_attn_global_row_f32")
     return ctx
 
 
