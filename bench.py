@@ -101,7 +101,7 @@ def main():
             dist.init_process_group(backend)
 
     from mergerec_amd import ops, parallel
-    from mergerec_amd.engine import ArenaLayout, EncoderRunner, EncoderSpec, WeightSet, default_gemm_mode
+    from mergerec_amd.engine import ArenaLayout, EncoderRunner, EncoderSpec, WeightSet
     from mergerec_amd.synthetic import blair_item_lengths, blair_sequence_lengths, _ids_from_lengths
 
     spec = EncoderSpec.blair_base()

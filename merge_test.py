@@ -94,7 +94,6 @@ def main(argv=None):
     from mergerec_amd.evaluator import Evaluator
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
     from mergerec_amd.module import ModelType, RecModule
-    from mergerec_amd.module.models import random_init_state_dict
     from mergerec_amd.utils import load_alpha_file, remove_duplicate_prefix, test_model
 
     torch.manual_seed(config.seed)

@@ -12,7 +12,7 @@ Recformer: the band + global-key attention backward is the same pair of kernels 
 (query_global / key_global / value_global projections) has its own one-query backward kernel; four embedding tables."""
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Optional
 
 import torch
 
