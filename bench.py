@@ -225,15 +225,16 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
         # (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950; tools/pmc_summary.py) -- PMC cannot be
         # collected from inside the timed run.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_raw = None, None, None
         tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{gemm_mode}.json")
         if world == 1 and os.path.exists(tpath):
             t = json.load(open(tpath)).get("gemm_nt_bf16x" if dom[0].startswith("gemm_nt_bf16x") else dom[0])
             if t:
                 traffic = t["fetch_bytes_x2_per_launch"] + t["write_bytes_per_launch"]
+                traffic_raw = t["fetch_bytes_raw_per_launch"] + t["write_bytes_per_launch"]  # uncorrected FETCH_SIZE: exact if 64-B row fragments are tallied exactly
                 traffic_src = f"profiles/r01_pmc_traffic_{gemm_mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
         roofline = dict(kernel=dom[0], **{k: dom[1][k] for k in ("mfma_flops_per_algorithmic_flop", "mfma_utilization") if k in dom[1]}, bound=dom[1]["bound"], achieved=dom[1]["achieved"], peak=dom[1]["peak"], unit=dom[1]["unit"],
-                        frac=dom[1]["frac"], traffic=traffic, traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
+                        frac=dom[1]["frac"], traffic=traffic, traffic_uncorrected=traffic_raw, traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=ops.PROF.summary()[dom[0]]["bytes"] / max(dom[1]["launches"], 1),
                         launches=dom[1]["launches"], avg_launch_ms=dom[1]["avg_ms"])
 
