@@ -467,3 +467,17 @@ def test_load_merging_module_pcb():
     want = O.pcb_vectors(base, [O.flatten_model(f)[0] for f in al], 0.2)
     got = mm.compact_task_vectors().cpu()
     assert torch.allclose(got, want, rtol=2e-4, atol=1e-9), (got - want).abs().max()
+
+
+@pytest.mark.parametrize("kind", ["blair_large", "recformer_large"])
+def test_large_configs_match_oracle(kind):
+    """24 x 1024, 16 heads (BLAIR_LARGE / RECFORMER_LARGE, BASELINE config 5's encoder): every GEMM mode against the CPU oracle"""
+    import sys
+
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tools"))
+    import large_models_check as L
+    from mergerec_amd.engine import EncoderSpec
+
+    res = L.check(kind, getattr(EncoderSpec, kind)(), verbose=False)
+    assert res["f32"][0] <= 5e-6 and res["bf16x6"][0] <= 5e-6 and res["bf16x3"][0] <= 5e-5, res
+    assert all(v[1] <= 1e-4 for v in res.values()), res  # the path's contract: cosine logits within 1e-4
