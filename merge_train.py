@@ -91,7 +91,7 @@ def main(argv=None):
     from mergerec_amd.merger import LearnType, LossType, MergeType, load_merging_module
     from mergerec_amd.module import (DistillSequenceModule, ModelType, MultiDatasetItemEncodingCallback, RecModule, SaveWeightsCallback,
                                      distill_loss_factory, teacher_scores)
-    from mergerec_amd.module.callbacks import ItemEncoderMixin
+    from mergerec_amd.module.callbacks import ItemEncoderMixin, WeightCheckpointCallback
     from mergerec_amd.utils import DistillTrainer, remove_duplicate_prefix, test_model_from_paths
 
     torch.manual_seed(config.seed)
@@ -171,9 +171,15 @@ def main(argv=None):
     if rank == 0:  # alpha is identical on every rank (same initial value, averaged gradients): one writer
         save_cb = SaveWeightsCallback(save_dir=opt["weights_dir"], log_every_steps=len(config.data_paths))
         callbacks.insert(0, save_cb)
+    weights_checkpoint = None
+    if opt["valid_ratio"] is not None:  # merge_train.py:172-175
+        weights_checkpoint = WeightCheckpointCallback(monitor=r"val/loss_epoch/dataloader_idx_\d+")
+        callbacks.append(weights_checkpoint)
     trainer = DistillTrainer(max_epochs=opt["max_epochs"], max_steps=opt["max_steps"], precision=config.precision, callbacks=callbacks,
                              verbose=rank == 0)
     history = trainer.fit(module, datamodule)
+    if weights_checkpoint is not None:
+        weights_checkpoint.load_weights(module)  # the best alpha on the held-out pseudo users
     result = dict(history=history, weights=merged_model.serialize_weights(), weights_file=str(save_cb.save_file) if save_cb else None,
                   rank=rank, world_size=world)
     if rank == 0:

@@ -1,6 +1,7 @@
 """Mirror of rec_retrieval/module/callbacks.py:18-64 (ItemEncoderMixin, ItemEncodingCallback) and :139-174 (SaveWeightsCallback)."""
 from __future__ import annotations
 
+import re
 from pathlib import Path
 from uuid import uuid4
 
@@ -97,3 +98,30 @@ class SaveWeightsCallback:
         if self._file_handler:
             self._file_handler.close()
             self._file_handler = None
+
+
+class WeightCheckpointCallback:
+    """callbacks.py:177-206: keeps the alpha with the lowest mean of the monitored validation metrics (regex over
+    ``trainer.callback_metrics``; merge_train.py monitors ``val/loss_epoch/dataloader_idx_\\d+``) and restores it after training."""
+
+    def __init__(self, monitor: str = "val/loss"):
+        self.monitor = monitor
+        self.best_score = float("inf")
+        self.best_weights = None
+
+    def on_validation_epoch_end(self, trainer, pl_module):
+        scores = [float(v) for k, v in trainer.callback_metrics.items() if re.fullmatch(self.monitor, k)]
+        if len(scores) == 0:
+            raise RuntimeError(f"No metrics found matching the monitor pattern: {self.monitor}")
+        current = sum(scores) / len(scores)
+        if current < self.best_score:
+            print(f"New best score: {current}. Saving weights.")
+            self.best_score = current
+            self.best_weights = pl_module.merged_model.serialize_weights()
+
+    def load_weights(self, pl_module):
+        if self.best_weights is not None:
+            pl_module.merged_model.load_weights_from_dict(self.best_weights)
+            print("Weights loaded from the best checkpoint.")
+        else:
+            print("No best weights found. Skipping loading.")

@@ -100,6 +100,7 @@ class DistillTrainer:
         self.current_epoch = 0
         self.global_step = 0
         self.history: List[float] = []
+        self.callback_metrics: Dict[str, torch.Tensor] = {}
 
     def _train_loader(self, datamodule):
         """One rank: the datamodule's own shuffled loader.  Several ranks (torch.distributed initialised): the same dataset and
@@ -148,9 +149,15 @@ class DistillTrainer:
                 module.eval()
                 module.on_validation_epoch_start()
                 for di, dl in enumerate(vals):
+                    tot, cnt = 0.0, 0
                     for bi, batch in enumerate(dl):
-                        module.validation_step(batch.to(module.device), bi, di)
+                        n = len(batch.dataset_indexes)
+                        tot += float(module.validation_step(batch.to(module.device), bi, di)) * n
+                        cnt += n
+                    # Lightning's on_epoch aggregation of self.log("val/loss", ...): batch-size-weighted mean per dataloader
+                    self.callback_metrics[f"val/loss_epoch/dataloader_idx_{di}"] = torch.tensor(tot / max(cnt, 1))
                 module.on_validation_epoch_end()
+                self._hook("on_validation_epoch_end", module)
             self.current_epoch += 1
             if self.max_epochs is not None and self.current_epoch >= self.max_epochs:
                 done = True

@@ -272,11 +272,12 @@ def test_merge_train_cli_recformer(tmp_path):
             "--data_paths", str(GOLDEN / "mini_dataset"), str(GOLDEN / "mini_dataset"), "--tokenizer_path", str(GOLDEN / "mini_tokenizer"),
             "--item_embeddings_paths", "auto", "--sequence_embeddings_paths", "auto", "--train_data_split", "item", "--test_data_split", "test",
             "--merge_type", "ties", "--learn_type", "layer_wise", "--loss_type", "SINGLE_PSEUDO_LABEL_KD", "--coefficient", "1000",
-            "--learning_rate", "0.01", "--max_steps", "6", "--batch_size", "16", "--max_seq_len", "128", "--max_attribute_len", "10", "--max_items", "20",
-            "--weights_dir", str(tmp_path)])
+            "--learning_rate", "0.01", "--max_epochs", "2", "--valid_ratio", "0.25", "--batch_size", "16", "--max_seq_len", "128",
+            "--max_attribute_len", "10", "--max_items", "20", "--weights_dir", str(tmp_path)])
     finally:
         models.RecformerBase.SPEC = staticmethod(old)
-    assert len(res["history"]) == 6 and all(h == h and abs(h) < 1e6 for h in res["history"])
+    # 2 domains x 60 items, 25 % held out -> 90 training pseudo users -> 6 steps per epoch; validation after every epoch picks the alpha
+    assert len(res["history"]) == 12 and all(h == h and abs(h) < 1e6 for h in res["history"])
     per = res["weights"]["per_weights"]
     assert set(per) >= {"others", "0", "1"} and any(abs(w - 0.2) > 1e-4 for ws in per.values() for w in ws), per
     assert "test/dataset_0/test/NDCG@10" in res["test_metrics"]
