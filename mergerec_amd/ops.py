@@ -465,7 +465,8 @@ def _pad16(n: int) -> int:
 def gemm_nt_train(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """A @ W.T (+ bias) (+ residual) for the training graph: split-K when the output has too few tiles to fill the chip."""
-    _dev(A, "A", torch.float32), _dev(W, "W", torch.float32)
+    if not (A.is_cuda and W.is_cuda and A.dtype == torch.float32 and W.dtype == torch.float32):
+        raise ValueError("A and W must be fp32 GPU tensors (the HIP path has no CPU fallback)")
     M, K = A.shape
     N = W.shape[0]
     if W.shape[1] != K or not W.is_contiguous() or A.stride(1) != 1:

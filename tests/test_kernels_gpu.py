@@ -344,3 +344,16 @@ def test_score_topk_full_catalog(ops, nU, M):
     assert O.ranks_equal_up_to_ties(ref, idx.cpu(), oi, atol=2e-6)
     loss = float((lse - lab).mean())
     assert abs(loss - O.ce_loss(ref, labels, 0.05)) < 1e-3
+
+
+@pytest.mark.parametrize("tool,env", [("gemm_fuzz.py", {"FZ_N": "25", "FZ_SEED": "3"}), ("attn_fuzz.py", {"FZ_N": "12", "FZ_SEED": "3"})])
+def test_randomised_differential_fuzz(tool, env):
+    """tools/gemm_fuzz.py / tools/attn_fuzz.py: random shapes, strides, epilogues, ragged lengths and windows against float64 torch"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / tool)], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
