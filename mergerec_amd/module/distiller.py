@@ -116,13 +116,20 @@ class DistillSequenceModule(nn.Module):
         B = representations.shape[0]
         ds = torch.as_tensor(list(dataset_indexes), dtype=torch.int64)
         sid = sequence_ids.detach().to("cpu", torch.int64) if isinstance(sequence_ids, torch.Tensor) else torch.as_tensor(list(sequence_ids), dtype=torch.int64)
-        total = None
-        for d_i in sorted(set(ds.tolist())):
-            sel = (ds == d_i).nonzero(as_tuple=True)[0]
-            reps_g = representations.index_select(0, sel.to(representations.device))
-            rows = ops.gather_rows(self.score_embeddings[d_i], sid[sel].to(torch.int32).to(self.device))
-            part = _GroupLossFn.apply(reps_g, self._items[d_i], self._items_t[d_i], rows, self.loss_fn, B)
+        # group the batch by dataset on the host, ship ONE index tensor (row permutation | teacher row ids) to the device
+        perm = torch.argsort(ds, stable=True)
+        counts = torch.bincount(ds, minlength=len(self._items)).tolist()
+        idx_dev = torch.cat([perm, sid[perm]]).to(torch.int32).to(self.device, non_blocking=True)
+        perm_dev, sid_dev = idx_dev[:B], idx_dev[B:]
+        reps_sorted = representations.index_select(0, perm_dev.long())
+        total, off = None, 0
+        for d_i, n in enumerate(counts):
+            if n == 0:
+                continue
+            rows = ops.gather_rows(self.score_embeddings[d_i], sid_dev[off:off + n])
+            part = _GroupLossFn.apply(reps_sorted[off:off + n], self._items[d_i], self._items_t[d_i], rows, self.loss_fn, B)
             total = part if total is None else total + part
+            off += n
         return total
 
     def _forward_distill(self, batch: BatchDistillationSequence):
