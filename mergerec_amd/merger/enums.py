@@ -1,28 +1,17 @@
-"""Mirror of rec_retrieval/merger/enums.py:11-40 (names and values are the drop-in boundary)."""
+"""The three option enums of rec_retrieval/merger/enums.py:11-40.  Member names and values (value == name) are part of the drop-in
+boundary: scripts select them by ``MergeType[flag.upper()]`` and weight files / configs spell them out."""
 from enum import Enum
 
 __all__ = ["MergeType", "LearnType", "LossType"]
 
 
-class MergeType(Enum):
-    TASK_VECTOR = "TASK_VECTOR"
-    TIES = "TIES"
-    PCB = "PCB"
-    LOCALIZE_AND_STITCH = "LOCALIZE_AND_STITCH"
+def _named(cls_name: str, members: str) -> Enum:
+    return Enum(cls_name, {m: m for m in members.split()}, module=__name__)
 
 
-class LearnType(Enum):
-    TASK_WISE = "TASK_WISE"
-    LAYER_WISE = "LAYER_WISE"
-
-
-class LossType(Enum):
-    CE = "CE"
-    KD = "KD"
-    MSE = "MSE"
-    ADAMERGING = "ADAMERGING"
-    ADAMERGING_KD = "ADAMERGING_KD"
-    MERGED_PSEUDO_LABEL = "MERGED_PSEUDO_LABEL"
-    SINGLE_PSEUDO_LABEL = "SINGLE_PSEUDO_LABEL"
-    MERGED_PSEUDO_LABEL_KD = "MERGED_PSEUDO_LABEL_KD"
-    SINGLE_PSEUDO_LABEL_KD = "SINGLE_PSEUDO_LABEL_KD"
+MergeType = _named("MergeType", "TASK_VECTOR TIES PCB LOCALIZE_AND_STITCH")
+LearnType = _named("LearnType", "TASK_WISE LAYER_WISE")
+LossType = _named(
+    "LossType",
+    "CE KD MSE ADAMERGING ADAMERGING_KD MERGED_PSEUDO_LABEL SINGLE_PSEUDO_LABEL MERGED_PSEUDO_LABEL_KD SINGLE_PSEUDO_LABEL_KD",
+)
