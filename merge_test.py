@@ -2,7 +2,7 @@
 """Drop-in for the reference's merge_test.py (merge_test.py:16-110) on MI355X: same flag names (TestMergeConfig,
 configs/base.py:22-108, configs/test.py:34-43), argparse instead of tyro.  Flags of subsystems outside the path
 (--lora.*) are accepted and ignored with a note; --data_paths may be dataset directories in the reference's JSON format
-(then --tokenizer_path must be a local tokenizer directory) or the pre-tokenised / synthetic specs of mergerec_amd/data.py; --precision must be 32-true (parity configuration).
+(then --tokenizer_path must be a local tokenizer directory) or the pre-tokenised / synthetic specs of mergerec_amd/data.py; --precision 32-true keeps the model's arithmetic (default bf16x6, fp32-grade); bf16-mixed (the reference's default) selects bf16x3.
 
 Example (synthetic weights + data, 2-domain merge):
   python merge_test.py --model_type BLAIR_BASE --model_kwargs init_seed 7 \

@@ -110,6 +110,18 @@ class BaseEncoderModel(nn.Module):
         self._weights = WeightSet(layout, flat, self.gemm_mode)
         self._views = self._weights.views
 
+    def set_gemm_mode(self, mode: Optional[str]):
+        """Switch the encoder GEMM / attention arithmetic ("f32", "bf16x6", "bf16x3"; None keeps the current one)."""
+        if mode is None or mode == self._weights.mode:
+            return
+        from ..engine import GEMM_MODES
+
+        if mode not in GEMM_MODES:
+            raise ValueError(f"gemm mode must be one of {GEMM_MODES}")
+        self.gemm_mode = mode
+        self._weights.mode = mode
+        self._weights.refresh()
+
     def weights_updated(self):
         """The bound arena was rewritten in place (a merge): re-derive the bf16 pieces the GEMMs read."""
         self._weights.refresh()

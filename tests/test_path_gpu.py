@@ -291,6 +291,26 @@ def test_merge_test_cli_json_dataset_with_local_tokenizer(tmp_path):
     assert users.shape == (40, 128) and torch.allclose(users.norm(dim=-1), torch.ones(40), atol=1e-5)
 
 
+def test_precision_flag_selects_arithmetic():
+    """Lightning precision strings: 32-true keeps the model's mode, the reference's default bf16-mixed runs bf16x3, junk raises"""
+    from mergerec_amd.module import RecModule
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.data import load_domain
+    from mergerec_amd.utils import Trainer, precision_to_gemm_mode, test_model
+
+    assert precision_to_gemm_mode("32-true") is None and precision_to_gemm_mode("bf16-mixed") == "bf16x3"
+    with pytest.raises(ValueError):
+        precision_to_gemm_mode("int4")
+    model = _tiny_model(dict(hidden=128, heads=2, layers=2, intermediate=256, vocab=1000, max_pos=514))
+    dom = load_domain("synthetic:Tiny:120:40", vocab=1000)
+    mod = RecModule(model=model, evaluator=Evaluator(metrics=["NDCG", "RECALL"], ks=[10]), negative_sample=None, similarity="cosine")
+    _, m32, _, _ = test_model(mod, [dom.item_dataloader(16)], [dom.sequence_dataloader(16)], ["Tiny"], precision="32-true")
+    assert model._weights.mode == "bf16x6"
+    _, m16, _, _ = test_model(mod, [dom.item_dataloader(16)], [dom.sequence_dataloader(16)], ["Tiny"], precision="bf16-mixed")
+    assert model._weights.mode == "bf16x3"
+    assert abs(m32[0]["test/loss"] - m16[0]["test/loss"]) < 1e-3 and m32[0].keys() == m16[0].keys()
+
+
 def test_extract_and_finetune_test_single_model(tmp_path):
     """Lightning-style checkpoint -> scripts/extract.py -> finetune_test.py (single-model path): state_dict.pt keys are
     ``model.model.*`` + ``item_embeddings``; the CLI must load it (prefix stripped, item_embeddings dropped) and evaluate"""
