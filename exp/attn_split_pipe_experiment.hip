@@ -1,0 +1,522 @@
+// K4': the attention kernel of attn.hip with both products (S^T = K Q^T and O^T = V^T P^T) evaluated in split precision
+// on the bf16 matrix cores (see gemm_bf16.hip): every fp32 operand is NP bf16 pieces (NP = 2: three products, NP = 3: six),
+// products accumulate in fp32.  Per 32-query x 32-key tile that is 24 (48) v_mfma_f32_32x32x16_bf16 = 768 (1536) matrix-pipe
+// cycles instead of 64 x 64 = 4096 for the fp32 MFMA kernel.
+//
+// Same decomposition as attn.hip: workgroup = 4 waves = 128 queries of one (sequence, head); K/V tiles of 32 keys go through
+// double-buffered LDS with the next tile's loads in flight under the current tile's math; scores are computed transposed so P
+// stays in registers as the B operand of the second product.  Differences:
+//   * K is split into its pieces while it is staged; LDS image per piece = [32 keys][64 bf16] (128-B rows), the eight 16-B
+//     chunks of a row XOR-swizzled by (row >> 1) & 7, so the ds_read_b128 of 16 keys is conflict-free.
+//   * Q is split once per wave into registers; P is split in registers after the softmax (register r = 8 s + j of the score
+//     accumulator is exactly element j of k-step s of the B operand).
+//   * V is split while it is staged, too: LDS image per piece = [32 keys][64 bf16] row-major (coalesced 8-byte stores), and
+//     the A operand of O^T = V^T P^T (k = key, so column-wise through that image) comes from gfx950's transposed LDS read
+//     ds_read_b64_tr_b16: a 16-lane group fetches a 4-key x 16-d block and lane i receives column i.  The 16-B chunks of a
+//     row are XOR-swizzled by 4 * ((row >> 1) & 1), which makes the 4 rows x 64 B of a 32-lane half hit all 64 banks once.
+//     (Splitting V in registers per wave, as before, cost more VALU time than both MFMA products together.)
+#include "common.h"
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kDh = 64;
+constexpr int KROWB = 128;           // bytes per K piece row (64 bf16)
+constexpr int KPIECE = 32 * KROWB;   // 4 KB per piece per tile
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// 8 fp32 -> NP pieces of 8 bf16 (4 dwords each); piece 0 = hi
+template <int NP>
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[NP]) {
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = x[i];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w = pack2(r[2 * j], r[2 * j + 1]);
+            out[p][j] = w;
+            if (p + 1 < NP) {
+                r[2 * j] -= lo_f(w);
+                r[2 * j + 1] -= hi_f(w);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
+    union { u32x4 u; bf16x8 b; } c;
+    c.u = v;
+    return c.b;
+}
+
+// acc += sum over the product set of piece pairs: NP = 2 -> (lo,hi) (hi,lo) (hi,hi); NP = 3 -> + (lo2,hi) (hi,lo2) (mid,mid)
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[NP], const u32x4 (&b)[NP], f32x16 c) {
+    if (NP == 3) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[2]), as_bf16x8(b[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[0]), as_bf16x8(b[2]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[1]), as_bf16x8(b[1]), c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[1]), as_bf16x8(b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[0]), as_bf16x8(b[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[0]), as_bf16x8(b[0]), c, 0, 0, 0);
+    return c;
+}
+
+template <bool WINDOWED, int NP>
+__global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel(const float* __restrict__ qkv,
+                                                                const int32_t* __restrict__ cu,
+                                                                const int32_t* __restrict__ seq_order, int H,
+                                                                float scale_log2e, int window, float* __restrict__ ctx) {
+    constexpr int BUFB = 2 * NP * KPIECE;  // K pieces, then V pieces
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUFB
+    const int b = seq_order ? seq_order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int t0 = cu[b], len = cu[b + 1] - t0;
+    const int q_base = blockIdx.x * 128;
+    if (q_base >= len) return;  // the whole workgroup leaves together, before any barrier
+    const int64_t ld = (int64_t)3 * H * kDh;
+    const float* __restrict__ Qb = qkv + (int64_t)t0 * ld + h * kDh;
+    const float* __restrict__ Kb = Qb + H * kDh;
+    const float* __restrict__ Vb = Qb + 2 * H * kDh;
+
+    const int q0 = q_base + wave * 32;
+    const bool wave_active = q0 < len;  // wave-uniform
+    const int qi = q0 + lr;
+
+    // Q pieces as the B operand of S^T = K Q^T: k-step s covers d = 16 s + 8 lh + j; pre-scaled by scale * log2(e)
+    u32x4 qp[4][NP];
+    {
+        const int qrow = qi < len ? qi : len - 1;
+        const float* qr = Qb + (int64_t)qrow * ld + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 x0 = *reinterpret_cast<const float4*>(qr + 16 * s);
+            const float4 x1 = *reinterpret_cast<const float4*>(qr + 16 * s + 4);
+            const float x[8] = {x0.x * scale_log2e, x0.y * scale_log2e, x0.z * scale_log2e, x0.w * scale_log2e,
+                                x1.x * scale_log2e, x1.y * scale_log2e, x1.z * scale_log2e, x1.w * scale_log2e};
+            split8<NP>(x, qp[s]);
+        }
+    }
+
+    // key-tile schedule of the workgroup (as attn.hip)
+    int k_lo = 0, k_hi = len;
+    if (WINDOWED) {
+        k_lo = q_base - window;
+        k_lo = k_lo < 0 ? 0 : (k_lo & ~31);
+        k_hi = q_base + 127 + window + 1;
+        k_hi = k_hi > len ? len : k_hi;
+    }
+    const bool extra0 = WINDOWED && k_lo > 0;
+    const int ntiles = (k_hi - k_lo + 31) / 32 + (extra0 ? 1 : 0);
+    auto tile_base = [&](int it) { return extra0 ? (it == 0 ? 0 : k_lo + (it - 1) * 32) : k_lo + it * 32; };
+
+    // staging map: thread -> (row sr / sr + 16, 4 consecutive d at sc)
+    const int sr = tid >> 4, sc4 = tid & 15, sc = sc4 * 4;
+    float4 kreg0, kreg1, vreg0, vreg1;
+    auto gload = [&](int kb) {
+        int r0 = kb + sr, r1 = kb + sr + 16;
+        r0 = r0 < len ? r0 : len - 1;
+        r1 = r1 < len ? r1 : len - 1;
+        kreg0 = *reinterpret_cast<const float4*>(Kb + (int64_t)r0 * ld + sc);
+        kreg1 = *reinterpret_cast<const float4*>(Kb + (int64_t)r1 * ld + sc);
+        vreg0 = *reinterpret_cast<const float4*>(Vb + (int64_t)r0 * ld + sc);
+        vreg1 = *reinterpret_cast<const float4*>(Vb + (int64_t)r1 * ld + sc);
+    };
+    // K piece position of (row, 4-d group sc4): 16-B chunk (sc4 >> 1) ^ ((row >> 1) & 7), 8-B half sc4 & 1
+    const int kw0 = sr * KROWB + ((((sc4 >> 1) ^ ((sr >> 1) & 7)) << 4) | ((sc4 & 1) << 3));
+    const int kw1 = (sr + 16) * KROWB + ((((sc4 >> 1) ^ (((sr + 16) >> 1) & 7)) << 4) | ((sc4 & 1) << 3));
+    auto store_k = [&](const float4 x, unsigned char* dst) {
+        float r0 = x.x, r1 = x.y, r2 = x.z, r3 = x.w;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uint32_t w0 = pack2(r0, r1), w1 = pack2(r2, r3);
+            *reinterpret_cast<uint2*>(dst + p * KPIECE) = make_uint2(w0, w1);
+            if (p + 1 < NP) { r0 -= lo_f(w0); r1 -= hi_f(w0); r2 -= lo_f(w1); r3 -= hi_f(w1); }
+        }
+    };
+    // V piece position of (row, 4-d group sc4): 16-B chunk (sc4 >> 1) ^ (4 * ((row >> 1) & 1)); rows sr and sr + 16 share the bit
+    const int vw0 = sr * KROWB + ((((sc4 >> 1) ^ (((sr >> 1) & 1) << 2)) << 4) | ((sc4 & 1) << 3));
+    const int vw1 = vw0 + 16 * KROWB;
+    auto lstore = [&](unsigned char* buf) {
+        store_k(kreg0, buf + kw0);
+        store_k(kreg1, buf + kw1);
+        store_k(vreg0, buf + NP * KPIECE + vw0);
+        store_k(vreg1, buf + NP * KPIECE + vw1);
+    };
+    // transposed V read: lane 4 q + p4 of a 16-lane group addresses row (4 lh + q) + 16 st + 8 jj, d columns 4 p4 .. + 3 of the
+    // 16-d block g1 of d tile dt; it receives column (lane & 15) of the block's four keys
+    int vtr[2];
+    {
+        const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, g1 = (lane >> 4) & 1, bsw = (q >> 1) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            vtr[dt] = (4 * lh + q) * KROWB + ((4 * (dt ^ bsw) + 2 * g1 + (p4 >> 1)) << 4) + ((p4 & 1) << 3);
+    }
+    // K fragment read: lane (key lr, half lh), k-step s -> logical 16-B chunk 2 s + lh of row lr
+    const int kswz = (lr >> 1) & 7;
+
+    float m = -INFINITY, l = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+
+    gload(tile_base(0));
+    lstore(lds);
+    __syncthreads();
+
+    for (int it = 0; it < ntiles; ++it) {
+        const unsigned char* buf = lds + (it & 1) * BUFB;
+        const int kb = tile_base(it);
+        gload(tile_base(it + 1 < ntiles ? it + 1 : it));  // unconditional: keeps the loads in flight under the math
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        bool relevant = wave_active;
+        if (WINDOWED) relevant = relevant && (kb == 0 || (kb + 31 >= q0 - window && kb <= q0 + 31 + window));
+        if (relevant) {
+            // ---- S^T tile = K Q^T
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                u32x4 ka[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    ka[p] = *reinterpret_cast<const u32x4*>(buf + p * KPIECE + lr * KROWB + (((2 * st + lh) ^ kswz) << 4));
+                s = mfma_split<NP>(ka, qp[st], s);
+            }
+            // ---- mask + online softmax (base 2); s[r] is key kb + (r&3) + 8*(r>>2) + 4*lh for query q0 + lr
+            float mx = -INFINITY;
+            if (!WINDOWED && kb + 32 <= len) {  // interior tile of full attention: every key valid, no masking work
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    bool ok = key < len;
+                    if (WINDOWED) {
+                        const int dlt = qi - key;
+                        ok = ok && (key == 0 || (dlt <= window && dlt >= -window));
+                    }
+                    s[r] = ok ? s[r] : -INFINITY;
+                    mx = fmaxf(mx, s[r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float corr = (m == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : __builtin_amdgcn_exp2f(m - m_use);
+            float ps = 0.f;
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pv[r] = __builtin_amdgcn_exp2f(s[r] - m_use);  // raw v_exp_f32 (arguments <= 0; results below 2^-126 flush to 0)
+                ps += pv[r];
+            }
+            ps += __shfl_xor(ps, 32, 64);
+            l = l * corr + ps;
+            m = m_new;
+            if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0) {  // wave-uniform: the running maxima usually stop moving early
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+            }
+            // P pieces: k-step st of the second product takes registers 8 st .. 8 st + 7
+            u32x4 pp[2][NP];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const float x[8] = {pv[8 * st], pv[8 * st + 1], pv[8 * st + 2], pv[8 * st + 3],
+                                    pv[8 * st + 4], pv[8 * st + 5], pv[8 * st + 6], pv[8 * st + 7]};
+                split8<NP>(x, pp[st]);
+            }
+            // ---- O^T += V^T P^T: A operand element j of k-step st is V[kb + (j & 3) + 8 (2 st + (j >> 2)) + 4 lh][d]
+            const unsigned char* vbase = buf + NP * KPIECE;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    u32x4 va[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const unsigned char* a0 = vbase + p * KPIECE + vtr[dt] + (16 * st) * KROWB;
+                        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                       (__attribute__((address_space(3))) s16x4*)a0));
+                        const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                       (__attribute__((address_space(3))) s16x4*)(a0 + 8 * KROWB)));
+                        va[p][0] = lo.x; va[p][1] = lo.y; va[p][2] = hi.x; va[p][3] = hi.y;
+                    }
+                    if (dt == 0) o0 = mfma_split<NP>(va, pp[st], o0);
+                    else o1 = mfma_split<NP>(va, pp[st], o1);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(lds + ((it + 1) & 1) * BUFB);
+        __syncthreads();
+    }
+
+    if (wave_active && qi < len && !(WINDOWED && qi == 0)) {
+        const float inv = 1.0f / l;
+        float* op = ctx + (int64_t)(t0 + qi) * ((int64_t)H * kDh) + h * kDh + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<float4*>(op + 8 * g) =
+                make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 32 + 8 * g) =
+                make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
+
+// Software-pipelined variant for full attention (no window): the score MFMAs of tile t+1 are issued BEFORE the softmax of tile t, and a
+// sched_group_barrier pipeline interleaves them with that softmax's VALU work (a wave issues in order: VALU placed after a dependent
+// MFMA chain only starts when the chain has drained), then the P V MFMAs of tile t are interleaved with the split + LDS store of tile
+// t+2.  Needs three LDS stages (K of t+1 and V of t are read while t+2 is written): 3 x 2 NP x 4 KB = 48 KB (NP = 2).
+template <int NP>
+__global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_pipe_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                                     const int32_t* __restrict__ seq_order, int H, float scale_log2e,
+                                                                     float* __restrict__ ctx) {
+    constexpr int BUFB = 2 * NP * KPIECE;  // K pieces, then V pieces
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 3 * BUFB
+    const int b = seq_order ? seq_order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int t0 = cu[b], len = cu[b + 1] - t0;
+    const int q_base = blockIdx.x * 128;
+    if (q_base >= len) return;
+    const int64_t ld = (int64_t)3 * H * kDh;
+    const float* __restrict__ Qb = qkv + (int64_t)t0 * ld + h * kDh;
+    const float* __restrict__ Kb = Qb + H * kDh;
+    const float* __restrict__ Vb = Qb + 2 * H * kDh;
+    const int q0 = q_base + wave * 32;
+    const bool wave_active = q0 < len;
+    const int qi = q0 + lr;
+
+    u32x4 qp[4][NP];
+    {
+        const int qrow = qi < len ? qi : len - 1;
+        const float* qr = Qb + (int64_t)qrow * ld + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 x0 = *reinterpret_cast<const float4*>(qr + 16 * s);
+            const float4 x1 = *reinterpret_cast<const float4*>(qr + 16 * s + 4);
+            const float x[8] = {x0.x * scale_log2e, x0.y * scale_log2e, x0.z * scale_log2e, x0.w * scale_log2e,
+                                x1.x * scale_log2e, x1.y * scale_log2e, x1.z * scale_log2e, x1.w * scale_log2e};
+            split8<NP>(x, qp[s]);
+        }
+    }
+    const int ntiles = (len + 31) / 32;
+
+    const int sr = tid >> 4, sc4 = tid & 15, sc = sc4 * 4;
+    float4 kreg0, kreg1, vreg0, vreg1;
+    auto gload = [&](int kb) {
+        int r0 = kb + sr, r1 = kb + sr + 16;
+        r0 = r0 < len ? r0 : len - 1;
+        r1 = r1 < len ? r1 : len - 1;
+        kreg0 = *reinterpret_cast<const float4*>(Kb + (int64_t)r0 * ld + sc);
+        kreg1 = *reinterpret_cast<const float4*>(Kb + (int64_t)r1 * ld + sc);
+        vreg0 = *reinterpret_cast<const float4*>(Vb + (int64_t)r0 * ld + sc);
+        vreg1 = *reinterpret_cast<const float4*>(Vb + (int64_t)r1 * ld + sc);
+    };
+    const int kw0 = sr * KROWB + ((((sc4 >> 1) ^ ((sr >> 1) & 7)) << 4) | ((sc4 & 1) << 3));
+    const int kw1 = (sr + 16) * KROWB + ((((sc4 >> 1) ^ (((sr + 16) >> 1) & 7)) << 4) | ((sc4 & 1) << 3));
+    const int vw0 = sr * KROWB + ((((sc4 >> 1) ^ (((sr >> 1) & 1) << 2)) << 4) | ((sc4 & 1) << 3));
+    const int vw1 = vw0 + 16 * KROWB;
+    auto store_k = [&](const float4 x, unsigned char* dst) {
+        float r0 = x.x, r1 = x.y, r2 = x.z, r3 = x.w;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uint32_t w0 = pack2(r0, r1), w1 = pack2(r2, r3);
+            *reinterpret_cast<uint2*>(dst + p * KPIECE) = make_uint2(w0, w1);
+            if (p + 1 < NP) { r0 -= lo_f(w0); r1 -= hi_f(w0); r2 -= lo_f(w1); r3 -= hi_f(w1); }
+        }
+    };
+    auto lstore = [&](unsigned char* buf) {
+        store_k(kreg0, buf + kw0);
+        store_k(kreg1, buf + kw1);
+        store_k(vreg0, buf + NP * KPIECE + vw0);
+        store_k(vreg1, buf + NP * KPIECE + vw1);
+    };
+    const int kswz = (lr >> 1) & 7;
+    int vtr[2];
+    {
+        const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, g1 = (lane >> 4) & 1, bsw = (q >> 1) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            vtr[dt] = (4 * lh + q) * KROWB + ((4 * (dt ^ bsw) + 2 * g1 + (p4 >> 1)) << 4) + ((p4 & 1) << 3);
+    }
+    auto scores = [&](const unsigned char* buf) {  // S^T tile = K Q^T (raw, unmasked)
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            u32x4 ka[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                ka[p] = *reinterpret_cast<const u32x4*>(buf + p * KPIECE + lr * KROWB + (((2 * st + lh) ^ kswz) << 4));
+            s = mfma_split<NP>(ka, qp[st], s);
+        }
+        return s;
+    };
+
+    float m = -INFINITY, l = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+
+    auto stage = [&](int it) { return lds + (it % 3) * BUFB; };
+    gload(0);
+    lstore(stage(0));
+    gload(ntiles > 1 ? 32 : 0);
+    __syncthreads();
+    f32x16 s_cur = scores(stage(0));
+    lstore(stage(1));
+    gload(ntiles > 2 ? 64 : 0);
+    __syncthreads();
+
+    for (int it = 0; it < ntiles; ++it) {
+        const int kb = it * 32;
+        // ---- (A) scores of the NEXT tile (matrix pipe) beside the softmax of this one (VALU)
+        f32x16 s_next = scores(stage(it + 1));  // (past the end: stage holds stale data, result unused)
+        f32x16 s = s_cur;
+        float mx = -INFINITY;
+        if (kb + 32 <= len) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                s[r] = key < len ? s[r] : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float corr = (m == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : __builtin_amdgcn_exp2f(m - m_use);
+        float ps = 0.f;
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pv[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
+            ps += pv[r];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * corr + ps;
+        m = m_new;
+        u32x4 pp[2][NP];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const float x[8] = {pv[8 * st], pv[8 * st + 1], pv[8 * st + 2], pv[8 * st + 3], pv[8 * st + 4], pv[8 * st + 5], pv[8 * st + 6], pv[8 * st + 7]};
+            split8<NP>(x, pp[st]);
+        }
+#define MR_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+        // 4 k-steps x (NP == 2 ? 3 : 6) MFMAs of s_next, each followed by a slice of the softmax / P-split VALU work
+#pragma unroll
+        for (int k = 0; k < 4 * (NP == 2 ? 3 : 6); ++k) { MR_SGB(0x008, 1); MR_SGB(0x002, (NP == 2 ? 12 : 7)); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+        }
+        // ---- (B) O^T += V^T P^T of this tile beside the split + LDS store of tile it + 2
+        const unsigned char* vbase = stage(it) + NP * KPIECE;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                u32x4 va[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const unsigned char* a0 = vbase + p * KPIECE + vtr[dt] + (16 * st) * KROWB;
+                    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0));
+                    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * KROWB)));
+                    va[p][0] = lo.x; va[p][1] = lo.y; va[p][2] = hi.x; va[p][3] = hi.y;
+                }
+                if (wave_active) {
+                    if (dt == 0) o0 = mfma_split<NP>(va, pp[st], o0);
+                    else o1 = mfma_split<NP>(va, pp[st], o1);
+                }
+            }
+        }
+        lstore(stage(it + 2));  // tile it + 2 (its stage held tile it - 1, last read before the previous barrier)
+        gload((it + 3 < ntiles ? it + 3 : 0) * 32);
+#pragma unroll
+        for (int k = 0; k < 4 * (NP == 2 ? 3 : 6); ++k) { MR_SGB(0x008, 1); MR_SGB(0x002, 4); MR_SGB(0x200, 1); }
+#undef MR_SGB
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        s_cur = s_next;
+    }
+
+    if (wave_active && qi < len) {
+        const float inv = 1.0f / l;
+        float* op = ctx + (int64_t)(t0 + qi) * ((int64_t)H * kDh) + h * kDh + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<float4*>(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh,
+                                 int max_len, float scale, int window, int products, float* ctx, mr_stream_t stream) {
+    if (!qkv || !cu_seqlens || !ctx || B < 0 || H < 1 || max_len < 0) return MR_EINVAL;
+    if (dh != kDh || (products != 3 && products != 6)) return MR_EUNSUPPORTED;
+    if (!mr::aligned16(qkv) || !mr::aligned16(ctx)) return MR_EALIGN;
+    if (B == 0 || max_len == 0) return MR_OK;
+    const dim3 grid((max_len + 127) / 128, H, B);
+    const float scale_log2e = scale * 1.4426950408889634f;
+    hipStream_t st = (hipStream_t)stream;
+#define MR_ATTN_LAUNCH(W_, NP_)                                                                                          \
+    hipLaunchKernelGGL((attn_split_kernel<W_, NP_>), grid, dim3(kThreads), (size_t)2 * (2 * NP_ * KPIECE), st, qkv,       \
+                       cu_seqlens, seq_order, H, scale_log2e, window, ctx)
+    static const int use_pipe = [] { const char* e = getenv("MR_ATTN_PIPE"); return e ? atoi(e) : 1; }();
+    if (window >= 0) {
+        if (products == 3) MR_ATTN_LAUNCH(true, 2); else MR_ATTN_LAUNCH(true, 3);
+    } else if (use_pipe) {
+#define MR_ATTN_PIPE_LAUNCH(NP_)                                                                                                      \
+    do {                                                                                                                              \
+        static bool attr_done = false;                                                                                                \
+        if (!attr_done) {                                                                                                             \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_pipe_kernel<NP_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                3 * 2 * NP_ * KPIECE);                                                                                \
+            attr_done = true;                                                                                                         \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((attn_split_pipe_kernel<NP_>), grid, dim3(kThreads), (size_t)3 * (2 * NP_ * KPIECE), st, qkv, cu_seqlens,    \
+                           seq_order, H, scale_log2e, ctx);                                                                           \
+    } while (0)
+        if (products == 3) MR_ATTN_PIPE_LAUNCH(2); else MR_ATTN_PIPE_LAUNCH(3);
+#undef MR_ATTN_PIPE_LAUNCH
+    } else {
+        if (products == 3) MR_ATTN_LAUNCH(false, 2); else MR_ATTN_LAUNCH(false, 3);
+    }
+#undef MR_ATTN_LAUNCH
+    return mr::check_launch();
+}
