@@ -19,6 +19,13 @@
 #include <math.h>
 #include <stdint.h>
 
+// phase-timing hooks: empty in the library; exp/attn_phases.hip defines them (s_memtime deltas per phase)
+#ifndef MR_PH_DECL
+#define MR_PH_DECL
+#define MR_PH(i)
+#define MR_PH_FLUSH(pid)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -178,9 +185,11 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 
+    MR_PH_DECL
     gload(tile_base(0));
     lstore(lds);
     __syncthreads();
+    MR_PH(0)
 
     for (int it = 0; it < ntiles; ++it) {
         const unsigned char* buf = lds + (it & 1) * BUFB;
@@ -204,6 +213,7 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
                     ka[p] = *reinterpret_cast<const u32x4*>(buf + p * KPIECE + lr * KROWB + (((2 * st + lh) ^ kswz) << 4));
                 s = mfma_split<NP>(ka, qp[st], s);
             }
+            MR_PH(1)
             // ---- mask + online softmax (base 2); s[r] is key kb + (r&3) + 8*(r>>2) + 4*lh for query q0 + lr
             float mx = -INFINITY;
             if (!WINDOWED && kb + 32 <= len) {  // interior tile of full attention: every key valid, no masking work
@@ -248,6 +258,7 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
                                     pv[8 * st + 4], pv[8 * st + 5], pv[8 * st + 6], pv[8 * st + 7]};
                 split8<NP>(x, pp[st]);
             }
+            MR_PH(2)
             // ---- O^T += V^T P^T: A operand element j of k-step st is V[kb + (j & 3) + 8 (2 st + (j >> 2)) + 4 lh][d]
             const unsigned char* vbase = buf + NP * KPIECE;
 #pragma unroll
@@ -269,10 +280,14 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
                 }
             }
         }
+        MR_PH(3)
         __builtin_amdgcn_sched_barrier(0);
         lstore(lds + ((it + 1) & 1) * BUFB);
+        MR_PH(4)
         __syncthreads();
+        MR_PH(5)
     }
+    MR_PH_FLUSH((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)
 
     if (wave_active && qi < len && !(WINDOWED && qi == 0)) {
         const float inv = 1.0f / l;
