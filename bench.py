@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak
+SUSTAINED_CLOCK_GHZ = {"bf16x3": 1.1, "bf16x6": 1.44}  # measured inside the encoder GEMM kernels (profiles/r01_inkernel_clock.txt)
 
 
 def parse():
@@ -237,6 +238,13 @@ def main():
                         frac=dom[1]["frac"], traffic=traffic, traffic_uncorrected=traffic_raw, traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=ops.PROF.summary()[dom[0]]["bytes"] / max(dom[1]["launches"], 1),
                         launches=dom[1]["launches"], avg_launch_ms=dom[1]["avg_ms"])
+        if "mfma_utilization" in roofline:
+            # the dense peak assumes 2.4 GHz; under this kernel the chip sustains ~1.1 GHz (in-kernel s_memtime / s_memrealtime of the same
+            # kernel, profiles/r01_inkernel_clock.txt: 1.04-1.16 GHz on two devices) -- the matrix pipe's busy fraction at THAT clock:
+            roofline["sustained_clock_ghz"] = SUSTAINED_CLOCK_GHZ.get(gemm_mode)
+            roofline["sustained_clock_source"] = "profiles/r01_inkernel_clock.txt (exp/gemm_phases.hip)"
+            if roofline["sustained_clock_ghz"]:
+                roofline["mfma_busy_at_sustained_clock"] = roofline["mfma_utilization"] * 2.4 / roofline["sustained_clock_ghz"]
 
     # ---------------- CPU baseline (oracle port, rank 0, N == 1 only) ----------------
     cpu_baseline = None
