@@ -41,6 +41,7 @@ __global__ void split_w_kernel(const float* __restrict__ w, int N, int K, uint16
     }
 }
 
+__device__ unsigned long long g_clk[8192 * 4];
 constexpr int BM = 256, BN = 256, BK = 32, NTHR = 512;
 constexpr int ROWB = 32;
 constexpr int SUB = 256 * ROWB;          // one piece x one 16-k sub-block x 256 rows = 8 KB
@@ -62,6 +63,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 __global__ __launch_bounds__(NTHR, 1) void gemm_v5_kernel(const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ wh,
                                                           const uint16_t* __restrict__ wm_, const float* __restrict__ bias, int M,
                                                           int N, int K, float* __restrict__ C, int64_t ldc, int tiles_n, int nwg) {
+    const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int pid = xcd_remap(blockIdx.x, nwg);
     const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_v5_kernel(const float* __restric
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    if (threadIdx.x == 0 && blockIdx.x < 8192) { g_clk[blockIdx.x * 4] = clk_c0; g_clk[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime(); g_clk[blockIdx.x * 4 + 2] = clk_r0; g_clk[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
     const bool interior = (m0 + BM <= M) && (n0 + BN <= N);
     if (interior) {
         float bz[4];
@@ -293,6 +296,15 @@ int main(int argc, char** argv) {
         }
         std::sort(ts.begin(), ts.end());
         const double fl = 2.0 * M * N * K;
+        {
+            static unsigned long long hc[8192 * 4];
+            CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_clk), sizeof(hc)));
+            double cs = 0, rs = 0;
+            const int nw = nwg < 8192 ? nwg : 8192;
+            for (int w = 0; w < nw; ++w) { cs += (double)(hc[w * 4 + 1] - hc[w * 4]); rs += (double)(hc[w * 4 + 3] - hc[w * 4 + 2]); }
+            const double ghz = cs / rs * 0.1, mf = 3.0 * fl / ts[ts.size() / 2] / 1e9;
+            printf("      main-loop clock %.2f GHz; MFMA %.0f TFLOP/s = %.0f %% of the pipe at that clock\n", ghz, mf, 100.0 * mf / (2500.0 * ghz / 2.4));
+        }
         printf("v5 %-5s M=%d N=%d K=%d: %.3f ms  %.1f TFLOP/s alg (best %.1f)  max rel-to-magnitude err %.3g %s\n", sh.name, M, N, K,
                ts[ts.size() / 2], fl / ts[ts.size() / 2] / 1e9, fl / ts[0] / 1e9, worst, worst < 3e-5 ? "OK" : "FAIL");
         fflush(stdout);
