@@ -494,7 +494,7 @@ def test_large_configs_match_oracle(kind):
     """24 x 1024, 16 heads (BLAIR_LARGE / RECFORMER_LARGE, BASELINE config 5's encoder): every GEMM mode against the CPU oracle"""
     import sys
 
-    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tools"))
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent / "tools"))
     import large_models_check as L
     from mergerec_amd.engine import EncoderSpec
 

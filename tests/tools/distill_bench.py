@@ -2,7 +2,7 @@
 cfg5 shape: 16 rows per step over a catalog of M items (SINGLE_PSEUDO_LABEL_KD, T = 0.05, coefficient = 1000); a large-batch
 shape shows the HBM-bound regime.  Algorithmic bytes per row: z and t read once, dz written once = 12 M bytes."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mergerec_amd import ops
 from oracle import ref_cpu as O

@@ -1,7 +1,7 @@
 """BLaIR-large and Recformer-large (24 x 1024, 16 heads) through the HIP encoder against the CPU oracle on a few short sequences,
 all three GEMM modes; random weights at the true dims.  Prints max |difference| of the normalised CLS embeddings."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from collections import OrderedDict
 import torch
 from mergerec_amd.engine import ArenaLayout, EncoderRunner, EncoderSpec, WeightSet

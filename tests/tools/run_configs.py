@@ -4,12 +4,12 @@ at the TRUE architecture dims, time every stage, and cross-check a sample agains
   cfg2: 2-domain merge BLaIR-base, fixed alpha = 0.5 (TASK_VECTOR / TASK_WISE)
   cfg3: 3-domain merge Recformer-base, per-layer-group alpha (TIES / LAYER_WISE, the published recipe of scripts/3_mergerec)
 
-python tools/run_configs.py [--users 2048] [--items 4968] [--out profiles/r01_configs.json]
+python tests/tools/run_configs.py [--users 2048] [--items 4968] [--out profiles/r01_configs.json]
 """
 import argparse, json, os, sys, time
 from collections import OrderedDict
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from mergerec_amd.data import load_domain

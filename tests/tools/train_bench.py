@@ -2,7 +2,7 @@
 8 fine-tuned checkpoints, batch of 16 pseudo-user sequences (item texts, ~40 tokens), 8 catalogs of M items, SINGLE_PSEUDO_LABEL_KD.
 Reports ms/step with a per-stage breakdown (HIP events) and, with TB_CPU=1, the same step through the CPU oracle + torch autograd."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from collections import OrderedDict
 import torch
 from mergerec_amd import ops
