@@ -318,6 +318,20 @@ int mr_attn_global_row_bwd_f32(const float* qg, const float* kvg, const float* c
 int mr_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int T, int d, float* table, int64_t ldt,
                             mr_stream_t stream);
 
+/* ---- fine-tuning (finetune_train.py): the optimizer step over the parameter arena ------------- */
+
+/* One AdamW step over a flat fp32 vector of n elements (n % 4 == 0), in place: torch.optim.AdamW's update
+ *   p *= 1 - lr wd;  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g g;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * with the weight decay looked up per segment (seg_off: S + 1 ascending int64 element offsets, multiples of 4, seg_off[0] = 0,
+ * seg_off[S] = n; seg_wd: S floats; both NULL -> `weight_decay` everywhere) and, when grad_sumsq != NULL, the gradient first scaled by
+ * min(1, max_grad_norm / (sqrt(*grad_sumsq) + 1e-6)) -- torch.nn.utils.clip_grad_norm_ with the norm read from DEVICE memory.
+ * `step` counts from 1.  Hyper-parameters are doubles (python floats in the reference); the arithmetic is fp32.
+ * replaces: torch.optim.AdamW over the two parameter groups of module/recommender/module.py:44-72 (configure_optimizers) and
+ * Lightning's gradient_clip_val (finetune_train.py:106). */
+int mr_adamw_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const int64_t* seg_off,
+                      const float* seg_wd, int S, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                      const float* grad_sumsq, float max_grad_norm, mr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ c_p = ctypes.c_void_p
 c_i = ctypes.c_int
 c_i64 = ctypes.c_int64
 c_f = ctypes.c_float
+c_d = ctypes.c_double
 c_sz = ctypes.c_size_t
 
 # name -> (restype, argtypes); mirrors include/mergerec_hip.h
@@ -55,6 +56,7 @@ SIGNATURES = {
     "mr_attn_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p]),
     "mr_attn_global_row_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
     "mr_scatter_add_rows_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_p, c_i64, c_p]),
+    "mr_adamw_step_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i, c_d, c_d, c_d, c_d, c_d, c_i64, c_p, c_f, c_p]),
     "mr_pack_tokens": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mr_embed_gather_ln_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p]),
     "mr_gemm_nt_bias_act_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p]),

@@ -1,4 +1,5 @@
-"""Mirror of rec_retrieval/module/callbacks.py:18-64 (ItemEncoderMixin, ItemEncodingCallback) and :139-174 (SaveWeightsCallback)."""
+"""Mirror of rec_retrieval/module/callbacks.py:18-78 (ItemEncoderMixin, ItemEncodingCallback, ItemEncodingNegativeSampleCallback), :81-109
+(MultiDatasetItemEncodingCallback) and :139-174 (SaveWeightsCallback)."""
 from __future__ import annotations
 
 import re
@@ -35,6 +36,28 @@ class ItemEncoderMixin:
 class ItemEncodingCallback(ItemEncoderMixin):
     def __init__(self, item_dataloader=None):
         self.item_dataloader = item_dataloader
+
+    def on_train_epoch_start(self, trainer, pl_module):
+        """callbacks.py:57-59: full-catalog training scores against a catalog frozen at the start of each epoch."""
+        print(f"[Train - epoch {trainer.current_epoch} start] Encoding items.")
+        self.inject_item_embeddings(self.item_dataloader, pl_module)
+
+    def on_test_epoch_start(self, trainer, pl_module):
+        if pl_module.item_embeddings is None:
+            print("[Test - epoch start] Encoding items as no item embeddings are found.")
+            self.inject_item_embeddings(self.item_dataloader, pl_module)
+
+
+class ItemEncodingNegativeSampleCallback(ItemEncoderMixin):
+    """callbacks.py:67-78: negative-sampling fine-tuning needs the catalog only for validation (re-encoded with the current
+    weights at every validation epoch) and for the final test."""
+
+    def __init__(self, item_dataloader=None):
+        self.item_dataloader = item_dataloader
+
+    def on_validation_epoch_start(self, trainer, pl_module):
+        print(f"[Validation - epoch {trainer.current_epoch} start] Encoding items.")
+        self.inject_item_embeddings(self.item_dataloader, pl_module)
 
     def on_test_epoch_start(self, trainer, pl_module):
         if pl_module.item_embeddings is None:

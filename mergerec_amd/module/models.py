@@ -132,6 +132,22 @@ class BaseEncoderModel(nn.Module):
             raise TypeError("Input must be a BatchEncoding object.")  # encoder/_base.py:34-35
         return self.runner.encode(self._weights, batch, self.device, normalize=False)
 
+    # -- fine-tuning (finetune_train.py): the same forward with an autograd edge to the arena ------
+    def train_leaf(self) -> torch.Tensor:
+        """The parameter arena as ONE autograd leaf (shares the arena's storage): ``.grad`` is d loss / d parameters in arena
+        layout -- what ``optim.ArenaAdamW.step`` consumes.  The reference's ~200 nn.Parameters are views of it (``state_dict``)."""
+        leaf = getattr(self, "_train_leaf", None)
+        if leaf is None or leaf.data_ptr() != self._flat.data_ptr():
+            leaf = self._train_leaf = self._flat.detach().requires_grad_(True)
+        return leaf
+
+    def forward_with_grad(self, batch) -> torch.Tensor:
+        """(B, d) CLS rows through the exact-fp32 training graph (engine_train.EncoderTrainGraph), differentiable w.r.t. ``train_leaf()``."""
+        from ..engine_train import EncoderTrainGraph, encode_with_grad
+
+        graph = EncoderTrainGraph(self.spec, self._weights.layout, prefix=self.runner.prefix)  # one per forward: it owns the saved activations
+        return encode_with_grad(graph, self.train_leaf(), self.runner.pack(batch, self.device))
+
     def encode_normalized(self, batch, normalize: bool, lens=None, validate: bool = True) -> torch.Tensor:
         """forward + F.normalize fused into the pooling kernel (module/recommender/module.py:74-77)."""
         return self.runner.encode(self._weights, batch, self.device, normalize=normalize, lens=lens, validate=validate)

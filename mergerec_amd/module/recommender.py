@@ -1,6 +1,6 @@
-"""Mirror of rec_retrieval/module/recommender/module.py:21-361 restricted to merged-model inference
-(forward dispatch, item encoding, full-catalog scoring, test loop); the fine-tuning side
-(training_step, negative sampling, optimizers, RecJointModule) is out of scope.
+"""Mirror of rec_retrieval/module/recommender/module.py:21-361: forward dispatch, item encoding, full-catalog scoring and the
+test / validation loops (merged-model inference), and the fine-tuning side of RecModule -- negative-sampling scores
+(:79-131), ``training_step`` (:168-189) and ``configure_optimizers`` (:44-72).  RecJointModule is not built.
 
 RecModule is a LightningModule when ``lightning`` is importable, otherwise a hook-compatible nn.Module
 driven by mergerec_amd.utils.Trainer -- the hooks and their order are the same either way."""
@@ -12,8 +12,10 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..autograd import cross_entropy_rows, matmul_nt
+from ..configs import NegativeSampleOption
 from ..evaluator import Evaluator
-from ..model_batch import BatchItem, BatchSequence
+from ..model_batch import BatchItem, BatchSequence, BatchSequenceWithNegative
 
 try:  # pragma: no cover - lightning is not installed in the build image
     import lightning as L
@@ -36,7 +38,8 @@ except Exception:  # noqa: BLE001
             return getattr(m, "device", torch.device("cuda", torch.cuda.current_device()))
 
         def log(self, name, value, **_):
-            self._logged[name] = float(value)
+            # device scalars stay on the device (no host sync per step); read them with float() when needed
+            self._logged[name] = value.detach() if isinstance(value, torch.Tensor) else float(value)
 
         def log_dict(self, d, **_):
             for k, v in d.items():
@@ -73,6 +76,10 @@ class RecModule(_Base):
 
     # -- forward (module.py:74-77, 133-166) --------------------------------------------------------
     def _encode(self, batch) -> torch.Tensor:
+        if torch.is_grad_enabled() and self.training and hasattr(self.model, "forward_with_grad"):
+            # fine-tuning: the exact-fp32 training graph, then F.normalize on the (B, d) rows under autograd
+            out = self.model.forward_with_grad(batch)
+            return nn.functional.normalize(out, p=2, dim=-1) if self.similarity == "cosine" else out
         if hasattr(self.model, "encode_normalized"):
             return self.model.encode_normalized(batch, normalize=self.similarity == "cosine")
         out = self.model.forward(batch)  # e.g. a TaskVectorMergingModule (re-merges, then encodes)
@@ -84,8 +91,35 @@ class RecModule(_Base):
     def _forward_all_negative(self, batch, labels: torch.Tensor):
         user = self._encode(batch)
         E = self.item_embeddings.data
-        scores = ops.gemm_nt(user, [E])  # scores = user @ item_embeddings.T (module.py:137)
+        scores = matmul_nt(user, E) if user.requires_grad else ops.gemm_nt(user, [E])  # user @ item_embeddings.T (module.py:137)
         return scores, labels, user
+
+    def _forward_negative_sample(self, sequence_batch, target_batch, negative_batch):
+        """module.py:79-131.  The reference encodes the three batches one after the other; here they go through ONE packed
+        encoder pass (padding never reaches a kernel), and every score the modes need comes from one GEMM ``user @ [target; negatives].T``."""
+        from ..data import _cat_encodings
+
+        mode = self.negative_sample.mode
+        need_neg = mode in (NegativeSampleOption.SAMPLE, NegativeSampleOption.IN_BATCH_SAMPLE)
+        if need_neg:
+            assert negative_batch is not None, f"negative_batch must not be None in {mode.name.lower()} mode"
+        elif mode != NegativeSampleOption.IN_BATCH:
+            raise ValueError(f"Invalid negative sample mode: {mode}")
+        parts = [sequence_batch, target_batch] + ([negative_batch] if need_neg else [])
+        reps = self._encode(_cat_encodings([dict(p) for p in parts], getattr(self.model.spec, "pad_id", 1)))
+        B = sequence_batch["input_ids"].shape[0]
+        user, others = reps[:B], reps[B:]
+        full = matmul_nt(user, others)  # (B, B [+ B k])
+        dev = full.device
+        if mode == NegativeSampleOption.IN_BATCH:
+            return full, torch.arange(B, device=dev)
+        k = self.negative_sample.k
+        own_neg = B + torch.arange(B, device=dev).view(B, 1) * k + torch.arange(k, device=dev).view(1, k)  # columns of row b's negatives
+        neg_scores = torch.gather(full, 1, own_neg)
+        if mode == NegativeSampleOption.SAMPLE:
+            pos = torch.gather(full, 1, torch.arange(B, device=dev).view(B, 1))
+            return torch.cat((pos, neg_scores), dim=1), torch.zeros(B, dtype=torch.long, device=dev)
+        return torch.cat((full[:, :B], neg_scores), dim=1), torch.arange(B, device=dev)
 
     def _forward_item_encoding(self, batch):
         assert "labels" not in batch, "labels must not be in batch when encoding items"
@@ -96,14 +130,45 @@ class RecModule(_Base):
             return self._forward_item_encoding(batch.items)
         if isinstance(batch, BatchSequence):
             return self._forward_all_negative(batch.sequence, batch.labels)
+        if isinstance(batch, BatchSequenceWithNegative):
+            return self._forward_negative_sample(batch.sequence, batch.target, batch.negatives)
         raise ValueError(f"Invalid batch type {type(batch)}")
 
-    # -- test loop (module.py:325-361) ------------------------------------------------------------
-    def on_test_epoch_start(self):
+    # -- fine-tuning (module.py:44-72, 168-189) ----------------------------------------------------
+    def training_step(self, batch, batch_idx: int):
+        output = self.forward(batch)
+        if len(output) == 2:
+            scores, labels = output
+        elif len(output) == 3:
+            scores, labels, _ = output
+        else:
+            raise ValueError(f"Invalid output length {len(output)}")
+        loss = cross_entropy_rows(scores / self.temperature, labels)
+        self.log("train/loss", loss.detach(), on_step=True, on_epoch=True, prog_bar=True)
+        return loss
+
+    def configure_optimizers(self):
+        """AdamW with decay on everything but biases / LayerNorm weights + linear warm-up / decay, as ONE fused arena step
+        (optim.ArenaAdamW).  ``warmup_steps``: int = steps, float = fraction of trainer.estimated_stepping_batches."""
+        from ..optim import ArenaAdamW
+
+        total = self.trainer.estimated_stepping_batches
+        if isinstance(self.warmup_steps, float):
+            warmup = total * self.warmup_steps
+        elif isinstance(self.warmup_steps, int):
+            warmup = self.warmup_steps
+        else:
+            raise ValueError(f"Invalid warmup_steps type {type(self.warmup_steps)}")
+        return ArenaAdamW(self.model.train_leaf().detach(), self.model._weights.layout, lr=self.learning_rate, weight_decay=self.weight_decay,
+                          num_warmup_steps=warmup, num_training_steps=total,
+                          max_grad_norm=getattr(self.trainer, "gradient_clip_val", None))
+
+    # -- evaluation loops (module.py:283-361; validation = the test loop under the "val/" prefix) ----
+    def _eval_start(self):
         self.eval_scores, self.eval_labels, self.eval_user_embeddings = [], [], []
         self._ranks, self._lse, self._lab, self.eval_topk_indices = [], [], [], []
 
-    def test_step(self, batch: BatchSequence, batch_idx: int, dataloader_idx: int = 0):
+    def _eval_step(self, batch: BatchSequence):
         user = self._encode(batch.sequence)
         labels = batch.labels.to(user.device, torch.int64).contiguous()
         k = min(self.evaluator._max_k, self.item_embeddings.shape[0])
@@ -118,7 +183,7 @@ class RecModule(_Base):
         if self.keep_scores:
             self.eval_scores.append(scores.cpu())
 
-    def on_test_epoch_end(self):
+    def _eval_end(self, prefix: str, loss_key: str):
         cat = lambda xs, empty: torch.cat(xs, dim=0) if xs else empty
         dev = self.device
         self.eval_labels = cat(self.eval_labels, torch.empty(0, dtype=torch.int64, device=dev)).cpu()
@@ -127,9 +192,27 @@ class RecModule(_Base):
         self.eval_scores = torch.cat(self.eval_scores, dim=0) if (self.keep_scores and self.eval_scores) else None
         ranks = cat(self._ranks, torch.empty(0, dtype=torch.int32, device=dev))
         lse, lab = cat(self._lse, torch.empty(0, device=dev)), cat(self._lab, torch.empty(0, device=dev))
-        # cross_entropy(scores / T, labels) = mean(logsumexp(row / T) - row[label] / T)   (module.py:356)
+        # cross_entropy(scores / T, labels) = mean(logsumexp(row / T) - row[label] / T)   (module.py:318, 356)
         loss = float((lse.double() - lab.double()).mean()) if lse.numel() else float("nan")
-        metrics = self.evaluator.from_ranks(ranks, metric_prefix="test/")
-        metrics["test/loss"] = loss
+        metrics = self.evaluator.from_ranks(ranks, metric_prefix=prefix)
+        metrics[loss_key] = loss
         self.log_dict(metrics, prog_bar=True)
         return metrics
+
+    def on_validation_epoch_start(self):
+        self._eval_start()
+
+    def validation_step(self, batch: BatchSequence, batch_idx: int, dataloader_idx: int = 0):
+        self._eval_step(batch)
+
+    def on_validation_epoch_end(self):
+        return self._eval_end("val/", "val/epoch_loss")
+
+    def on_test_epoch_start(self):
+        self._eval_start()
+
+    def test_step(self, batch: BatchSequence, batch_idx: int, dataloader_idx: int = 0):
+        self._eval_step(batch)
+
+    def on_test_epoch_end(self):
+        return self._eval_end("test/", "test/loss")

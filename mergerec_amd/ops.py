@@ -563,3 +563,35 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, table: torch.Tensor):
     check(_lib.load().mr_scatter_add_rows_f32(ptr(src), src.stride(0), ptr(idx), T, d, ptr(table), table.stride(0), _stream(src)),
           "mr_scatter_add_rows_f32")
     return table
+
+
+# ------------------------------------------------------------------------------------------ optimizer step (finetune_train)
+def sum_squares(x: torch.Tensor) -> torch.Tensor:
+    """||x||^2 of a flat arena vector as a 1-element DEVICE tensor: the deterministic two-stage dot-product reduction of the
+    alpha-gradient kernel with the vector as its own 'task vector' (feeds the clip coefficient of ``adamw_step`` without a host sync)."""
+    return merge_bwd_alpha(x.view(1, -1), x).view(1)
+
+
+def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float, step: int,
+               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, seg_off: Optional[torch.Tensor] = None,
+               seg_wd: Optional[torch.Tensor] = None, grad_sumsq: Optional[torch.Tensor] = None, max_grad_norm: float = 0.0):
+    """One fused AdamW step over flat fp32 arenas, in place (see mr_adamw_step_f32)."""
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _dev(t, n, torch.float32)
+        if t.dim() != 1 or t.numel() != param.numel():
+            raise ValueError(f"{n} must be a flat vector of the arena's length")
+    S = 0
+    if seg_off is not None:
+        _dev(seg_off, "seg_off", torch.int64), _dev(seg_wd, "seg_wd", torch.float32)
+        S = seg_wd.numel()
+        if seg_off.numel() != S + 1:
+            raise ValueError("seg_off needs one more entry than seg_wd")
+    if grad_sumsq is not None:
+        _dev(grad_sumsq, "grad_sumsq", torch.float32)
+    n = param.numel()
+    ev = PROF.begin(param.device)
+    check(_lib.load().mr_adamw_step_f32(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), n, ptr(seg_off), ptr(seg_wd), S, float(lr),
+                                        float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), ptr(grad_sumsq),
+                                        float(max_grad_norm), _stream(param)), "mr_adamw_step_f32")
+    PROF.end(ev, param.device, "adamw_step", flops=0.0, nbytes=28.0 * n)
+    return param

@@ -181,6 +181,164 @@ class DistillTrainer:
         return self.history
 
 
+class FinetuneTrainer:
+    """``lightning.Trainer(...).fit(module, datamodule)`` followed by ``.test(module, datamodule, ckpt_path="best")`` as
+    finetune_train.py:78-114 configures them: gradient accumulation, global-norm clipping, per-step LR schedule, a validation pass
+    after every epoch, ModelCheckpoint(monitor, mode="max", save_top_k=1, "epoch_{epoch:02d}") and EarlyStopping(monitor, patience).
+
+    One step = ONE packed encoder forward + backward over [sequences; targets (; negatives)] through the HIP training graph, the
+    gradient accumulated in one arena, and one fused clip + AdamW launch per optimizer step.  With torch.distributed initialised the
+    epoch's permutation is dealt over the ranks and the gradient arena is averaged in ONE all-reduce per optimizer step."""
+
+    def __init__(self, max_epochs: int, accumulate_grad_batches: int = 1, gradient_clip_val: Optional[float] = None, precision: str = "32-true",
+                 callbacks: Sequence = (), monitor: str = "val/NDCG@10", patience: int = 5, default_root_dir="MergeRecFineTune",
+                 log_every_n_steps: int = 50, coalesce_tokens: int = 65536, max_steps: Optional[int] = None, verbose: bool = True):
+        self.gemm_mode = precision_to_gemm_mode(precision)  # evaluation arithmetic; the training graph is exact fp32
+        self.max_epochs, self.max_steps = int(max_epochs), max_steps
+        self.accumulate_grad_batches = max(1, int(accumulate_grad_batches))
+        self.gradient_clip_val = gradient_clip_val
+        self.callbacks = list(callbacks)
+        self.monitor, self.patience = monitor, patience
+        self.root = Path(default_root_dir)
+        self.log_every_n_steps, self.coalesce_tokens, self.verbose = log_every_n_steps, coalesce_tokens, verbose
+        self.current_epoch = self.global_step = 0
+        self.estimated_stepping_batches = 0
+        self.callback_metrics: Dict[str, float] = {}
+        self.history: List[float] = []
+        self.lr_history: List[float] = []
+        self.best_score: Optional[float] = None
+        self.best_model_path: Optional[Path] = None
+        self.optimizer = None
+
+    def _hook(self, name, module):
+        for cb in self.callbacks:
+            if hasattr(cb, name):
+                getattr(cb, name)(self, module)
+
+    @staticmethod
+    def _dist():
+        import torch.distributed as dist
+
+        on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+
+    def _train_loader(self, datamodule):
+        from torch.utils.data import DataLoader, Subset
+
+        loader = datamodule.train_dataloader()
+        rank, world = self._dist()
+        if world == 1:
+            return loader
+        idx = shard_indices(len(loader.dataset), rank, world, 1234 + self.current_epoch)
+        return DataLoader(Subset(loader.dataset, idx), batch_size=loader.batch_size, collate_fn=loader.collate_fn, shuffle=False,
+                          num_workers=loader.num_workers, drop_last=True)
+
+    # -- validation / checkpoint ---------------------------------------------------------------------
+    @torch.no_grad()
+    def _validate(self, module, datamodule) -> Dict[str, float]:
+        from .data import coalesce_batches
+
+        module.eval()
+        if self.gemm_mode is not None and hasattr(module.model, "set_gemm_mode"):
+            module.model.set_gemm_mode(self.gemm_mode)
+        self._hook("on_validation_epoch_start", module)
+        module.on_validation_epoch_start()
+        dl = datamodule.val_dataloader()
+        stream = coalesce_batches(dl, self.coalesce_tokens) if self.coalesce_tokens else dl
+        for i, batch in enumerate(stream):
+            module.validation_step(batch.to(module.device), i)
+        metrics = module.on_validation_epoch_end()
+        self.callback_metrics.update(metrics)
+        return metrics
+
+    def _save_checkpoint(self, module) -> Path:
+        """Lightning's checkpoint layout as far as scripts/extract.py reads it: ``state_dict`` with the module's parameter names
+        (``model.model.*`` + ``item_embeddings``)."""
+        d = self.root / "checkpoints"
+        d.mkdir(parents=True, exist_ok=True)
+        path = d / f"epoch_{self.current_epoch:02d}.ckpt"
+        sd = {"model." + k: v.detach().cpu().clone() for k, v in module.model.state_dict().items()}
+        if module.item_embeddings is not None:
+            sd["item_embeddings"] = module.item_embeddings.detach().cpu().clone()
+        torch.save({"state_dict": sd, "epoch": self.current_epoch, "global_step": self.global_step,
+                    "monitor": self.monitor, "score": self.best_score}, path)
+        return path
+
+    # -- fit -----------------------------------------------------------------------------------------
+    def fit(self, module, datamodule):
+        module.trainer = self
+        if getattr(datamodule, "train_dataset", None) is None:
+            datamodule.setup("fit")
+        rank, world = self._dist()
+        acc = self.accumulate_grad_batches
+        n_batches = len(self._train_loader(datamodule))
+        self.estimated_stepping_batches = -(-n_batches // acc) * max(self.max_epochs, 1)
+        if self.max_steps is not None and self.max_steps >= 0:
+            self.estimated_stepping_batches = min(self.estimated_stepping_batches, self.max_steps)
+        opt = self.optimizer = module.configure_optimizers()
+        leaf = module.model.train_leaf()
+        wait, stop = 0, False
+        while not stop and self.current_epoch < self.max_epochs:
+            module.train()
+            self._hook("on_train_epoch_start", module)
+            loader = self._train_loader(datamodule)
+            last = len(loader) - 1
+            leaf.grad = None
+            for batch_idx, batch in enumerate(loader):
+                loss = module.training_step(batch.to(module.device), batch_idx)
+                (loss / acc).backward()  # accumulates into the one gradient arena
+                self.history.append(loss.detach())
+                if (batch_idx + 1) % acc and batch_idx != last:
+                    continue
+                allreduce_mean_grads([leaf])
+                self.lr_history.append(opt.step(leaf.grad))
+                leaf.grad = None
+                self.global_step += 1
+                if self.verbose and self.global_step % self.log_every_n_steps == 0:
+                    print(f"epoch {self.current_epoch} step {self.global_step}: train/loss {float(self.history[-1]):.6f} lr {self.lr_history[-1]:.3e}",
+                          flush=True)
+                if self.max_steps is not None and 0 <= self.max_steps <= self.global_step:
+                    stop = True
+                    break
+            module.model.weights_updated()  # the arena changed under the inference path's bf16 weight pieces
+            self._hook("on_train_epoch_end", module)
+            metrics = self._validate(module, datamodule)
+            score = metrics.get(self.monitor)
+            if score is None:
+                raise KeyError(f"monitored metric {self.monitor!r} not produced by validation: {sorted(metrics)}")
+            if self.verbose:
+                print(f"epoch {self.current_epoch}: " + ", ".join(f"{k} {v:.5f}" for k, v in sorted(metrics.items())), flush=True)
+            if self.best_score is None or score > self.best_score:  # ModelCheckpoint(mode="max", save_top_k=1) + EarlyStopping
+                self.best_score, wait = score, 0
+                if rank == 0:
+                    old = self.best_model_path
+                    self.best_model_path = self._save_checkpoint(module)
+                    if old is not None and old != self.best_model_path and old.exists():
+                        old.unlink()
+            else:
+                wait += 1
+                if wait >= self.patience:
+                    if self.verbose:
+                        print(f"early stopping: {self.monitor} did not improve for {wait} validation epochs (best {self.best_score:.5f})")
+                    stop = True
+            self.current_epoch += 1
+        self.history = [float(x) for x in self.history]
+        return self.history
+
+    # -- test ----------------------------------------------------------------------------------------
+    def test(self, module, datamodule, ckpt_path: Optional[str] = "best"):
+        if ckpt_path == "best":
+            ckpt_path = self.best_model_path
+        if ckpt_path is not None:
+            sd = dict(torch.load(ckpt_path, map_location="cpu")["state_dict"])
+            items = sd.pop("item_embeddings", None)
+            module.model.load_state_dict(remove_duplicate_prefix(sd))
+            module.item_embeddings = None if items is None else torch.nn.Parameter(items.to(module.device), requires_grad=False)
+        tester = Trainer(precision="32-true", callbacks=self.callbacks, coalesce_tokens=self.coalesce_tokens)
+        tester.gemm_mode = self.gemm_mode
+        return tester.test(module, datamodule.test_dataloader())
+
+
 def get_data_module(model_type, batch_size, data_path, item_prompt, max_attribute_len, max_items, max_seq_len, model_tokenizer,
                     negative_sample_config, num_workers, reverse_sequence, sequence_prompt):
     """utils.py:137-175 (_get_data_module): the Recformer datamodule for the RECFORMER* model types, the text one otherwise."""

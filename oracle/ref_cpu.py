@@ -617,3 +617,70 @@ def forward_distill(reps: torch.Tensor, item_embeddings, score_embeddings, datas
         logit = reps[i] @ item_embeddings[ds].T
         losses.append(loss(logit.unsqueeze(0), score_embeddings[ds][sid].unsqueeze(0)))
     return torch.stack(losses).mean()
+
+
+# --------------------------------------------------------------------------------------------
+# fine-tuning (finetune_train.py): negative-sampling scores, loss, optimizer groups, schedule, AdamW
+# pinned by tests/golden/g9_finetune.pt (oracle/gen_golden_finetune.py ran the reference's RecModule)
+# --------------------------------------------------------------------------------------------
+def negative_sample_scores(user: torch.Tensor, target: torch.Tensor, negatives: Optional[torch.Tensor], mode: str,
+                           k: Optional[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """module/recommender/module.py:79-131 on already encoded + normalised rows -> (scores, labels)."""
+    B = user.shape[0]
+    if mode == "IN_BATCH":  # :92-94
+        return user @ target.T, torch.arange(B)
+    assert negatives is not None, "negative_batch must not be None"
+    neg = negatives.reshape(B, k, -1)
+    if mode == "SAMPLE":  # :96-109: [target | own negatives], label 0
+        allenc = torch.cat((target.unsqueeze(1), neg), dim=1)
+        return torch.bmm(user.unsqueeze(1), allenc.transpose(1, 2)).squeeze(1), torch.zeros(B, dtype=torch.long)
+    if mode == "IN_BATCH_SAMPLE":  # :111-126: [every target of the batch | own negatives], label = row
+        own = torch.bmm(user.unsqueeze(1), neg.transpose(1, 2)).squeeze(1)
+        return torch.cat((user @ target.T, own), dim=1), torch.arange(B)
+    raise ValueError(f"Invalid negative sample mode: {mode}")
+
+
+def finetune_loss(scores: torch.Tensor, labels: torch.Tensor, temperature: float = 0.05) -> torch.Tensor:
+    """module.py:183: cross_entropy(scores / temperature, labels)."""
+    return F.cross_entropy(scores / temperature, labels)
+
+
+def optimizer_groups(names: Sequence[str], weight_decay: float) -> "OrderedDict[str, float]":
+    """module.py:45-56: weight decay per parameter name -- 0 for names containing "bias" or "LayerNorm.weight"."""
+    no_decay = ("bias", "LayerNorm.weight")
+    return OrderedDict((n, 0.0 if any(nd in n for nd in no_decay) else weight_decay) for n in names)
+
+
+def resolve_warmup(warmup_steps, estimated_stepping_batches: int):
+    """module.py:58-63: a float is a fraction of all optimizer steps, an int a step count."""
+    if isinstance(warmup_steps, float):
+        return estimated_stepping_batches * warmup_steps
+    if isinstance(warmup_steps, int):
+        return warmup_steps
+    raise ValueError(f"Invalid warmup_steps type {type(warmup_steps)}")
+
+
+def linear_warmup_multiplier(step: int, num_warmup_steps, num_training_steps) -> float:
+    """transformers.get_linear_schedule_with_warmup (module.py:66-70), the lambda of its LambdaLR: the multiplier in force for the
+    optimizer step taken after ``step`` earlier ones."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
+
+
+def clip_coefficient(grads: Sequence[torch.Tensor], max_norm: float) -> torch.Tensor:
+    """torch.nn.utils.clip_grad_norm_ (Lightning's gradient_clip_val, finetune_train.py:106): min(1, max_norm / (||g||_2 + 1e-6))."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads]))
+    return torch.clamp(max_norm / (total + 1e-6), max=1.0)
+
+
+def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, weight_decay: float, step: int,
+               betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """torch.optim.AdamW (module.py:65), single-tensor update, in place on p, m, v; ``step`` counts from 1."""
+    b1, b2 = betas
+    p.mul_(1 - lr * weight_decay)
+    m.lerp_(g, 1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))

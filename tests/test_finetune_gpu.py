@@ -1,0 +1,244 @@
+"""Fine-tuning path on the GPU (finetune_train.py): fused AdamW arena step, differentiable score GEMM + row cross entropy,
+RecModule.training_step and the FinetuneTrainer loop, against the reference-pinned golden g9_finetune.pt and torch autograd
+through the CPU oracle."""
+import sys
+from collections import OrderedDict
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from tests.conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_arena_adamw_replays_reference_optimizer():
+    """the reference's configure_optimizers() (AdamW groups + warm-up schedule) + Lightning's clipping, recorded step by step in g9:
+    the fused arena kernel fed the same gradients lands on the same parameters and learning rates"""
+    from mergerec_amd.engine import ArenaLayout
+    from mergerec_amd.optim import ArenaAdamW
+
+    for c in load_golden("g9_finetune.pt")["optim"]:
+        layout = ArenaLayout(OrderedDict((k, tuple(v.shape)) for k, v in c["init"].items()))
+        flat = layout.pack(c["init"], DEV)
+        warm = O.resolve_warmup(c["warmup_steps"], c["estimated_stepping_batches"])
+        opt = ArenaAdamW(flat, layout, lr=c["learning_rate"], weight_decay=c["weight_decay"], betas=c["betas"], eps=c["eps"],
+                         num_warmup_steps=warm, num_training_steps=c["estimated_stepping_batches"], max_grad_norm=c["gradient_clip_val"])
+        for s, rec in enumerate(c["steps"]):
+            lr = opt.step(layout.pack(rec["grads"], DEV))
+            assert all(abs(lr - x) <= 1e-12 for x in rec["lr"]), (s, lr, rec["lr"])
+            got = layout.views(flat)
+            for k, want in rec["params"].items():
+                torch.testing.assert_close(got[k].cpu(), want, rtol=2e-6, atol=2e-7, msg=lambda e: f"step {s} {k}: {e}")
+
+
+def test_adamw_large_arena_matches_torch_and_rejects_bad_arguments():
+    """P ~ 3.3 M in 40 ragged segments with alternating decay, 3 steps with clipping, against torch.optim.AdamW on the CPU"""
+    from mergerec_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(0)
+    sizes = [int(x) * 64 for x in torch.randint(1, 2600, (40,), generator=g)]
+    seg_off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int64)
+    seg_wd = torch.tensor([0.05 if i % 2 == 0 else 0.0 for i in range(40)])
+    n = int(seg_off[-1])
+    p0 = torch.randn(n, generator=g)
+    ps = [p0[seg_off[i]:seg_off[i + 1]].clone().requires_grad_(True) for i in range(40)]
+    ref = torch.optim.AdamW([{"params": [ps[i] for i in range(0, 40, 2)], "weight_decay": 0.05},
+                             {"params": [ps[i] for i in range(1, 40, 2)], "weight_decay": 0.0}], lr=3e-3)
+    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * (10.0 if step == 2 else 0.01)
+        for i, q in enumerate(ps):
+            q.grad = grad[seg_off[i]:seg_off[i + 1]].clone()
+        norm = torch.nn.utils.clip_grad_norm_(ps, 1.0)
+        ref.step()
+        gd = grad.to(DEV)
+        ss = ops.sum_squares(gd)
+        assert abs(float(ss.sqrt()) - float(norm)) <= 1e-4 * float(norm)
+        ops.adamw_step(p, gd, m, v, lr=3e-3, step=step, seg_off=seg_off.to(DEV), seg_wd=seg_wd.to(DEV), grad_sumsq=ss, max_grad_norm=1.0)
+        torch.testing.assert_close(p.cpu(), torch.cat([q.detach() for q in ps]), rtol=2e-5, atol=2e-6)
+    lib = _lib.load()
+    bad = lib.mr_adamw_step_f32(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, 0.0, None)
+    assert bad == -1  # MR_EINVAL: step counts from 1
+    bad = lib.mr_adamw_step_f32(p.data_ptr() + 4, gd.data_ptr(), m.data_ptr(), v.data_ptr(), n - 4, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None, 0.0, None)
+    assert bad == -2  # MR_EALIGN
+
+
+def test_score_gemm_and_row_cross_entropy_gradients():
+    from mergerec_amd.autograd import cross_entropy_rows, matmul_nt
+
+    g = torch.Generator().manual_seed(4)
+    for n, m, d in [(6, 6, 64), (64, 64, 768), (5, 333, 128)]:
+        A, B = torch.randn(n, d, generator=g) / d ** 0.5, torch.randn(m, d, generator=g) / d ** 0.5
+        labels = torch.randint(0, m, (n,), generator=g)
+        a, b = A.clone().requires_grad_(True), B.clone().requires_grad_(True)
+        want = O.finetune_loss(a @ b.T, labels, 0.05)
+        want.backward()
+        ad, bd = A.to(DEV).requires_grad_(True), B.to(DEV).requires_grad_(True)
+        got = cross_entropy_rows(matmul_nt(ad, bd) / 0.05, labels.to(DEV))
+        got.backward()
+        torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(ad.grad.cpu(), a.grad, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-4, atol=1e-6)
+
+
+class _FixedReps(torch.nn.Module):
+    """stands where the encoder stands: hands back preset rows (with an autograd edge) for whatever batch arrives"""
+
+    def __init__(self, reps):
+        super().__init__()
+        self.reps = reps
+        self.spec = type("S", (), {"pad_id": 1})()
+        self.tokenizer = None
+
+    def forward_with_grad(self, batch):
+        assert batch["input_ids"].shape[0] == self.reps.shape[0]
+        return self.reps
+
+
+def test_negative_sampling_modes_match_reference_scores():
+    """RecModule._forward_negative_sample / training_step on the reference's recorded (normalised) representations"""
+    from mergerec_amd.configs import NegativeSampleConfig
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.model_batch import BatchSequenceWithNegative
+    from mergerec_amd.module import RecModule
+
+    ids = lambda n: {"input_ids": torch.ones(n, 3, dtype=torch.int64), "attention_mask": torch.ones(n, 3, dtype=torch.int64)}
+    for c in load_golden("g9_finetune.pt")["scores"]:
+        B, k = c["user"].shape[0], c["k"]
+        parts = [c["user"], c["target"]] + ([c["negatives"]] if k is not None else [])
+        reps_cpu = torch.cat(parts).clone().requires_grad_(True)
+        s_ref, l_ref = O.negative_sample_scores(reps_cpu[:B], reps_cpu[B:2 * B], reps_cpu[2 * B:] if k is not None else None, c["mode"], k)
+        O.finetune_loss(s_ref, l_ref, c["temperature"]).backward()
+        reps = torch.cat(parts).to(DEV).requires_grad_(True)
+        ns = NegativeSampleConfig(k=k, in_batch=c["mode"].startswith("IN_BATCH"))
+        assert ns.mode.name == c["mode"]
+        mod = RecModule(model=_FixedReps(reps), evaluator=Evaluator(["NDCG"], [1]), negative_sample=ns, similarity="dot", temperature=c["temperature"])
+        mod.train()
+        batch = BatchSequenceWithNegative(sequence=ids(B), target=ids(B), negatives=ids(B * k) if k is not None else None)
+        scores, labels = mod.forward(batch)
+        assert torch.equal(labels.cpu(), c["labels"])
+        torch.testing.assert_close(scores.detach().cpu(), c["scores"], rtol=0, atol=5e-7)
+        loss = mod.training_step(batch, 0)
+        torch.testing.assert_close(loss.detach().cpu(), c["loss"], rtol=2e-6, atol=2e-6)
+        loss.backward()
+        torch.testing.assert_close(reps.grad.cpu(), reps_cpu.grad, rtol=1e-4, atol=1e-6)
+
+
+def _tiny_blair(seed=3):
+    from mergerec_amd.module import ModelType
+
+    over = dict(hidden=128, heads=2, layers=2, intermediate=256, vocab=300, max_pos=130)
+    return ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": seed, "spec_overrides": over, "device": DEV, "gemm_mode": "f32"}), over
+
+
+def _toy_tokens(B, L, vocab, g):
+    lens = torch.randint(3, L + 1, (B,), generator=g)
+    ids = torch.randint(3, vocab, (B, L), generator=g)
+    ids[:, 0] = 0
+    mask = (torch.arange(L).view(1, L) < lens.view(B, 1)).long()
+    ids = ids * mask + (1 - mask)
+    return {"input_ids": ids, "attention_mask": mask}
+
+
+def test_training_steps_match_oracle_autograd_and_adamw():
+    """three optimizer steps (accumulation 2, clipping, warm-up, weight decay) of in-batch fine-tuning on a tiny BLaIR: loss per
+    micro-step and every parameter after every step against torch autograd through the oracle encoder + the oracle's AdamW"""
+    from mergerec_amd.configs import NegativeSampleConfig
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.model_batch import BatchSequenceWithNegative
+    from mergerec_amd.module import RecModule
+
+    model, over = _tiny_blair()
+    cfg = O.EncoderConfig(hidden=128, heads=2, layers=2, intermediate=256, vocab=300, max_pos=130)
+    T, LR, WD, CLIP, ACC, TOTAL, WARM = 0.05, 2e-3, 0.01, 0.5, 2, 6, 2
+    mod = RecModule(model=model, evaluator=Evaluator(["NDCG"], [10]), negative_sample=NegativeSampleConfig(in_batch=True), similarity="cosine",
+                    temperature=T, learning_rate=LR, warmup_steps=WARM, weight_decay=WD)
+    mod.trainer = type("Tr", (), {"estimated_stepping_batches": TOTAL, "gradient_clip_val": CLIP})()
+    opt = mod.configure_optimizers()
+    leaf = model.train_leaf()
+    mod.train()
+    # CPU side
+    p = OrderedDict((k, v.detach().cpu().clone().requires_grad_(not k.endswith("position_ids"))) for k, v in model.state_dict().items())
+    wd = O.optimizer_groups(list(p), WD)
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
+    g = torch.Generator().manual_seed(21)
+    for step in range(3):
+        for micro in range(ACC):
+            seq, tgt = _toy_tokens(8, 40, 300, g), _toy_tokens(8, 12, 300, g)
+            u = O.maybe_normalize(O.roberta_encode(p, seq["input_ids"], seq["attention_mask"], cfg, prefix="model."))
+            t = O.maybe_normalize(O.roberta_encode(p, tgt["input_ids"], tgt["attention_mask"], cfg, prefix="model."))
+            s_ref, l_ref = O.negative_sample_scores(u, t, None, "IN_BATCH", None)
+            want = O.finetune_loss(s_ref, l_ref, T)
+            (want / ACC).backward()
+            loss = mod.training_step(BatchSequenceWithNegative(sequence=seq, target=tgt).to(DEV), micro)
+            (loss / ACC).backward()
+            torch.testing.assert_close(loss.detach().cpu(), want.detach(), rtol=2e-4, atol=2e-4)
+        lr = opt.step(leaf.grad)
+        leaf.grad = None
+        assert abs(lr - LR * O.linear_warmup_multiplier(step, WARM, TOTAL)) < 1e-15
+        trainable = [k for k, q in p.items() if q.requires_grad and q.grad is not None]
+        coef = O.clip_coefficient([p[k].grad for k in trainable], CLIP)
+        with torch.no_grad():
+            for k in trainable:
+                O.adamw_step(p[k], p[k].grad * coef, m[k], v2[k], lr, wd[k], step + 1)
+                p[k].grad = None
+        got = model.state_dict()
+        lr_sum = sum(LR * O.linear_warmup_multiplier(s_, WARM, TOTAL) for s_ in range(step + 1))
+        for k in p:
+            # Adam normalises every coordinate's step to ~lr: a coordinate whose gradient is pure rounding noise (key biases: softmax is
+            # shift invariant) may move by +-lr in either implementation, so the per-coordinate bound is 2 sum(lr) ...
+            err = float((got[k].cpu() - p[k].detach()).abs().max())
+            assert err <= 2.05 * lr_sum + 1e-7, (step, k, err)
+        # ... and the check with teeth is the mean deviation over all trained coordinates, a small fraction of one step
+        diff = torch.cat([(got[k].cpu() - p[k].detach()).reshape(-1) for k in trainable])
+        assert float(diff.abs().mean()) <= 0.02 * LR, float(diff.abs().mean())
+
+
+def test_finetune_train_cli_end_to_end(tmp_path):
+    """finetune_train.py on the mini JSON dataset with the local tokenizer: in-batch fine-tuning lowers the training loss, writes the
+    best checkpoint in the layout scripts/extract.py reads, and the extracted state_dict loads through finetune_test.py"""
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import finetune_test
+    import finetune_train
+    from mergerec_amd.engine import EncoderSpec
+    from mergerec_amd.module import models
+
+    root = tmp_path / "run"
+    argv = ["--model_type", "blair_base", "--model_kwargs", "init_seed", "7", "--tokenizer_path", str(GOLDEN / "mini_tokenizer"),
+            "--data_path", str(GOLDEN / "mini_dataset"), "--batch_size", "8", "--negative_sample.in_batch", "--temperature", "0.05",
+            "--warmup_steps", "2", "--learning_rate", "1e-3", "--gradient_accumulation_steps", "2", "--gradient_clip_val", "1.0",
+            "--max_epochs", "3", "--max_seq_len", "96", "--max_attribute_len", "12", "--max_items", "20", "--precision", "32-true",
+            "--log_every_n_steps", "1", "--default_root_dir", str(root), "--lora.enable", "False"]
+    old = models.BLaIRBase.SPEC
+    models.BLaIRBase.SPEC = staticmethod(lambda: EncoderSpec(hidden=128, heads=2, layers=2, intermediate=256, vocab=50265, max_pos=514))
+    try:
+        trainer, metrics = finetune_train.main(argv)
+        hist = trainer.history
+        assert trainer.current_epoch >= 1 and len(hist) >= 4 and all(x == x for x in hist)
+        first, lastq = sum(hist[:2]) / 2, sum(hist[-2:]) / 2
+        assert lastq < first, (first, lastq)  # memorising a 40-user training set with lr 1e-3: the loss must fall
+        assert trainer.lr_history[0] == 0.0 and max(trainer.lr_history) <= 1e-3
+        assert set(metrics[0]) >= {"test/NDCG@10", "test/Recall@50", "test/loss"}
+        ckpt = trainer.best_model_path
+        assert ckpt is not None and ckpt.exists() and ckpt.parent.name == "checkpoints" and ckpt.name.startswith("epoch_")
+        assert len(list(ckpt.parent.glob("*.ckpt"))) == 1  # save_top_k = 1
+        sd = torch.load(ckpt, map_location="cpu")["state_dict"]
+        assert "item_embeddings" in sd and all(k.startswith("model.model.") for k in sd if k != "item_embeddings")
+        # scripts/extract.py -> state_dict.pt -> finetune_test.py gives the test metrics of the best checkpoint again
+        sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "scripts"))
+        import extract
+
+        out = tmp_path / "extracted"
+        extract.extract_checkpoint(ckpt, out)
+        again = finetune_test.main(["--model_type", "blair_base", "--model_kwargs", "init_seed", "7", "--finetune_checkpoint_path",
+                                    str(out / "state_dict.pt"), "--data_path", str(GOLDEN / "mini_dataset"), "--tokenizer_path",
+                                    str(GOLDEN / "mini_tokenizer"), "--batch_size", "8", "--max_seq_len", "96", "--max_attribute_len", "12",
+                                    "--max_items", "20"])
+        assert abs(again[0]["test/NDCG@10"] - metrics[0]["test/NDCG@10"]) <= 1e-6
+    finally:
+        models.BLaIRBase.SPEC = staticmethod(old)

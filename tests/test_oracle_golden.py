@@ -168,3 +168,35 @@ def test_forward_distill_matches_reference():
     (g,) = torch.autograd.grad(loss, reps)
     assert torch.allclose(loss, f["value"], rtol=1e-6)
     assert torch.allclose(g, f["rep_grad"], rtol=1e-5, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------- fine-tuning (g9: the reference's RecModule)
+def test_negative_sample_scores_match_reference():
+    """module.py:79-131, 183: scores / labels / loss of the three negative-sampling modes"""
+    for c in load_golden("g9_finetune.pt")["scores"]:
+        scores, labels = O.negative_sample_scores(c["user"], c["target"], c["negatives"], c["mode"], c["k"])
+        assert torch.equal(labels, c["labels"]), c["mode"]
+        torch.testing.assert_close(scores, c["scores"], rtol=0, atol=2e-7)
+        torch.testing.assert_close(O.finetune_loss(scores, labels, c["temperature"]), c["loss"], rtol=1e-6, atol=1e-6)
+
+
+def test_optimizer_groups_schedule_and_adamw_match_reference():
+    """module.py:44-72 driven like Lightning drives it: groups, warm-up schedule, clip, AdamW -- replayed from the recorded gradients"""
+    for c in load_golden("g9_finetune.pt")["optim"]:
+        names = list(c["init"].keys())
+        wd = O.optimizer_groups(names, c["weight_decay"])
+        for grp_names, grp_wd in zip(c["group_names"], c["group_weight_decay"]):
+            assert all(wd[n] == grp_wd for n in grp_names), (grp_names, grp_wd)
+        warm = O.resolve_warmup(c["warmup_steps"], c["estimated_stepping_batches"])
+        p = OrderedDict((n, t.clone()) for n, t in c["init"].items())
+        m = OrderedDict((n, torch.zeros_like(t)) for n, t in p.items())
+        v = OrderedDict((n, torch.zeros_like(t)) for n, t in p.items())
+        for s, rec in enumerate(c["steps"]):
+            lr = c["learning_rate"] * O.linear_warmup_multiplier(s, warm, c["estimated_stepping_batches"])
+            assert all(abs(lr - x) <= 1e-12 for x in rec["lr"]), (s, lr, rec["lr"])
+            coef = 1.0
+            if c["gradient_clip_val"] is not None:
+                coef = O.clip_coefficient(list(rec["grads"].values()), c["gradient_clip_val"])
+            for n in names:
+                O.adamw_step(p[n], rec["grads"][n] * coef, m[n], v[n], lr, wd[n], s + 1, c["betas"], c["eps"])
+                torch.testing.assert_close(p[n], rec["params"][n], rtol=1e-6, atol=1e-7, msg=lambda e: f"step {s} {n}: {e}")
