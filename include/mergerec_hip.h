@@ -290,17 +290,21 @@ int mr_gemm_nt_splitk_f32(const float* A, int64_t lda, const float* W, const flo
 /* out[c][r] = in[r][c] (r < R, c < C); columns R .. R_pad - 1 of every output row are zero-filled (ldo >= R_pad). */
 int mr_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int64_t ldo, int R_pad, mr_stream_t stream);
 
-/* out[c] = sum_r x[r][c], rows in ascending order (bias gradients). */
-int mr_colsum_f32(const float* x, int64_t ldx, int R, int C, float* out, mr_stream_t stream);
+/* out[c] = sum_r x[r][c] (bias gradients): fixed summation order -- 8 interleaved row lanes per 256-row chunk, chunks ascending.
+ * ws: mr_colsum_ws_bytes(R, C) bytes (0 when R <= 256: then ws may be NULL). */
+size_t mr_colsum_ws_bytes(int R, int C);
+int mr_colsum_f32(const float* x, int64_t ldx, int R, int C, float* out, void* ws, size_t ws_bytes, mr_stream_t stream);
 
 /* h = gelu_erf(u) (the training forward keeps the pre-activation u);  du = dh * d/du gelu_erf(u). */
 int mr_gelu_fwd_f32(const float* u, int64_t n, float* h, mr_stream_t stream);
 int mr_gelu_bwd_f32(const float* u, const float* dh, int64_t n, float* du, mr_stream_t stream);
 
 /* LayerNorm backward over the last dimension: dx (T, d); stats (T, 2) receives (mean, rstd) of x; dgamma / dbeta (d) may both
- * be NULL.  x is the LayerNorm INPUT. */
+ * be NULL.  x is the LayerNorm INPUT.  ws: mr_layernorm_bwd_ws_bytes(T, d) bytes for the parameter gradients' row-chunk partials
+ * (0 when T <= 256 or dgamma == NULL). */
+size_t mr_layernorm_bwd_ws_bytes(int T, int d);
 int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ldy, const float* gamma, float eps, int T, int d,
-                         float* dx, int64_t lddx, float* stats, float* dgamma, float* dbeta, mr_stream_t stream);
+                         float* dx, int64_t lddx, float* stats, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mr_stream_t stream);
 
 /* Softmax self-attention backward on packed sequences: qkv (T, 3 H dh) = [Q | K | V] and ctx (T, H dh) as in mr_attn_f32,
  * dctx = d loss / d ctx; rowstat (T, H, 2) is workspace; dqkv (T, 3 H dh) receives [dQ | dK | dV].  dh must be 64.
@@ -317,6 +321,17 @@ int mr_attn_global_row_bwd_f32(const float* qg, const float* kvg, const float* c
 /* table[idx[t]][:] += src[t][:] (atomic adds: embedding-table gradients; with unique indices a plain row scatter). */
 int mr_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int T, int d, float* table, int64_t ldt,
                             mr_stream_t stream);
+
+/* Split-K form of the bf16x3 GEMM for one pre-split, k-blocked weight (hi / mid piece arenas, element offset `off`):
+ * C = A W^T (+ bias) (+ R), K cut into `splits` chunks (multiples of 32) computed by separate workgroups, partial products summed in
+ * chunk order from `ws` (mr_gemm_nt_bf16x3_splitk_ws_bytes).  N % 4 == 0, K % 16 == 0.  For the fine-tuning weight gradients
+ * dW = dY^T X (outputs of a few dozen tiles, K = number of tokens).
+ * replaces: the weight-gradient products of torch autograd through transformers' Linear layers (encoder/_base.py:37 under
+ * module/recommender/module.py:168-189). */
+size_t mr_gemm_nt_bf16x3_splitk_ws_bytes(int M, int N, int splits);
+int mr_gemm_nt_bf16x3_splitk_f32(const float* A, int64_t lda, const uint16_t* w_hi, const uint16_t* w_mid, int64_t off, const float* bias,
+                                 int M, int N, int K, const float* R, int64_t ldr, float* C, int64_t ldc, int splits, void* ws,
+                                 size_t ws_bytes, mr_stream_t stream);
 
 /* ---- fine-tuning (finetune_train.py): the optimizer step over the parameter arena ------------- */
 

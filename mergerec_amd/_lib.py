@@ -49,13 +49,17 @@ SIGNATURES = {
     "mr_gemm_nt_splitk_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "mr_gemm_nt_splitk_f32": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_i, c_p, c_sz, c_p]),
     "mr_transpose_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_i64, c_i, c_p]),
-    "mr_colsum_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
+    "mr_colsum_ws_bytes": (c_sz, [c_i, c_i]),
+    "mr_colsum_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_sz, c_p]),
     "mr_gelu_fwd_f32": (c_i, [c_p, c_i64, c_p, c_p]),
     "mr_gelu_bwd_f32": (c_i, [c_p, c_p, c_i64, c_p, c_p]),
-    "mr_layernorm_bwd_f32": (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_f, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "mr_layernorm_bwd_ws_bytes": (c_sz, [c_i, c_i]),
+    "mr_layernorm_bwd_f32": (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_f, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "mr_attn_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p]),
     "mr_attn_global_row_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
     "mr_scatter_add_rows_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_p, c_i64, c_p]),
+    "mr_gemm_nt_bf16x3_splitk_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "mr_gemm_nt_bf16x3_splitk_f32": (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_i, c_p, c_sz, c_p]),
     "mr_adamw_step_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i, c_d, c_d, c_d, c_d, c_d, c_i64, c_p, c_f, c_p]),
     "mr_pack_tokens": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mr_embed_gather_ln_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p]),

@@ -41,23 +41,40 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
-// out[c] = sum_r x[r][c].  Workgroup = 32 columns x 8 row lanes (rows r = lane, lane + 8, ...), partials combined in a fixed
-// order through LDS: deterministic, with 8 x shorter serial loops on 8 x more workgroups than one thread per column.
-constexpr int kColW = 32, kRowL = kThreads / kColW;
+// out[c] = sum_r x[r][c].  Workgroup = 32 columns x 8 row lanes over one chunk of kRowsPerChunk rows (rows r = lane, lane + 8, ...),
+// partials combined in a fixed order through LDS.  Tall matrices (token-sized: fine-tuning batches) are cut into row chunks whose
+// partial sums go to a workspace and are added in chunk order by a second launch: deterministic, and R / 256 x more workgroups.
+constexpr int kColW = 32, kRowL = kThreads / kColW, kRowsPerChunk = 256;
+static inline int row_chunks(int R) { return R > 0 ? (R + kRowsPerChunk - 1) / kRowsPerChunk : 1; }
+
 __global__ __launch_bounds__(kThreads) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int R, int C, float* __restrict__ out) {
     __shared__ float part[kRowL][kColW];
     const int cl = threadIdx.x % kColW, rl = threadIdx.x / kColW;
     const int c = blockIdx.x * kColW + cl;
+    const int r0 = blockIdx.y * kRowsPerChunk, r1 = (r0 + kRowsPerChunk < R) ? r0 + kRowsPerChunk : R;
     float s = 0.f;
     if (c < C)
-        for (int r = rl; r < R; r += kRowL) s += x[(int64_t)r * ldx + c];
+        for (int r = r0 + rl; r < r1; r += kRowL) s += x[(int64_t)r * ldx + c];
     part[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < C) {
         float t = part[0][cl];
 #pragma unroll
         for (int k = 1; k < kRowL; ++k) t += part[k][cl];
-        out[c] = t;
+        out[(int64_t)blockIdx.y * C + c] = t;
+    }
+}
+
+// out[j][c] = sum over chunks (ascending) of part[j][chunk][c], j < nout
+__global__ __launch_bounds__(kThreads) void chunk_reduce_kernel(const float* __restrict__ part, int nchunk, int C, int nout, float* __restrict__ out0,
+                                                               float* __restrict__ out1) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    for (int j = 0; j < nout; ++j) {
+        const float* p = part + (int64_t)j * nchunk * C + c;
+        float t = p[0];
+        for (int k = 1; k < nchunk; ++k) t += p[(int64_t)k * C];
+        (j == 0 ? out0 : out1)[c] = t;
     }
 }
 
@@ -118,16 +135,18 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_rows_kernel(const floa
     }
 }
 
-// dgamma[c] = sum_t dy[t][c] * xhat[t][c], dbeta[c] = sum_t dy[t][c]; 32 columns x 8 row lanes per workgroup, fixed-order LDS combine
+// dgamma[c] = sum_t dy[t][c] * xhat[t][c], dbeta[c] = sum_t dy[t][c]; 32 columns x 8 row lanes per workgroup and row chunk,
+// fixed-order LDS combine; outputs indexed [chunk][c] (chunk_reduce_kernel adds the chunks when there is more than one)
 __global__ __launch_bounds__(kThreads) void layernorm_bwd_params_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
                                                                        int64_t ldy, const float* __restrict__ stats, int T, int d,
                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ float pg[kRowL][kColW], pb[kRowL][kColW];
     const int cl = threadIdx.x % kColW, rl = threadIdx.x / kColW;
     const int c = blockIdx.x * kColW + cl;
+    const int t0 = blockIdx.y * kRowsPerChunk, t1 = (t0 + kRowsPerChunk < T) ? t0 + kRowsPerChunk : T;
     float g = 0.f, b = 0.f;
     if (c < d)
-        for (int t = rl; t < T; t += kRowL) {
+        for (int t = t0 + rl; t < t1; t += kRowL) {
             const float dyv = dy[(int64_t)t * ldy + c];
             g += dyv * (x[(int64_t)t * ldx + c] - stats[2 * t]) * stats[2 * t + 1];
             b += dyv;
@@ -139,8 +158,8 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_params_kernel(const fl
         float tg = pg[0][cl], tb = pb[0][cl];
 #pragma unroll
         for (int k = 1; k < kRowL; ++k) { tg += pg[k][cl]; tb += pb[k][cl]; }
-        dgamma[c] = tg;
-        dbeta[c] = tb;
+        dgamma[(int64_t)blockIdx.y * d + c] = tg;
+        dbeta[(int64_t)blockIdx.y * d + c] = tb;
     }
 }
 
@@ -423,10 +442,20 @@ extern "C" int mr_transpose_f32(const float* in, int64_t ldi, int R, int C, floa
     return mr::check_launch();
 }
 
-extern "C" int mr_colsum_f32(const float* x, int64_t ldx, int R, int C, float* out, mr_stream_t stream) {
+extern "C" size_t mr_colsum_ws_bytes(int R, int C) {
+    const int n = row_chunks(R);
+    return (n > 1 && C > 0) ? (size_t)n * C * sizeof(float) : 0;
+}
+
+extern "C" int mr_colsum_f32(const float* x, int64_t ldx, int R, int C, float* out, void* ws, size_t ws_bytes, mr_stream_t stream) {
     if (!x || !out || R < 0 || C < 0 || ldx < C) return MR_EINVAL;
     if (C == 0) return MR_OK;
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + kColW - 1) / kColW), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, R, C, out);
+    const int n = row_chunks(R);
+    if (n > 1 && (!ws || ws_bytes < mr_colsum_ws_bytes(R, C))) return MR_EWS;
+    float* part = n > 1 ? reinterpret_cast<float*>(ws) : out;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + kColW - 1) / kColW, n), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, R, C, part);
+    if (n > 1)
+        hipLaunchKernelGGL(chunk_reduce_kernel, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, part, n, C, 1, out, out);
     return mr::check_launch();
 }
 
@@ -448,8 +477,14 @@ extern "C" int mr_gelu_bwd_f32(const float* u, const float* dh, int64_t n, float
     return mr::check_launch();
 }
 
+extern "C" size_t mr_layernorm_bwd_ws_bytes(int T, int d) {
+    const int n = row_chunks(T);
+    return (n > 1 && d > 0) ? (size_t)2 * n * d * sizeof(float) : 0;
+}
+
 extern "C" int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ldy, const float* gamma, float eps, int T, int d,
-                                    float* dx, int64_t lddx, float* stats, float* dgamma, float* dbeta, mr_stream_t stream) {
+                                    float* dx, int64_t lddx, float* stats, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                    mr_stream_t stream) {
     if (!x || !dy || !gamma || !dx || !stats || T < 0 || d < 1 || ldx < d || ldy < d || lddx < d) return MR_EINVAL;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return MR_EINVAL;
     if (T == 0) {
@@ -459,11 +494,19 @@ extern "C" int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy
         }
         return mr::check_launch();
     }
+    const int n = row_chunks(T);
+    if (dgamma && n > 1 && (!ws || ws_bytes < mr_layernorm_bwd_ws_bytes(T, d))) return MR_EWS;
     hipLaunchKernelGGL(layernorm_bwd_rows_kernel, dim3((T + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, (hipStream_t)stream, x,
                        ldx, dy, ldy, gamma, eps, T, d, dx, lddx, stats);
-    if (dgamma)
-        hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3((d + kColW - 1) / kColW), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, dy,
-                           ldy, stats, T, d, dgamma, dbeta);
+    if (dgamma) {
+        float* pg = n > 1 ? reinterpret_cast<float*>(ws) : dgamma;
+        float* pb = n > 1 ? pg + (size_t)n * d : dbeta;
+        hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3((d + kColW - 1) / kColW, n), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, dy,
+                           ldy, stats, T, d, pg, pb);
+        if (n > 1)
+            hipLaunchKernelGGL(chunk_reduce_kernel, dim3((d + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, pg, n, d, 2, dgamma,
+                               dbeta);
+    }
     return mr::check_launch();
 }
 

@@ -99,13 +99,15 @@ __global__ __launch_bounds__(kThreads) void split_weights_kblock_kernel(const fl
 // NP = number of bf16 pieces per operand: 3 -> six products (fp32-grade, ~2^-24), 2 -> three products hi*hi + hi*lo + lo*hi (~2^-16)
 // NT = MFMA tiles along N per wave: 2 -> 128x128 block tile (3 workgroups/CU), 4 -> 128x256 block tile (wave tile 64x128:
 // twice the MFMAs per barrier / LDS read / A byte; 128 accumulator VGPRs, 2 workgroups/CU)
-template <int ACT, bool HAS_R, bool PF2, int NP, int NT>
+// SK (split-K, training weight gradients: small outputs, token-deep K): blockIdx.y owns k in [y * kchunk, min(K, (y + 1) * kchunk))
+// and writes its partial product to C + y * split_stride; the caller adds the partials (splitk_sum_kernel).
+template <int ACT, bool HAS_R, bool PF2, int NP, int NT, bool SK = false>
 __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_kernel(
     const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ wh, const uint16_t* __restrict__ wm_,
     const uint16_t* __restrict__ wl, int64_t off0, int64_t off1, int64_t off2, const float* __restrict__ b0,
     const float* __restrict__ b1, const float* __restrict__ b2, int M, int seg_n, int K,
     const float* __restrict__ R, int64_t ldr, float* __restrict__ C, int64_t ldc, int tiles_n_seg, int tiles_n,
-    int nwg, int group_n, int tiles_m) {
+    int nwg, int group_n, int tiles_m, int kchunk = 0, int64_t split_stride = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUF bytes
     constexpr int BN = 64 * NT;                 // 128 or 256 columns per workgroup
     constexpr int BPIECE = (BN / 128) * PIECE;  // bytes of one B piece tile
@@ -124,8 +126,15 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
     const int seg = tn / tiles_n_seg;
     const int n0 = (tn - seg * tiles_n_seg) * BN;
     const int m0 = tm * BM;
-    const int64_t woff = seg == 0 ? off0 : (seg == 1 ? off1 : off2);
+    int64_t woff = seg == 0 ? off0 : (seg == 1 ? off1 : off2);
     const float* __restrict__ bias = seg == 0 ? b0 : (seg == 1 ? b1 : b2);
+    if (SK) {  // this workgroup's k range: shift the operand origins, shorten K
+        const int kbeg = blockIdx.y * kchunk;
+        A += kbeg;
+        woff += (int64_t)kbeg * seg_n;  // k-blocked: advancing k by one block of 16 skips N * 16 elements
+        C += (int64_t)blockIdx.y * split_stride;
+        K = (K - kbeg) < kchunk ? (K - kbeg) : kchunk;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -379,6 +388,30 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
     MR_PH_FLUSH(pid)
 }
 
+// C[m][n] = sum over splits (ascending) of part[s][m][n] (+ bias[n]) (+ R[m][n]); one float4 per thread, N % 4 == 0
+__global__ __launch_bounds__(kThreads) void splitk_sum_kernel(const float* __restrict__ part, int splits, int64_t split_stride, int M, int N,
+                                                             const float* __restrict__ bias, const float* __restrict__ R, int64_t ldr,
+                                                             float* __restrict__ C, int64_t ldc) {
+    const int nq = N >> 2;
+    const int64_t total = (int64_t)M * nq;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int m = (int)(e / nq), n = (int)(e - (int64_t)m * nq) * 4;
+        const float* p = part + (int64_t)m * N + n;
+        float4 a = *reinterpret_cast<const float4*>(p);
+        for (int s = 1; s < splits; ++s) {
+            const float4 b = *reinterpret_cast<const float4*>(p + (int64_t)s * split_stride);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (bias) { a.x += bias[n]; a.y += bias[n + 1]; a.z += bias[n + 2]; a.w += bias[n + 3]; }
+        float* c = C + (int64_t)m * ldc + n;
+        if (R) {
+            const float* r = R + (int64_t)m * ldr + n;
+            a.x += r[0]; a.y += r[1]; a.z += r[2]; a.w += r[3];
+        }
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
+    }
+}
+
 }  // namespace
 
 extern "C" int mr_split_bf16x3_f32(const float* x, int64_t n, uint16_t* hi, uint16_t* mid, uint16_t* lo,
@@ -480,5 +513,57 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
 #undef MR_GEMM_LAUNCH3
 #undef MR_GEMM_LAUNCH4
 #undef MR_GEMM_LAUNCH5
+    return mr::check_launch();
+}
+
+// ---- split-K variant of the bf16x3 GEMM (one weight segment, no activation): C = A W^T (+ bias) (+ R) with K cut into `splits`
+// chunks whose partial products meet in `ws` and are added in chunk order.  For the fine-tuning weight gradients dW = dY^T X:
+// outputs of a few dozen tiles, K = the number of tokens.
+extern "C" size_t mr_gemm_nt_bf16x3_splitk_ws_bytes(int M, int N, int splits) {
+    if (M < 0 || N < 1 || splits < 1) return 0;
+    return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int mr_gemm_nt_bf16x3_splitk_f32(const float* A, int64_t lda, const uint16_t* w_hi, const uint16_t* w_mid, int64_t off,
+                                            const float* bias, int M, int N, int K, const float* R, int64_t ldr, float* C, int64_t ldc,
+                                            int splits, void* ws, size_t ws_bytes, mr_stream_t stream) {
+    if (!A || !w_hi || !w_mid || !C || M < 0 || N < 1 || K < 1 || splits < 1) return MR_EINVAL;
+    if (splits == 1)
+        return mr_gemm_nt_bf16x6_f32(A, lda, w_hi, w_mid, w_hi, off, 0, 0, bias, nullptr, nullptr, 1, M, N, K, MR_ACT_NONE, R, ldr, C, ldc, 3, stream);
+    if ((K % BK) || (N & 3)) return MR_EUNSUPPORTED;
+    if ((lda & 3) || !mr::aligned16(A) || !mr::aligned16(w_hi) || !mr::aligned16(w_mid) || (off & 7)) return MR_EALIGN;
+    if (!ws || ws_bytes < mr_gemm_nt_bf16x3_splitk_ws_bytes(M, N, splits) || !mr::aligned16(ws)) return MR_EWS;
+    if (M == 0) return MR_OK;
+    // chunk = a multiple of two k-tiles (the kernel's prefetch-distance-2 pipeline) covering K in `splits` pieces
+    int kchunk = ((K + splits - 1) / splits + 2 * BK - 1) / (2 * BK) * (2 * BK);
+    const int nsplit = (K + kchunk - 1) / kchunk;
+    const bool pf2 = ((K - (nsplit - 1) * kchunk) / BK) % 2 == 0;  // the last chunk may hold an odd number of k-tiles
+    const int tiles_m = (M + BM - 1) / BM;
+    const bool wide = (N % 256 == 0) && ((int64_t)tiles_m * (N / 256) * nsplit >= 512);
+    const int BN = wide ? 256 : 128;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    float* part = reinterpret_cast<float*>(ws);
+    const int64_t stride = (int64_t)M * N;
+    if (N > (1 << 21)) return MR_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+#define MR_SK_LAUNCH(PF2_, NT_)                                                                                                          \
+    do {                                                                                                                                 \
+        static bool attr_done = false;                                                                                                   \
+        if (!attr_done) {                                                                                                                \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<MR_ACT_NONE, false, PF2_, 2, NT_, true>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * PIECE + 3 * (NT_ / 2) * PIECE));                    \
+            attr_done = true;                                                                                                            \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<MR_ACT_NONE, false, PF2_, 2, NT_, true>), dim3(nwg, nsplit), dim3(kThreads),            \
+                           2 * (size_t)(3 * PIECE + 3 * (BN / 128) * PIECE), st, A, lda, w_hi, w_mid, w_hi, off, 0, 0, nullptr, nullptr,  \
+                           nullptr, M, N, K, nullptr, 0, part, (int64_t)N, tiles_n, tiles_n, nwg, tiles_n, tiles_m, kchunk, stride);      \
+    } while (0)
+    if (pf2) { if (wide) MR_SK_LAUNCH(true, 4); else MR_SK_LAUNCH(true, 2); }
+    else { if (wide) MR_SK_LAUNCH(false, 4); else MR_SK_LAUNCH(false, 2); }
+#undef MR_SK_LAUNCH
+    int64_t blocks = ((int64_t)M * (N / 4) + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, part, nsplit, stride, M, N, bias, R, ldr, C, ldc);
     return mr::check_launch();
 }

@@ -19,17 +19,100 @@ import torch
 from . import ops
 from .engine import ArenaLayout, EncoderSpec, PackedBatch
 
-__all__ = ["EncoderTrainGraph", "RobertaTrainGraph", "encode_with_grad"]
+__all__ = ["EncoderTrainGraph", "RobertaTrainGraph", "SplitWeights", "encode_with_grad"]
+
+_LINEARS = ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "intermediate.dense", "output.dense")
+
+
+def _pad32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+class SplitWeights:
+    """bf16 pieces of the weights for the "bf16x3" training graph (fine-tuning at token-sized batches): the k-blocked split of every
+    Linear weight W (forward, y = x W^T) and of its transpose (backward, dx = dy W), re-derived by ``refresh(flat)`` whenever the
+    arena changes (once per optimizer step: two split launches + one transpose per weight)."""
+
+    def __init__(self, spec: EncoderSpec, layout: ArenaLayout, prefix: str, device):
+        self.spec, self.layout, self.prefix = spec, layout, prefix
+        d, di = spec.hidden, spec.intermediate
+        rec = spec.kind == "recformer"
+        fwd_names = list(_LINEARS) + (["attention.self.query_global", "attention.self.key_global", "attention.self.value_global"] if rec else [])
+        ent = []
+        for l in range(spec.layers):
+            for n in fwd_names:
+                k = f"{prefix}encoder.layer.{l}.{n}.weight"
+                ent.append((layout.offsets[k],) + tuple(layout.shapes[k]))
+        self.table = ops.KBlockTable(ent, device)
+        # transposed scratch: per layer [Wq; Wk; Wv]^T (d, 3d) | Wo^T (d, d) | W1^T (d, di) | W2^T (di, d) (| [Wkg; Wvg]^T (d, 2d))
+        self.t_off, ent_t, off = {}, [], 0
+        for l in range(spec.layers):
+            for key, (n, k) in (("qkv", (d, 3 * d)), ("attention.output.dense", (d, d)), ("intermediate.dense", (d, di)), ("output.dense", (di, d))) + (
+                    (("kvg", (d, 2 * d)),) if rec else ()):
+                self.t_off[(l, key)] = off
+                ent_t.append((off, n, k))
+                off += n * k
+        self.scratch = torch.zeros(off, dtype=torch.float32, device=device)
+        self.table_t = ops.KBlockTable(ent_t, device)
+        self.fwd = self.bwd = None
+        self.version = None
+
+    def refresh(self, flat: torch.Tensor, version=None):
+        if version is not None and version == self.version and self.fwd is not None:
+            return self
+        sp, p = self.spec, self.prefix
+        d, di = sp.hidden, sp.intermediate
+        w = self.layout.views(flat)
+        self.fwd = ops.split_weights_kblock(flat, self.table, self.fwd)
+        for l in range(sp.layers):
+            lp = f"{p}encoder.layer.{l}."
+            o = self.t_off[(l, "qkv")]
+            wt = self.scratch[o:o + d * 3 * d].view(d, 3 * d)
+            for k, n in enumerate(("query", "key", "value")):
+                ops.transpose_pad(w[f"{lp}attention.self.{n}.weight"], out=wt[:, k * d:(k + 1) * d])
+            for key, (r, c) in (("attention.output.dense", (d, d)), ("intermediate.dense", (d, di)), ("output.dense", (di, d))):
+                o = self.t_off[(l, key)]
+                ops.transpose_pad(w[lp + key + ".weight"], out=self.scratch[o:o + r * c].view(r, c))
+            if sp.kind == "recformer":
+                o = self.t_off[(l, "kvg")]
+                wt = self.scratch[o:o + d * 2 * d].view(d, 2 * d)
+                for k, n in enumerate(("key_global", "value_global")):
+                    ops.transpose_pad(w[f"{lp}attention.self.{n}.weight"], out=wt[:, k * d:(k + 1) * d])
+        self.bwd = ops.split_weights_kblock(self.scratch, self.table_t, self.bwd)
+        self.version = version
+        return self
 
 
 class EncoderTrainGraph:
-    def __init__(self, spec: EncoderSpec, layout: ArenaLayout, prefix: str = "model."):
+    """``mode``: "f32" -- every product through the exact-fp32 NT GEMM (merge_train's tiny batches; bit-comparable with the oracle);
+    "bf16x3" -- the split-precision MFMA GEMM of the inference path (three bf16 products per fp32 product, ~1e-6 relative) for the
+    token-sized batches of fine-tuning, with split-K weight gradients; needs ``split_weights`` (a refreshed SplitWeights)."""
+
+    def __init__(self, spec: EncoderSpec, layout: ArenaLayout, prefix: str = "model.", mode: str = "f32", split_weights: Optional[SplitWeights] = None):
         if spec.hidden // spec.heads != 64:
             raise ValueError("attention kernels are built for head_dim == 64")
+        if mode not in ("f32", "bf16x3"):
+            raise ValueError("training graph mode must be 'f32' or 'bf16x3'")
+        if mode == "bf16x3" and (split_weights is None or spec.hidden % 128):
+            raise ValueError("bf16x3 training needs SplitWeights and hidden % 128 == 0")
         self.spec, self.layout, self.prefix = spec, layout, prefix
+        self.mode, self.sw = mode, split_weights
         self.rec = spec.kind == "recformer"
         self.window = spec.one_sided_window if self.rec else -1
         self._saved = None
+
+    # ---------------------------------------------------------------------------------------------- products
+    def _linear(self, x, w, name: str, residual=None, out=None):
+        """x W^T + b for the Linear ``name`` (arena key without ".weight")."""
+        if self.mode == "f32":
+            return ops.gemm_nt_train(x, w[name + ".weight"], w[name + ".bias"], residual=residual, out=out)
+        n, k = self.layout.shapes[name + ".weight"]
+        return ops.gemm_nt_split(x, self.sw.fwd, [self.layout.offsets[name + ".weight"]], n, k, biases=[w[name + ".bias"]], residual=residual,
+                                 out=out, products=3)
+
+    def _tpad(self, x, out=None):
+        """token-major transpose: (T, C) -> (C, T_pad), pad columns zero (T_pad % 32 == 0 in bf16x3 mode: whole prefetch pairs)"""
+        return ops.transpose_pad(x, out=out, pad=32 if self.mode == "bf16x3" else 16)
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, flat: torch.Tensor, pb: PackedBatch) -> torch.Tensor:
@@ -49,38 +132,61 @@ class EncoderTrainGraph:
             lp = f"{p}encoder.layer.{l}."
             names = [f"{lp}attention.self.{n}" for n in ("query", "key", "value")]
             qkv = torch.empty(pb.T, 3 * sp.hidden, dtype=torch.float32, device=x.device)
-            for s, n in enumerate(names):
-                ops.gemm_nt_train(x, w[n + ".weight"], w[n + ".bias"], out=qkv[:, s * sp.hidden:(s + 1) * sp.hidden])
+            if self.mode == "f32":
+                for s, n in enumerate(names):
+                    ops.gemm_nt_train(x, w[n + ".weight"], w[n + ".bias"], out=qkv[:, s * sp.hidden:(s + 1) * sp.hidden])
+            else:  # one launch over the three weight segments
+                ops.gemm_nt_split(x, self.sw.fwd, [self.layout.offsets[n + ".weight"] for n in names], sp.hidden, sp.hidden,
+                                  biases=[w[n + ".bias"] for n in names], out=qkv, products=3)
             ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=self.window, seq_order=pb.seq_order, products=0)
             qg = kvg = None
             if self.rec:  # Longformer global row: CLS attends to every token through the *_global projections and overwrites ctx[cls]
                 x_cls = ops.gather_rows(x, pb.cls_rows)
-                qg = ops.gemm_nt_train(x_cls, w[f"{lp}attention.self.query_global.weight"], w[f"{lp}attention.self.query_global.bias"])
+                qg = self._linear(x_cls, w, f"{lp}attention.self.query_global")
                 kvg = torch.empty(pb.T, 2 * sp.hidden, dtype=torch.float32, device=x.device)
                 for s, n in enumerate(("key_global", "value_global")):
-                    ops.gemm_nt_train(x, w[f"{lp}attention.self.{n}.weight"], w[f"{lp}attention.self.{n}.bias"], out=kvg[:, s * sp.hidden:(s + 1) * sp.hidden])
+                    self._linear(x, w, f"{lp}attention.self.{n}", out=kvg[:, s * sp.hidden:(s + 1) * sp.hidden])
                 ops.attention_global_row(qg, kvg, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx)
-            a = ops.gemm_nt_train(ctx, w[lp + "attention.output.dense.weight"], w[lp + "attention.output.dense.bias"], residual=x)
+            a = self._linear(ctx, w, lp + "attention.output.dense", residual=x)
             h = ops.layernorm(a, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps)
-            u = ops.gemm_nt_train(h, w[lp + "intermediate.dense.weight"], w[lp + "intermediate.dense.bias"])
+            u = self._linear(h, w, lp + "intermediate.dense")
             i = ops.gelu_fwd(u)
-            o = ops.gemm_nt_train(i, w[lp + "output.dense.weight"], w[lp + "output.dense.bias"], residual=h)
+            o = self._linear(i, w, lp + "output.dense", residual=h)
             x_next = ops.layernorm(o, w[lp + "output.LayerNorm.weight"], w[lp + "output.LayerNorm.bias"], sp.ln_eps)
-            saved["layers"].append(dict(x=x, qkv=qkv, ctx=ctx, a=a, h=h, u=u, i=i, o=o, qg=qg, kvg=kvg))
+            saved["layers"].append(dict(x=x, qkv=qkv, ctx=ctx, a=a, h=h, u=u, i=i, o=o, qg=qg, kvg=kvg, l=l))
             x = x_next
         self._saved = saved
         return ops.gather_rows(x, pb.cls_rows)
 
     # ---------------------------------------------------------------------------------------------- backward
-    @staticmethod
-    def _dgrad(dy: torch.Tensor, W: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """dX = dY @ W (+ residual): the NT kernel on W^T."""
-        return ops.gemm_nt_train(dy, ops.transpose_pad(W), residual=residual)
+    def _dgrad(self, dy: torch.Tensor, w, l: int, key: str, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dX = dY @ W (+ residual) for layer l's Linear ``key`` ("qkv" / "kvg" = the stacked projections): the NT kernel on W^T."""
+        sp, d = self.spec, self.spec.hidden
+        if self.mode == "bf16x3":
+            n, k = {"qkv": (d, 3 * d), "kvg": (d, 2 * d), "attention.output.dense": (d, d), "intermediate.dense": (d, sp.intermediate),
+                    "output.dense": (sp.intermediate, d)}[key]
+            return ops.gemm_nt_split(dy, self.sw.bwd, [self.sw.t_off[(l, key)]], n, k, residual=residual, products=3)
+        lp = f"{self.prefix}encoder.layer.{l}."
+        if key in ("qkv", "kvg"):
+            names = ("query", "key", "value") if key == "qkv" else ("key_global", "value_global")
+            wt = torch.empty(d, len(names) * d, dtype=torch.float32, device=dy.device)  # [Wq; Wk; Wv]^T
+            for k, n in enumerate(names):
+                ops.transpose_pad(w[f"{lp}attention.self.{n}.weight"], out=wt[:, k * d:(k + 1) * d])
+            return ops.gemm_nt_train(dy, wt, residual=residual)
+        return ops.gemm_nt_train(dy, ops.transpose_pad(w[lp + key + ".weight"]), residual=residual)
 
-    @staticmethod
-    def _wgrad(dy_t: torch.Tensor, x_t: torch.Tensor, out: torch.Tensor):
+    def _xt(self, x: torch.Tensor):
+        """the token-major operand of a weight gradient, prepared once per activation: x^T (C, T_pad) and, in bf16x3 mode, its pieces"""
+        x_t = self._tpad(x)
+        return (x_t, ops.split_matrix_kblock(x_t)) if self.mode == "bf16x3" else (x_t, None)
+
+    def _wgrad(self, dy_t: torch.Tensor, xt, out: torch.Tensor):
         """dW = dY^T @ X written into ``out`` (a view of the gradient arena): both operands token-major transposed."""
-        ops.gemm_nt_train(dy_t, x_t, out=out)
+        x_t, pieces = xt
+        if pieces is None:
+            ops.gemm_nt_train(dy_t, x_t, out=out)
+        else:
+            ops.gemm_nt_split_k(dy_t, pieces, 0, x_t.shape[0], x_t.shape[1], out=out)
 
     def backward(self, d_cls: torch.Tensor) -> torch.Tensor:
         """d loss / d CLS rows (B, d) -> d loss / d parameters, flat, arena layout (pads zero)."""
@@ -101,53 +207,47 @@ class EncoderTrainGraph:
             do = ops.layernorm_bwd(s["o"], dx, w[lp + "output.LayerNorm.weight"], sp.ln_eps, g[lp + "output.LayerNorm.weight"],
                                    g[lp + "output.LayerNorm.bias"])
             # o = i W2^T + b2 + h
-            do_t = ops.transpose_pad(do)
             ops.colsum(do, g[lp + "output.dense.bias"])
-            self._wgrad(do_t, ops.transpose_pad(s["i"]), g[lp + "output.dense.weight"])
-            di = self._dgrad(do, w[lp + "output.dense.weight"])
+            self._wgrad(self._tpad(do), self._xt(s["i"]), g[lp + "output.dense.weight"])
+            di = self._dgrad(do, w, l, "output.dense")
             # i = gelu(u), u = h W1^T + b1
             du = ops.gelu_bwd(s["u"], di)
             ops.colsum(du, g[lp + "intermediate.dense.bias"])
-            h_t = ops.transpose_pad(s["h"])
-            self._wgrad(ops.transpose_pad(du), h_t, g[lp + "intermediate.dense.weight"])
-            dh = self._dgrad(du, w[lp + "intermediate.dense.weight"], residual=do)  # + the residual path of o
+            self._wgrad(self._tpad(du), self._xt(s["h"]), g[lp + "intermediate.dense.weight"])
+            dh = self._dgrad(du, w, l, "intermediate.dense", residual=do)  # + the residual path of o
             # h = LN1(a)
             da = ops.layernorm_bwd(s["a"], dh, w[lp + "attention.output.LayerNorm.weight"], sp.ln_eps,
                                    g[lp + "attention.output.LayerNorm.weight"], g[lp + "attention.output.LayerNorm.bias"])
             # a = ctx Wo^T + bo + x
             ops.colsum(da, g[lp + "attention.output.dense.bias"])
-            self._wgrad(ops.transpose_pad(da), ops.transpose_pad(s["ctx"]), g[lp + "attention.output.dense.weight"])
-            dctx = self._dgrad(da, w[lp + "attention.output.dense.weight"])
+            self._wgrad(self._tpad(da), self._xt(s["ctx"]), g[lp + "attention.output.dense.weight"])
+            dctx = self._dgrad(da, w, l, "attention.output.dense")
             dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window)
-            x_t = ops.transpose_pad(s["x"])
+            xt = self._xt(s["x"])
             if self.rec:
                 dqg, dkvg = ops.attention_global_row_bwd(s["qg"], s["kvg"], ops.gather_rows(s["ctx"], pb.cls_rows), ops.gather_rows(dctx, pb.cls_rows),
                                                          pb.cu_seqlens, pb.B, sp.heads)
                 # key_global / value_global read every token
-                dkvg_t = ops.transpose_pad(dkvg)
+                dkvg_t = self._tpad(dkvg)
                 bs2 = ops.colsum(dkvg)
-                wt2 = torch.empty(d, 2 * d, dtype=torch.float32, device=dx.device)
                 for k, n in enumerate(("key_global", "value_global")):
                     name = f"{lp}attention.self.{n}"
                     g[name + ".bias"].copy_(bs2[k * d:(k + 1) * d])
-                    self._wgrad(dkvg_t[k * d:(k + 1) * d], x_t, g[name + ".weight"])
-                    ops.transpose_pad(w[name + ".weight"], out=wt2[:, k * d:(k + 1) * d])
-                da = ops.gemm_nt_train(dkvg, wt2, residual=da)  # folded into the residual that the qkv d-grad below carries on
-                # query_global reads the CLS rows only
+                    self._wgrad(dkvg_t[k * d:(k + 1) * d], xt, g[name + ".weight"])
+                da = self._dgrad(dkvg, w, l, "kvg", residual=da)  # folded into the residual that the qkv d-grad below carries on
+                # query_global reads the CLS rows only (a handful of rows: the exact-fp32 kernel in either mode)
                 name = f"{lp}attention.self.query_global"
                 ops.colsum(dqg, g[name + ".bias"])
-                self._wgrad(ops.transpose_pad(dqg), ops.transpose_pad(ops.gather_rows(s["x"], pb.cls_rows)), g[name + ".weight"])
-                ops.scatter_add_rows(self._dgrad(dqg, w[name + ".weight"]), pb.cls_rows, da)
+                ops.gemm_nt_train(ops.transpose_pad(dqg), ops.transpose_pad(ops.gather_rows(s["x"], pb.cls_rows)), out=g[name + ".weight"])
+                ops.scatter_add_rows(ops.gemm_nt_train(dqg, ops.transpose_pad(w[name + ".weight"])), pb.cls_rows, da)
             # qkv = x [Wq; Wk; Wv]^T + b
-            dqkv_t = ops.transpose_pad(dqkv)  # (3 d, T_pad)
+            dqkv_t = self._tpad(dqkv)  # (3 d, T_pad)
             bsum = ops.colsum(dqkv)
-            wt = torch.empty(d, 3 * d, dtype=torch.float32, device=dx.device)  # [Wq; Wk; Wv]^T
             for k, n in enumerate(("query", "key", "value")):
                 name = f"{lp}attention.self.{n}"
                 g[name + ".bias"].copy_(bsum[k * d:(k + 1) * d])
-                self._wgrad(dqkv_t[k * d:(k + 1) * d], x_t, g[name + ".weight"])
-                ops.transpose_pad(w[name + ".weight"], out=wt[:, k * d:(k + 1) * d])
-            dx = ops.gemm_nt_train(dqkv, wt, residual=da)  # + the residual path of a
+                self._wgrad(dqkv_t[k * d:(k + 1) * d], xt, g[name + ".weight"])
+            dx = self._dgrad(dqkv, w, l, "qkv", residual=da)  # + the residual path of a
         # x0 = LN(emb), emb = word[ids] + pos[pos_ids] + type[0]
         e = p + "embeddings."
         de = ops.layernorm_bwd(sv["emb"], dx, w[e + "LayerNorm.weight"], sp.ln_eps, g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"])

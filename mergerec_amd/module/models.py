@@ -97,6 +97,7 @@ class BaseEncoderModel(nn.Module):
                 if tuple(sd[k].shape) != self.layout.shapes[k]:
                     raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {self.layout.shapes[k]}")
                 self._views[k].copy_(sd[k].to(self._views[k].device, torch.float32))
+        self.arena_changed()
         self._weights.refresh()
         return missing, unexpected
 
@@ -123,7 +124,8 @@ class BaseEncoderModel(nn.Module):
         self._weights.refresh()
 
     def weights_updated(self):
-        """The bound arena was rewritten in place (a merge): re-derive the bf16 pieces the GEMMs read."""
+        """The bound arena was rewritten in place (a merge, an optimizer step): re-derive the bf16 pieces the GEMMs read."""
+        self.arena_changed()
         self._weights.refresh()
 
     # -- forward ---------------------------------------------------------------------------------
@@ -141,11 +143,25 @@ class BaseEncoderModel(nn.Module):
             leaf = self._train_leaf = self._flat.detach().requires_grad_(True)
         return leaf
 
-    def forward_with_grad(self, batch) -> torch.Tensor:
-        """(B, d) CLS rows through the exact-fp32 training graph (engine_train.EncoderTrainGraph), differentiable w.r.t. ``train_leaf()``."""
-        from ..engine_train import EncoderTrainGraph, encode_with_grad
+    train_mode = "f32"  # "f32": exact-fp32 products; "bf16x3": split-precision MFMA products (fine-tuning at token-sized batches)
 
-        graph = EncoderTrainGraph(self.spec, self._weights.layout, prefix=self.runner.prefix)  # one per forward: it owns the saved activations
+    def arena_changed(self):
+        """The arena was rewritten in place (an optimizer step): derived weight forms are stale.  Cheap -- the training graph's bf16
+        pieces are re-derived lazily at the next forward; the inference path's are re-derived by ``weights_updated()``."""
+        self._arena_version = getattr(self, "_arena_version", 0) + 1
+
+    def forward_with_grad(self, batch) -> torch.Tensor:
+        """(B, d) CLS rows through the training graph (engine_train.EncoderTrainGraph), differentiable w.r.t. ``train_leaf()``."""
+        from ..engine_train import EncoderTrainGraph, SplitWeights, encode_with_grad
+
+        layout, sw = self._weights.layout, None
+        if self.train_mode == "bf16x3":
+            sw = getattr(self, "_split_weights", None)
+            if sw is None or sw.layout is not layout:
+                sw = self._split_weights = SplitWeights(self.spec, layout, self.runner.prefix, self.device)
+            sw.refresh(self._flat, (self._flat.data_ptr(), getattr(self, "_arena_version", 0)))
+        # one graph object per forward: it owns the saved activations
+        graph = EncoderTrainGraph(self.spec, layout, prefix=self.runner.prefix, mode=self.train_mode, split_weights=sw)
         return encode_with_grad(graph, self.train_leaf(), self.runner.pack(batch, self.device))
 
     def encode_normalized(self, batch, normalize: bool, lens=None, validate: bool = True) -> torch.Tensor:

@@ -484,11 +484,11 @@ def gemm_nt_train(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
-def transpose_pad(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """(R, C) -> (C, pad16(R)) with the pad columns zeroed: the K-contiguous operand layout of the NT GEMM."""
+def transpose_pad(x: torch.Tensor, out: Optional[torch.Tensor] = None, pad: int = 16) -> torch.Tensor:
+    """(R, C) -> (C, R padded to a multiple of ``pad``) with the pad columns zeroed: the K-contiguous operand layout of the NT GEMM."""
     _dev(x, "x", torch.float32)
     R, C = x.shape
-    Rp = _pad16(R)
+    Rp = (R + pad - 1) // pad * pad
     out = torch.empty(C, Rp, dtype=torch.float32, device=x.device) if out is None else out
     check(_lib.load().mr_transpose_f32(ptr(x), x.stride(0), R, C, ptr(out), out.stride(0), Rp, _stream(x)), "mr_transpose_f32")
     return out
@@ -498,7 +498,10 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(x, "x", torch.float32)
     R, C = x.shape
     out = torch.empty(C, dtype=torch.float32, device=x.device) if out is None else out
-    check(_lib.load().mr_colsum_f32(ptr(x), x.stride(0), R, C, ptr(out), _stream(x)), "mr_colsum_f32")
+    lib = _lib.load()
+    nbytes = lib.mr_colsum_ws_bytes(R, C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    check(lib.mr_colsum_f32(ptr(x), x.stride(0), R, C, ptr(out), ptr(ws), nbytes, _stream(x)), "mr_colsum_f32")
     return out
 
 
@@ -527,8 +530,11 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
     T, d = x.shape
     dx = torch.empty(T, d, dtype=torch.float32, device=x.device)
     stats = torch.empty(max(T, 1), 2, dtype=torch.float32, device=x.device)
-    check(_lib.load().mr_layernorm_bwd_f32(ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(gamma), eps, T, d, ptr(dx), dx.stride(0), ptr(stats),
-                                           ptr(dgamma), ptr(dbeta), _stream(x)), "mr_layernorm_bwd_f32")
+    lib = _lib.load()
+    nbytes = lib.mr_layernorm_bwd_ws_bytes(T, d) if dgamma is not None else 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    check(lib.mr_layernorm_bwd_f32(ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(gamma), eps, T, d, ptr(dx), dx.stride(0), ptr(stats),
+                                   ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _stream(x)), "mr_layernorm_bwd_f32")
     return dx
 
 
@@ -595,3 +601,45 @@ def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
                                         float(max_grad_norm), _stream(param)), "mr_adamw_step_f32")
     PROF.end(ev, param.device, "adamw_step", flops=0.0, nbytes=28.0 * n)
     return param
+
+
+# ------------------------------------------------------------------------------------------ bf16x3 products for the training graph
+_KB_TABLES = {}
+
+
+def split_matrix_kblock(x: torch.Tensor, pieces=None):
+    """One contiguous fp32 (N, K) matrix -> its (hi, mid, lo) bf16 pieces in the k-blocked layout the split GEMMs read
+    (``[K / 16][N][16]``).  K % 16 == 0."""
+    _dev(x, "x", torch.float32)
+    if x.dim() != 2 or not x.is_contiguous():
+        raise ValueError("x must be a contiguous (N, K) matrix")
+    N, K = x.shape
+    key = (N, K, x.device)
+    table = _KB_TABLES.get(key)
+    if table is None:
+        table = _KB_TABLES[key] = KBlockTable([(0, N, K)], x.device)
+    if pieces is None:
+        pieces = tuple(torch.empty(N * K, dtype=torch.bfloat16, device=x.device) for _ in range(3))
+    return split_weights_kblock(x.view(-1), table, pieces)
+
+
+def gemm_nt_split_k(A: torch.Tensor, pieces, off: int, N: int, K: int, bias: Optional[torch.Tensor] = None,
+                    residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, splits: Optional[int] = None) -> torch.Tensor:
+    """A (M, K) @ W.T for ONE pre-split k-blocked weight (N, K) at element offset ``off`` of ``pieces``, bf16x3, with K split over
+    workgroups when the output alone cannot fill the chip (weight gradients: K = tokens)."""
+    if A.dim() != 2 or A.stride(1) != 1 or A.shape[1] != K:
+        raise ValueError("A must be (M, K) with unit inner stride")
+    M = A.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device) if out is None else out
+    if splits is None:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        splits = max(1, min(K // 64, 64, 1024 // max(tiles, 1)))
+    lib = _lib.load()
+    nbytes = lib.mr_gemm_nt_bf16x3_splitk_ws_bytes(M, N, splits)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=A.device) if splits > 1 else None
+    ev = PROF.begin(A.device)
+    check(lib.mr_gemm_nt_bf16x3_splitk_f32(ptr(A), A.stride(0), ptr(pieces[0]), ptr(pieces[1]), off, ptr(bias), M, N, K, ptr(residual),
+                                           0 if residual is None else residual.stride(0), ptr(out), out.stride(0), splits, ptr(ws), nbytes,
+                                           _stream(A)), "mr_gemm_nt_bf16x3_splitk_f32")
+    PROF.end(ev, A.device, "gemm_nt_bf16x3_train", flops=2.0 * M * N * K, nbytes=4.0 * (M * K + M * N) + 4.0 * N * K)
+    return out

@@ -193,7 +193,10 @@ class FinetuneTrainer:
     def __init__(self, max_epochs: int, accumulate_grad_batches: int = 1, gradient_clip_val: Optional[float] = None, precision: str = "32-true",
                  callbacks: Sequence = (), monitor: str = "val/NDCG@10", patience: int = 5, default_root_dir="MergeRecFineTune",
                  log_every_n_steps: int = 50, coalesce_tokens: int = 65536, max_steps: Optional[int] = None, verbose: bool = True):
-        self.gemm_mode = precision_to_gemm_mode(precision)  # evaluation arithmetic; the training graph is exact fp32
+        # "32-true": exact-fp32 training graph, the model's own evaluation arithmetic; the reference's default "bf16-mixed" (autocast:
+        # 8-bit-mantissa products): bf16x3 split-precision products (fp32 accumulation, ~1e-6 relative) for training and evaluation
+        self.gemm_mode = precision_to_gemm_mode(precision)
+        self.train_mode = "f32" if self.gemm_mode is None else "bf16x3"
         self.max_epochs, self.max_steps = int(max_epochs), max_steps
         self.accumulate_grad_batches = max(1, int(accumulate_grad_batches))
         self.gradient_clip_val = gradient_clip_val
@@ -277,6 +280,8 @@ class FinetuneTrainer:
             self.estimated_stepping_batches = min(self.estimated_stepping_batches, self.max_steps)
         opt = self.optimizer = module.configure_optimizers()
         leaf = module.model.train_leaf()
+        if self.train_mode == "bf16x3" and module.model.spec.hidden % 128 == 0:
+            module.model.train_mode = "bf16x3"
         wait, stop = 0, False
         while not stop and self.current_epoch < self.max_epochs:
             module.train()
@@ -293,6 +298,7 @@ class FinetuneTrainer:
                 allreduce_mean_grads([leaf])
                 self.lr_history.append(opt.step(leaf.grad))
                 leaf.grad = None
+                module.model.arena_changed()
                 self.global_step += 1
                 if self.verbose and self.global_step % self.log_every_n_steps == 0:
                     print(f"epoch {self.current_epoch} step {self.global_step}: train/loss {float(self.history[-1]):.6f} lr {self.lr_history[-1]:.3e}",

@@ -33,6 +33,16 @@ def test_backward_kernels_match_torch():
     dx = ops.layernorm_bwd(xx.detach().to(DEV), dy.to(DEV), gam.detach().to(DEV), 1e-5, dg, db).cpu()
     assert torch.allclose(dx, xx.grad, atol=2e-5, rtol=1e-4)
     assert torch.allclose(dg.cpu(), gam.grad, atol=2e-5, rtol=1e-4) and torch.allclose(db.cpu(), bet.grad, atol=2e-5, rtol=1e-4)
+    # token-sized (fine-tuning) shapes: several 256-row chunks through the two-stage reductions
+    xt = torch.randn(1000, 100, generator=g)
+    assert torch.allclose(ops.colsum(xt.to(DEV)).cpu(), xt.sum(0), atol=1e-4)
+    xx = (torch.randn(777, 128, generator=g) * 3 + 1).requires_grad_(True)
+    dy = torch.randn(777, 128, generator=g)
+    gam.grad = bet.grad = None
+    torch.nn.functional.layer_norm(xx, (128,), gam, bet, 1e-5).backward(dy)
+    dx = ops.layernorm_bwd(xx.detach().to(DEV), dy.to(DEV), gam.detach().to(DEV), 1e-5, dg, db).cpu()
+    assert torch.allclose(dx, xx.grad, atol=2e-5, rtol=1e-4)
+    assert torch.allclose(dg.cpu(), gam.grad, atol=2e-4, rtol=1e-4) and torch.allclose(db.cpu(), bet.grad, atol=2e-4, rtol=1e-4)
     # scatter-add with repeated rows
     tab = torch.zeros(10, 64, device=DEV)
     idx = torch.tensor([3, 3, 9, 0, 3], dtype=torch.int32)
