@@ -1,0 +1,273 @@
+// Attention backward on the fp32 matrix cores (v_mfma_f32_32x32x2_f32): fine-tuning batches are token-sized (64 sequences of up
+// to 512 tokens per micro-step), where the per-thread FMA formulation spends 60 % of the step.
+//
+// qkv (T, 3 H 64) = [Q | K | V] as the forward; ctx, dctx (T, H 64); rowstat (T, H, 2) = (logsumexp of the scaled scores, delta);
+//     s_ij = scale q_i . k_j,  p_ij = exp(s_ij - lse_i),  delta_i = dO_i . O_i,  dS_ij = p_ij (dO_i . v_j - delta_i) scale
+//     dQ_i = sum_j dS_ij k_j      dK_j = sum_i dS_ij q_i      dV_j = sum_i p_ij dO_i
+// Longformer mode (window >= 0): query i sees key j iff j == 0 (global key) or |i - j| <= window; query row 0 belongs to the
+// global-row kernel and sees nothing here.
+//
+// Three launches over (128-row tile, head, sequence), four waves per workgroup, each wave owning 32 rows:
+//   stats   query-owned: S^T = K Q^T tile by tile -> online logsumexp per query (one lane per query, 16 keys per lane and step)
+//   dq      query-owned: S^T and dP^T = V dO^T  -> dS^T, which in the MFMA result layout IS the A operand of dQ += dS K
+//   dkv     key-owned:   S = Q K^T and dP = dO V^T -> P, dS, which in the result layout ARE the A operands of dV += P^T dO,
+//           dK += dS^T Q  (the k index of an MFMA may be enumerated in any order as long as both operands agree)
+// so no score tile is ever transposed or written anywhere.  The owned rows live in registers as B operands (k = d enumerated as
+// d = s + 32 * (lane / 32)); the other side's 32 x 64 tiles are staged in LDS with a 65-float pitch: rows along lanes and rows
+// along the k index are both conflict-free ds_read_b32.  Deterministic: every output element has one owner, fixed order.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kDh = 64;
+constexpr int kPitch = 65;
+constexpr int kTile = 32 * kPitch;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ bool allowed(int i, int j, int window) {
+    if (window < 0) return true;
+    if (i == 0) return false;
+    const int dlt = i - j;
+    return j == 0 || (dlt <= window && dlt >= -window);
+}
+// rows [r0, r0 + nr) against columns [c0, c0 + 32): can any (row, col) pair be allowed?
+__device__ __forceinline__ bool tile_needed(int r0, int nr, int c0, int window) {
+    if (window < 0 || c0 == 0) return true;
+    return c0 <= r0 + nr - 1 + window && c0 + 31 >= r0 - window;
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+// result-layout row of accumulator register i for this lane's half
+__device__ __forceinline__ int crow(int i, int lh) { return (i & 3) + 8 * (i >> 2) + 4 * lh; }
+
+// stage rows [row0, row0 + 32) x 64 floats of a (T, ld) matrix (column offset folded into src) into LDS, rows clamped to len - 1
+__device__ __forceinline__ void stage_tile(const float* __restrict__ src, int64_t ld, int row0, int len, float* __restrict__ dst) {
+    const int r = threadIdx.x >> 3, c = (threadIdx.x & 7) * 8;
+    int row = row0 + r;
+    row = row < len ? row : len - 1;
+    const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c);
+    const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c + 4);
+    float* d = dst + r * kPitch + c;
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+    d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+}
+
+// the owned 32 rows as an MFMA B operand: lane (lr, lh) holds row lr, d = s + 32 lh for s = 0 .. 31
+__device__ __forceinline__ void load_owned(const float* __restrict__ src, int64_t ld, int row, int lh, float (&reg)[32]) {
+    const float* p = src + (int64_t)row * ld + 32 * lh;
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + s);
+        reg[s] = v.x; reg[s + 1] = v.y; reg[s + 2] = v.z; reg[s + 3] = v.w;
+    }
+}
+
+// acc += T O^T: T = the staged tile (rows along lanes), O = the owned rows (registers)
+__device__ __forceinline__ f32x16 tile_times_owned(const float* __restrict__ tile, int lr, int lh, const float (&own)[32]) {
+    f32x16 acc = zero16();
+    const float* a = tile + lr * kPitch + 32 * lh;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], own[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- query-owned
+template <bool STATS>
+__global__ __launch_bounds__(kThreads, 2) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                                const float* __restrict__ dctx, const int32_t* __restrict__ cu, int H,
+                                                                float scale, int window, float* __restrict__ rowstat,
+                                                                float* __restrict__ dqkv) {
+    __shared__ float ks[kTile], vs[STATS ? 1 : kTile];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int t0 = cu[b], len = cu[b + 1] - t0;
+    const int Q0 = blockIdx.x * 128;
+    if (Q0 >= len) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
+    const float* Qb = qkv + (int64_t)t0 * ld + h * kDh;
+    const float* Kb = Qb + H * kDh;
+    const float* Vb = Qb + 2 * H * kDh;
+    const float* Gb = dctx + (int64_t)t0 * ldc + h * kDh;
+    const int q0 = Q0 + wave * 32, q = q0 + lr;
+    const bool q_on = q < len;
+    const int qc = q_on ? q : len - 1;
+    float qr[32], gr[STATS ? 1 : 32];
+    load_owned(Qb, ld, qc, lh, qr);
+    float lse = 0.f, dl = 0.f;
+    if constexpr (!STATS) {
+        load_owned(Gb, ldc, qc, lh, gr);
+        lse = rowstat[((int64_t)(t0 + qc) * H + h) * 2];
+        dl = rowstat[((int64_t)(t0 + qc) * H + h) * 2 + 1];
+    }
+    float m = -INFINITY, l = 0.f;
+    f32x16 dq0 = zero16(), dq1 = zero16();
+    for (int j0 = 0; j0 < len; j0 += 32) {
+        if (!tile_needed(Q0, 128, j0, window)) continue;  // uniform over the workgroup
+        __syncthreads();
+        stage_tile(Kb, ld, j0, len, ks);
+        if constexpr (!STATS) stage_tile(Vb, ld, j0, len, vs);
+        __syncthreads();
+        if (q0 >= len || !tile_needed(q0, 32, j0, window)) continue;  // uniform over the wave (no barrier below)
+        f32x16 st = tile_times_owned(ks, lr, lh, qr);  // S^T[key crow(i)][query lr]
+        if constexpr (STATS) {
+            float sv[16], tm = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = j0 + crow(i, lh);
+                const bool ok = key < len && allowed(q, key, window);
+                sv[i] = ok ? st[i] * scale : -INFINITY;
+                tm = fmaxf(tm, sv[i]);
+            }
+            if (tm > -INFINITY) {
+                const float mn = fmaxf(m, tm);
+                float add = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) add += __expf(sv[i] - mn);  // exp(-inf) = 0 for the masked ones
+                l = l * __expf(m - mn) + add;
+                m = mn;
+            }
+        } else {
+            f32x16 dpt = tile_times_owned(vs, lr, lh, gr);  // dP^T[key][query]
+            float ds[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = j0 + crow(i, lh);
+                const bool ok = key < len && allowed(q, key, window);
+                const float p = ok ? __expf(st[i] * scale - lse) : 0.f;
+                ds[i] = p * (dpt[i] - dl) * scale;
+            }
+            // dQ[query lr][d] += sum_key dS[query][key] K[key][d]: A = dS^T in its result layout, k = key crow(i, lh)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float* kr = ks + crow(i, lh) * kPitch + lr;
+                dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[i], kr[0], dq0, 0, 0, 0);
+                dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[i], kr[32], dq1, 0, 0, 0);
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // the two halves of a query's lane pair saw disjoint keys: merge, then delta = dO . O
+        const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+        const float M = fmaxf(m, m2);
+        float L = 0.f;
+        if (M > -INFINITY) L = l * __expf(m - M) + l2 * __expf(m2 - M);
+        const float* o = ctx + (int64_t)(t0 + qc) * ldc + h * kDh + 32 * lh;
+        const float* g = Gb + (int64_t)qc * ldc + 32 * lh;
+        float dsum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; s += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(o + s), c = *reinterpret_cast<const float4*>(g + s);
+            dsum += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+        }
+        dsum += __shfl_xor(dsum, 32, 64);
+        if (q_on && lh == 0) {
+            rowstat[((int64_t)(t0 + q) * H + h) * 2] = (L > 0.f) ? M + __logf(L) : 0.f;  // (no allowed key: the windowed mode's row 0)
+            rowstat[((int64_t)(t0 + q) * H + h) * 2 + 1] = dsum;
+        }
+    } else {
+        // result layout: row = query q0 + crow(i, lh), col = d lr (+ 32)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qq = q0 + crow(i, lh);
+            if (qq < len) {
+                float* o = dqkv + (int64_t)(t0 + qq) * ld + h * kDh + lr;
+                o[0] = dq0[i];
+                o[32] = dq1[i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ key-owned
+__global__ __launch_bounds__(kThreads, 2) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                                 const float* __restrict__ rowstat, const int32_t* __restrict__ cu, int H,
+                                                                 float scale, int window, float* __restrict__ dqkv) {
+    __shared__ float qs[kTile], gs[kTile], stat[32][2];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int t0 = cu[b], len = cu[b + 1] - t0;
+    const int K0 = blockIdx.x * 128;
+    if (K0 >= len) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
+    const float* Qb = qkv + (int64_t)t0 * ld + h * kDh;
+    const float* Kb = Qb + H * kDh;
+    const float* Vb = Qb + 2 * H * kDh;
+    const float* Gb = dctx + (int64_t)t0 * ldc + h * kDh;
+    const int k0 = K0 + wave * 32, key = k0 + lr;
+    const int kc = key < len ? key : len - 1;
+    float kr[32], vr[32];
+    load_owned(Kb, ld, kc, lh, kr);
+    load_owned(Vb, ld, kc, lh, vr);
+    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+    for (int i0 = 0; i0 < len; i0 += 32) {
+        // "needed" is symmetric in the band part; the global key 0 column makes every query tile needed for the first key tile
+        const bool wg_need = window < 0 || K0 == 0 || (i0 <= K0 + 127 + window && i0 + 31 >= K0 - window);
+        if (!wg_need) continue;
+        __syncthreads();
+        stage_tile(Qb, ld, i0, len, qs);
+        stage_tile(Gb, ldc, i0, len, gs);
+        if (threadIdx.x < 64) {
+            const int ir = threadIdx.x >> 1, i = i0 + ir < len ? i0 + ir : len - 1;
+            stat[ir][threadIdx.x & 1] = rowstat[((int64_t)(t0 + i) * H + h) * 2 + (threadIdx.x & 1)];
+        }
+        __syncthreads();
+        const bool w_need = window < 0 || k0 == 0 || (i0 <= k0 + 31 + window && i0 + 31 >= k0 - window);
+        if (k0 >= len || !w_need) continue;
+        f32x16 s = tile_times_owned(qs, lr, lh, kr);   // S[query crow(i)][key lr]
+        f32x16 dp = tile_times_owned(gs, lr, lh, vr);  // dP[query][key]
+        float p[16], ds[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = crow(i, lh), qi = i0 + r;
+            const bool ok = qi < len && allowed(qi, key, window);
+            p[i] = ok ? __expf(s[i] * scale - stat[r][0]) : 0.f;
+            ds[i] = p[i] * (dp[i] - stat[r][1]) * scale;
+        }
+        // dV[key lr][d] += sum_query P[query][key] dO[query][d];  dK[key][d] += sum_query dS[query][key] Q[query][d]
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = crow(i, lh);
+            const float* gr = gs + r * kPitch + lr;
+            const float* qr = qs + r * kPitch + lr;
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p[i], gr[0], dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p[i], gr[32], dv1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[i], qr[0], dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[i], qr[32], dk1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int kk = k0 + crow(i, lh);
+        if (kk < len) {
+            float* ok = dqkv + (int64_t)(t0 + kk) * ld + (H + h) * kDh + lr;
+            float* ov = dqkv + (int64_t)(t0 + kk) * ld + (2 * H + h) * kDh + lr;
+            ok[0] = dk0[i];
+            ok[32] = dk1[i];
+            ov[0] = dv0[i];
+            ov[32] = dv1[i];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, int B, int H, int dh,
+                               int max_len, float scale, int window, float* rowstat, float* dqkv, mr_stream_t stream) {
+    if (!qkv || !ctx || !dctx || !cu_seqlens || !rowstat || !dqkv || B < 0 || H < 1 || max_len < 0) return MR_EINVAL;
+    if (dh != kDh) return MR_EUNSUPPORTED;
+    if (!mr::aligned16(qkv) || !mr::aligned16(ctx) || !mr::aligned16(dctx)) return MR_EALIGN;
+    if (B == 0 || max_len == 0) return MR_OK;
+    if (H > 65535 || B > 65535) return MR_EUNSUPPORTED;
+    const dim3 grid((max_len + 127) / 128, H, B);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((attn_bwd_q_kernel<true>), grid, dim3(kThreads), 0, st, qkv, ctx, dctx, cu_seqlens, H, scale, window, rowstat, dqkv);
+    hipLaunchKernelGGL((attn_bwd_q_kernel<false>), grid, dim3(kThreads), 0, st, qkv, ctx, dctx, cu_seqlens, H, scale, window, rowstat, dqkv);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(kThreads), 0, st, qkv, dctx, rowstat, cu_seqlens, H, scale, window, dqkv);
+    return mr::check_launch();
+}

@@ -163,175 +163,6 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_params_kernel(const fl
     }
 }
 
-// ------------------------------------------------------------------------------------------------ attention backward
-// qkv (T, 3 H 64) = [Q | K | V] as the forward; ctx, dctx (T, H 64); rowstat (T, H, 2) = (logsumexp of the scaled scores, delta)
-// Longformer mode (window >= 0): query i sees key j iff j == 0 (global key) or |i - j| <= window, and query row 0 belongs to the
-// global-row kernel (its regular output is overwritten in the forward), so it sees nothing here.
-__device__ __forceinline__ bool attn_allowed(int i, int j, int window) {
-    if (window < 0) return true;
-    if (i == 0) return false;
-    const int dlt = i - j;
-    return j == 0 || (dlt <= window && dlt >= -window);
-}
-
-// One workgroup per (sequence, head).  Scores s_ij = scale * q_i . k_j, p_ij = exp(s_ij - lse_i), delta_i = dO_i . O_i,
-// dS_ij = p_ij (dO_i . v_j - delta_i):  dQ_i = scale sum_j dS_ij k_j;  dK_j = scale sum_i dS_ij q_i;  dV_j = sum_i p_ij dO_i.
-__global__ __launch_bounds__(kThreads) void attn_bwd_stats_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
-                                                                 const float* __restrict__ dctx, const int32_t* __restrict__ cu, int H,
-                                                                 float scale, int window, float* __restrict__ rowstat) {
-    __shared__ float ks[32][kDh];
-    const int b = blockIdx.x, h = blockIdx.y;
-    const int t0 = cu[b], len = cu[b + 1] - t0;
-    const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
-    for (int i0 = 0; i0 < len; i0 += kThreads) {
-        const int i = i0 + threadIdx.x;
-        const bool on = i < len;
-        const int ic = on ? i : len - 1;
-        const float* q = qkv + (int64_t)(t0 + ic) * ld + h * kDh;
-        float qr[kDh];
-#pragma unroll
-        for (int d = 0; d < kDh; ++d) qr[d] = q[d];
-        float m = -INFINITY, l = 0.f;
-        for (int j0 = 0; j0 < len; j0 += 32) {
-            __syncthreads();
-            for (int e = threadIdx.x; e < 32 * kDh; e += kThreads) {
-                const int jr = e / kDh, d = e % kDh;
-                const int j = j0 + jr < len ? j0 + jr : len - 1;
-                ks[jr][d] = qkv[(int64_t)(t0 + j) * ld + (H + h) * kDh + d];
-            }
-            __syncthreads();
-            const int nj = (len - j0) < 32 ? (len - j0) : 32;
-            for (int jr = 0; jr < nj; ++jr) {
-                if (!attn_allowed(ic, j0 + jr, window)) continue;
-                float s = 0.f;
-#pragma unroll
-                for (int d = 0; d < kDh; ++d) s = fmaf(qr[d], ks[jr][d], s);
-                s *= scale;
-                const float mn = fmaxf(m, s);
-                l = l * expf(m - mn) + expf(s - mn);
-                m = mn;
-            }
-        }
-        if (on) {
-            const float* o = ctx + (int64_t)(t0 + i) * ldc + h * kDh;
-            const float* g = dctx + (int64_t)(t0 + i) * ldc + h * kDh;
-            float dl = 0.f;
-#pragma unroll
-            for (int d = 0; d < kDh; ++d) dl = fmaf(o[d], g[d], dl);
-            rowstat[((int64_t)(t0 + i) * H + h) * 2] = (l > 0.f) ? m + logf(l) : 0.f;  // (no allowed key: the windowed mode's row 0)
-            rowstat[((int64_t)(t0 + i) * H + h) * 2 + 1] = dl;
-        }
-    }
-}
-
-// query-owned pass: thread i holds q_i, dO_i and accumulates dQ_i over all keys (keys / values staged through LDS in tiles of 32)
-__global__ __launch_bounds__(kThreads) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
-                                                              const float* __restrict__ rowstat, const int32_t* __restrict__ cu, int H,
-                                                              float scale, int window, float* __restrict__ dqkv) {
-    __shared__ float ks[32][kDh], vs[32][kDh];
-    const int b = blockIdx.x, h = blockIdx.y;
-    const int t0 = cu[b], len = cu[b + 1] - t0;
-    const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
-    for (int i0 = 0; i0 < len; i0 += kThreads) {
-        const int i = i0 + threadIdx.x;
-        const bool on = i < len;
-        const int ic = on ? i : len - 1;
-        float qr[kDh], gr[kDh], acc[kDh];
-        const float* q = qkv + (int64_t)(t0 + ic) * ld + h * kDh;
-        const float* g = dctx + (int64_t)(t0 + ic) * ldc + h * kDh;
-#pragma unroll
-        for (int d = 0; d < kDh; ++d) { qr[d] = q[d]; gr[d] = g[d]; acc[d] = 0.f; }
-        const float lse = rowstat[((int64_t)(t0 + ic) * H + h) * 2], dl = rowstat[((int64_t)(t0 + ic) * H + h) * 2 + 1];
-        for (int j0 = 0; j0 < len; j0 += 32) {
-            __syncthreads();
-            for (int e = threadIdx.x; e < 32 * kDh; e += kThreads) {
-                const int jr = e / kDh, d = e % kDh;
-                const int j = j0 + jr < len ? j0 + jr : len - 1;
-                ks[jr][d] = qkv[(int64_t)(t0 + j) * ld + (H + h) * kDh + d];
-                vs[jr][d] = qkv[(int64_t)(t0 + j) * ld + (2 * H + h) * kDh + d];
-            }
-            __syncthreads();
-            const int nj = (len - j0) < 32 ? (len - j0) : 32;
-            for (int jr = 0; jr < nj; ++jr) {
-                if (!attn_allowed(ic, j0 + jr, window)) continue;
-                float s = 0.f, dp = 0.f;
-#pragma unroll
-                for (int d = 0; d < kDh; ++d) {
-                    s = fmaf(qr[d], ks[jr][d], s);
-                    dp = fmaf(gr[d], vs[jr][d], dp);
-                }
-                const float ds = expf(s * scale - lse) * (dp - dl) * scale;
-#pragma unroll
-                for (int d = 0; d < kDh; ++d) acc[d] = fmaf(ds, ks[jr][d], acc[d]);
-            }
-        }
-        if (on) {
-            float* o = dqkv + (int64_t)(t0 + i) * ld + h * kDh;
-#pragma unroll
-            for (int d = 0; d < kDh; ++d) o[d] = acc[d];
-        }
-    }
-}
-
-// key-owned pass: a lane pair (2 j, 2 j + 1) owns key j, each lane one 32-wide half of d; queries staged through LDS
-__global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
-                                                               const float* __restrict__ rowstat, const int32_t* __restrict__ cu, int H,
-                                                               float scale, int window, float* __restrict__ dqkv) {
-    __shared__ float qs[32][kDh], gs[32][kDh], st[32][2];
-    const int b = blockIdx.x, h = blockIdx.y;
-    const int t0 = cu[b], len = cu[b + 1] - t0;
-    const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
-    const int half = threadIdx.x & 1, d0 = half * 32;
-    for (int jb = 0; jb < len; jb += kThreads / 2) {
-        const int j = jb + (threadIdx.x >> 1);
-        const bool on = j < len;
-        const int jc = on ? j : len - 1;
-        float kr[32], vr[32], dk[32], dv[32];
-        const float* k = qkv + (int64_t)(t0 + jc) * ld + (H + h) * kDh + d0;
-        const float* v = qkv + (int64_t)(t0 + jc) * ld + (2 * H + h) * kDh + d0;
-#pragma unroll
-        for (int d = 0; d < 32; ++d) { kr[d] = k[d]; vr[d] = v[d]; dk[d] = 0.f; dv[d] = 0.f; }
-        for (int i0 = 0; i0 < len; i0 += 32) {
-            __syncthreads();
-            for (int e = threadIdx.x; e < 32 * kDh; e += kThreads) {
-                const int ir = e / kDh, d = e % kDh;
-                const int i = i0 + ir < len ? i0 + ir : len - 1;
-                qs[ir][d] = qkv[(int64_t)(t0 + i) * ld + h * kDh + d];
-                gs[ir][d] = dctx[(int64_t)(t0 + i) * ldc + h * kDh + d];
-            }
-            if (threadIdx.x < 64) {
-                const int ir = threadIdx.x >> 1, i = i0 + ir < len ? i0 + ir : len - 1;
-                st[ir][threadIdx.x & 1] = rowstat[((int64_t)(t0 + i) * H + h) * 2 + (threadIdx.x & 1)];
-            }
-            __syncthreads();
-            const int ni = (len - i0) < 32 ? (len - i0) : 32;
-            for (int ir = 0; ir < ni; ++ir) {
-                float s = 0.f, dp = 0.f;
-#pragma unroll
-                for (int d = 0; d < 32; ++d) {
-                    s = fmaf(qs[ir][d0 + d], kr[d], s);
-                    dp = fmaf(gs[ir][d0 + d], vr[d], dp);
-                }
-                s += __shfl_xor(s, 1, 64);   // the pair's two halves of the dot products (same order in both lanes)
-                dp += __shfl_xor(dp, 1, 64);
-                const float p = attn_allowed(i0 + ir, jc, window) ? expf(s * scale - st[ir][0]) : 0.f;
-                const float ds = p * (dp - st[ir][1]) * scale;
-#pragma unroll
-                for (int d = 0; d < 32; ++d) {
-                    dk[d] = fmaf(ds, qs[ir][d0 + d], dk[d]);
-                    dv[d] = fmaf(p, gs[ir][d0 + d], dv[d]);
-                }
-            }
-        }
-        if (on) {
-            float* ok = dqkv + (int64_t)(t0 + j) * ld + (H + h) * kDh + d0;
-            float* ov = dqkv + (int64_t)(t0 + j) * ld + (2 * H + h) * kDh + d0;
-#pragma unroll
-            for (int d = 0; d < 32; ++d) { ok[d] = dk[d]; ov[d] = dv[d]; }
-        }
-    }
-}
-
 // Longformer global row backward: per (sequence, head) ONE query (qg, from query_global(x_cls)) against all keys / values of the
 // sequence (kvg = [key_global(x) | value_global(x)]).  dctx_cls (B, H 64) = d loss / d ctx[cls rows], ctx_cls the forward output.
 // Outputs dqg (B, H 64) and dkvg (T, 2 H 64).  One workgroup per (sequence, head), threads over keys.
@@ -507,19 +338,6 @@ extern "C" int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy
             hipLaunchKernelGGL(chunk_reduce_kernel, dim3((d + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, pg, n, d, 2, dgamma,
                                dbeta);
     }
-    return mr::check_launch();
-}
-
-extern "C" int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, int B, int H, int dh,
-                               float scale, int window, float* rowstat, float* dqkv, mr_stream_t stream) {
-    if (!qkv || !ctx || !dctx || !cu_seqlens || !rowstat || !dqkv || B < 0 || H < 1) return MR_EINVAL;
-    if (dh != kDh) return MR_EUNSUPPORTED;
-    if (B == 0) return MR_OK;
-    const dim3 grid(B, H);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_stats_kernel, grid, dim3(kThreads), 0, st, qkv, ctx, dctx, cu_seqlens, H, scale, window, rowstat);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(kThreads), 0, st, qkv, dctx, rowstat, cu_seqlens, H, scale, window, dqkv);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(kThreads), 0, st, qkv, dctx, rowstat, cu_seqlens, H, scale, window, dqkv);
     return mr::check_launch();
 }
 
