@@ -323,6 +323,10 @@ int mr_attn_global_row_bwd_f32(const float* qg, const float* kvg, const float* c
 int mr_scatter_add_rows_f32(const float* src, int64_t lds, const int32_t* idx, int T, int d, float* table, int64_t ldt,
                             mr_stream_t stream);
 
+/* Token-major activation x (T, C), row stride ldx -> the hi / mid bf16 pieces of x^T (C, T_pad) in the k-blocked layout
+ * [T_pad / 16][C][16] (tokens T .. T_pad - 1 zero): the pre-split operand of a weight gradient dW = dY^T x in one pass. */
+int mr_split_tokens_kblock_f32(const float* x, int64_t ldx, int T, int C, int T_pad, uint16_t* hi, uint16_t* mid, mr_stream_t stream);
+
 /* Split-K form of the bf16x3 GEMM for one pre-split, k-blocked weight (hi / mid piece arenas, element offset `off`):
  * C = A W^T (+ bias) (+ R), K cut into `splits` chunks (multiples of 32) computed by separate workgroups, partial products summed in
  * chunk order from `ws` (mr_gemm_nt_bf16x3_splitk_ws_bytes).  N % 4 == 0, K % 16 == 0.  For the fine-tuning weight gradients

@@ -96,6 +96,32 @@ __global__ __launch_bounds__(kThreads) void split_weights_kblock_kernel(const fl
     }
 }
 
+// Token-major activation x (T, C) -> the hi / mid pieces of x^T (C, T_pad) in the k-blocked layout, in ONE pass: the operand of a
+// weight gradient dW = dY^T x (k = tokens) without materialising the fp32 transpose.  One thread = one column c of one block of 16
+// tokens: 16 reads, each coalesced across the threads of a wave, and 32 contiguous bytes written per piece.  Tokens >= T are zeros.
+__global__ __launch_bounds__(kThreads) void split_tokens_kblock_kernel(const float* __restrict__ x, int64_t ldx, int T, int C,
+                                                                      uint16_t* __restrict__ hi, uint16_t* __restrict__ mid) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    const int t0 = blockIdx.y * 16;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (t0 + j < T) ? x[(int64_t)(t0 + j) * ldx + c] : 0.f;
+    uint32_t h[8], m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = pack2(v[2 * j], v[2 * j + 1]);
+        m[j] = pack2(v[2 * j] - lo_f(h[j]), v[2 * j + 1] - hi_f(h[j]));
+    }
+    const int64_t dst = ((int64_t)blockIdx.y * C + c) * 16;
+    uint4* ph = reinterpret_cast<uint4*>(hi + dst);
+    uint4* pm = reinterpret_cast<uint4*>(mid + dst);
+    ph[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    ph[1] = make_uint4(h[4], h[5], h[6], h[7]);
+    pm[0] = make_uint4(m[0], m[1], m[2], m[3]);
+    pm[1] = make_uint4(m[4], m[5], m[6], m[7]);
+}
+
 // NP = number of bf16 pieces per operand: 3 -> six products (fp32-grade, ~2^-24), 2 -> three products hi*hi + hi*lo + lo*hi (~2^-16)
 // NT = MFMA tiles along N per wave: 2 -> 128x128 block tile (3 workgroups/CU), 4 -> 128x256 block tile (wave tile 64x128:
 // twice the MFMAs per barrier / LDS read / A byte; 128 accumulator VGPRs, 2 workgroups/CU)
@@ -440,6 +466,18 @@ extern "C" int mr_split_weights_kblock_f32(const float* arena, const int64_t* ta
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(split_weights_kblock_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, arena, table,
                        unit_prefix, n_mat, hi, mid, lo);
+    return mr::check_launch();
+}
+
+extern "C" int mr_split_tokens_kblock_f32(const float* x, int64_t ldx, int T, int C, int T_pad, uint16_t* hi, uint16_t* mid,
+                                          mr_stream_t stream) {
+    if (!x || !hi || !mid || T < 0 || C < 1 || ldx < C || T_pad < T) return MR_EINVAL;
+    if (T_pad % 16) return MR_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(hi) & 15) || (reinterpret_cast<uintptr_t>(mid) & 15)) return MR_EALIGN;
+    if (T_pad == 0) return MR_OK;
+    if (T_pad / 16 > 65535) return MR_EUNSUPPORTED;
+    hipLaunchKernelGGL(split_tokens_kblock_kernel, dim3((C + kThreads - 1) / kThreads, T_pad / 16), dim3(kThreads), 0, (hipStream_t)stream, x,
+                       ldx, T, C, hi, mid);
     return mr::check_launch();
 }
 

@@ -138,7 +138,9 @@ class EncoderTrainGraph:
             else:  # one launch over the three weight segments
                 ops.gemm_nt_split(x, self.sw.fwd, [self.layout.offsets[n + ".weight"] for n in names], sp.hidden, sp.hidden,
                                   biases=[w[n + ".bias"] for n in names], out=qkv, products=3)
-            ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=self.window, seq_order=pb.seq_order, products=0)
+            # (bf16x3 mode: the split-precision attention of the inference path; its backward recomputes the probabilities in fp32)
+            ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=self.window, seq_order=pb.seq_order,
+                                products=3 if self.mode == "bf16x3" else 0)
             qg = kvg = None
             if self.rec:  # Longformer global row: CLS attends to every token through the *_global projections and overwrites ctx[cls]
                 x_cls = ops.gather_rows(x, pb.cls_rows)
@@ -176,9 +178,12 @@ class EncoderTrainGraph:
         return ops.gemm_nt_train(dy, ops.transpose_pad(w[lp + key + ".weight"]), residual=residual)
 
     def _xt(self, x: torch.Tensor):
-        """the token-major operand of a weight gradient, prepared once per activation: x^T (C, T_pad) and, in bf16x3 mode, its pieces"""
-        x_t = self._tpad(x)
-        return (x_t, ops.split_matrix_kblock(x_t)) if self.mode == "bf16x3" else (x_t, None)
+        """the token-major operand of a weight gradient, prepared once per activation: f32 mode x^T (C, T_pad); bf16x3 mode the bf16
+        pieces of x^T straight from x (no fp32 transpose)"""
+        if self.mode == "bf16x3":
+            pieces, t_pad = ops.split_tokens_kblock(x, pad=32)
+            return (x.shape[1], t_pad), pieces
+        return self._tpad(x), None
 
     def _wgrad(self, dy_t: torch.Tensor, xt, out: torch.Tensor):
         """dW = dY^T @ X written into ``out`` (a view of the gradient arena): both operands token-major transposed."""
@@ -186,7 +191,7 @@ class EncoderTrainGraph:
         if pieces is None:
             ops.gemm_nt_train(dy_t, x_t, out=out)
         else:
-            ops.gemm_nt_split_k(dy_t, pieces, 0, x_t.shape[0], x_t.shape[1], out=out)
+            ops.gemm_nt_split_k(dy_t, pieces, 0, x_t[0], x_t[1], out=out)
 
     def backward(self, d_cls: torch.Tensor) -> torch.Tensor:
         """d loss / d CLS rows (B, d) -> d loss / d parameters, flat, arena layout (pads zero)."""

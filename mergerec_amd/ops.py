@@ -627,6 +627,21 @@ def split_matrix_kblock(x: torch.Tensor, pieces=None):
     return split_weights_kblock(x.view(-1), table, pieces)
 
 
+def split_tokens_kblock(x: torch.Tensor, pad: int = 32):
+    """Token-major x (T, C) -> ((hi, mid) bf16 pieces of x^T in k-blocked form, T_pad): the weight-gradient operand without the fp32
+    transpose (mr_split_tokens_kblock_f32)."""
+    _dev(x, "x", torch.float32)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be (T, C) with unit inner stride")
+    T, C = x.shape
+    Tp = (T + pad - 1) // pad * pad
+    hi, mid = (torch.empty(C * Tp, dtype=torch.bfloat16, device=x.device) for _ in range(2))
+    ev = PROF.begin(x.device)
+    check(_lib.load().mr_split_tokens_kblock_f32(ptr(x), x.stride(0), T, C, Tp, ptr(hi), ptr(mid), _stream(x)), "mr_split_tokens_kblock_f32")
+    PROF.end(ev, x.device, "split_tokens", nbytes=8.0 * T * C)
+    return (hi, mid), Tp
+
+
 def gemm_nt_split_k(A: torch.Tensor, pieces, off: int, N: int, K: int, bias: Optional[torch.Tensor] = None,
                     residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, splits: Optional[int] = None) -> torch.Tensor:
     """A (M, K) @ W.T for ONE pre-split k-blocked weight (N, K) at element offset ``off`` of ``pieces``, bf16x3, with K split over

@@ -103,6 +103,19 @@ def test_splitk_bf16x3_gemm_matches_float64(M, N, K, splits):
     assert torch.equal(got, again)
 
 
+def test_fused_token_split_equals_transpose_then_split():
+    """x (T, C) -> k-blocked pieces of x^T in one pass == fp32 transpose + k-blocked split (bit-identical hi / mid pieces)"""
+    from mergerec_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    for T, C in [(37, 128), (1000, 768), (33, 300)]:
+        x = torch.randn(T, C, generator=g).to(DEV)
+        (hi, mid), t_pad = ops.split_tokens_kblock(x[:, :C], pad=32)
+        want = ops.split_matrix_kblock(ops.transpose_pad(x, pad=32))
+        assert t_pad == (T + 31) // 32 * 32
+        assert torch.equal(hi.view(torch.int16), want[0].view(torch.int16)) and torch.equal(mid.view(torch.int16), want[1].view(torch.int16))
+
+
 def test_bf16x3_training_graph_matches_exact_fp32_graph():
     """the fine-tuning arithmetic ("bf16-mixed" -> bf16x3 split products, split-K weight gradients) against the exact-fp32 graph:
     loss and the whole gradient arena on a tiny BLaIR at a token count that spans several reduction chunks"""
@@ -248,9 +261,11 @@ def test_training_steps_match_oracle_autograd_and_adamw():
         assert float(diff.abs().mean()) <= 0.02 * LR, float(diff.abs().mean())
 
 
-def test_finetune_train_cli_end_to_end(tmp_path):
-    """finetune_train.py on the mini JSON dataset with the local tokenizer: in-batch fine-tuning lowers the training loss, writes the
-    best checkpoint in the layout scripts/extract.py reads, and the extracted state_dict loads through finetune_test.py"""
+@pytest.mark.parametrize("kind", ["blair_base", "recformer_base"])
+def test_finetune_train_cli_end_to_end(tmp_path, kind):
+    """finetune_train.py (scripts/1_finetune/blair_base.sh / recformer_base.sh) on the mini JSON dataset with the local tokenizer:
+    in-batch fine-tuning lowers the training loss, writes the best checkpoint in the layout scripts/extract.py reads, and the
+    extracted state_dict loads through finetune_test.py"""
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
     import finetune_test
     import finetune_train
@@ -258,13 +273,19 @@ def test_finetune_train_cli_end_to_end(tmp_path):
     from mergerec_amd.module import models
 
     root = tmp_path / "run"
-    argv = ["--model_type", "blair_base", "--model_kwargs", "init_seed", "7", "--tokenizer_path", str(GOLDEN / "mini_tokenizer"),
+    argv = ["--model_type", kind, "--model_kwargs", "init_seed", "7", "--tokenizer_path", str(GOLDEN / "mini_tokenizer"),
             "--data_path", str(GOLDEN / "mini_dataset"), "--batch_size", "8", "--negative_sample.in_batch", "--temperature", "0.05",
             "--warmup_steps", "2", "--learning_rate", "1e-3", "--gradient_accumulation_steps", "2", "--gradient_clip_val", "1.0",
             "--max_epochs", "3", "--max_seq_len", "96", "--max_attribute_len", "12", "--max_items", "20", "--precision", "bf16-mixed",
             "--log_every_n_steps", "1", "--default_root_dir", str(root), "--lora.enable", "False"]
-    old = models.BLaIRBase.SPEC
-    models.BLaIRBase.SPEC = staticmethod(lambda: EncoderSpec(hidden=128, heads=2, layers=2, intermediate=256, vocab=50265, max_pos=514))
+    cls = models.BLaIRBase if kind == "blair_base" else models.RecformerBase
+    old = cls.SPEC
+    tiny = dict(hidden=128, heads=2, layers=2, intermediate=256, vocab=50265)
+    if kind == "blair_base":
+        cls.SPEC = staticmethod(lambda: EncoderSpec(max_pos=514, **tiny))
+    else:
+        cls.SPEC = staticmethod(lambda: EncoderSpec(kind="recformer", max_pos=4098, token_type_size=4, max_item_embeddings=51, one_sided_window=32,
+                                                    pooler=False, **tiny))
     try:
         trainer, metrics = finetune_train.main(argv)
         hist = trainer.history
@@ -284,10 +305,10 @@ def test_finetune_train_cli_end_to_end(tmp_path):
 
         out = tmp_path / "extracted"
         extract.extract_checkpoint(ckpt, out)
-        again = finetune_test.main(["--model_type", "blair_base", "--model_kwargs", "init_seed", "7", "--finetune_checkpoint_path",
+        again = finetune_test.main(["--model_type", kind, "--model_kwargs", "init_seed", "7", "--finetune_checkpoint_path",
                                     str(out / "state_dict.pt"), "--data_path", str(GOLDEN / "mini_dataset"), "--tokenizer_path",
                                     str(GOLDEN / "mini_tokenizer"), "--batch_size", "8", "--max_seq_len", "96", "--max_attribute_len", "12",
                                     "--max_items", "20"])
         assert abs(again[0]["test/NDCG@10"] - metrics[0]["test/NDCG@10"]) <= 1e-6
     finally:
-        models.BLaIRBase.SPEC = staticmethod(old)
+        cls.SPEC = staticmethod(old)
