@@ -295,6 +295,9 @@ int mr_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int
 size_t mr_colsum_ws_bytes(int R, int C);
 int mr_colsum_f32(const float* x, int64_t ldx, int R, int C, float* out, void* ws, size_t ws_bytes, mr_stream_t stream);
 
+/* out[r] = sum_c x[r][c] (r < R, c < C), fixed order: the bias gradient read off the transposed dY that the weight gradient consumes. */
+int mr_rowsum_f32(const float* x, int64_t ldx, int R, int C, float* out, mr_stream_t stream);
+
 /* h = gelu_erf(u) (the training forward keeps the pre-activation u);  du = dh * d/du gelu_erf(u). */
 int mr_gelu_fwd_f32(const float* u, int64_t n, float* h, mr_stream_t stream);
 int mr_gelu_bwd_f32(const float* u, const float* dh, int64_t n, float* du, mr_stream_t stream);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "mr_gemm_nt_splitk_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "mr_gemm_nt_splitk_f32": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_i, c_p, c_sz, c_p]),
     "mr_transpose_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_i64, c_i, c_p]),
+    "mr_rowsum_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
     "mr_colsum_ws_bytes": (c_sz, [c_i, c_i]),
     "mr_colsum_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_sz, c_p]),
     "mr_gelu_fwd_f32": (c_i, [c_p, c_i64, c_p, c_p]),

@@ -13,8 +13,10 @@
 //   dkv     key-owned:   S = Q K^T and dP = dO V^T -> P, dS, which in the result layout ARE the A operands of dV += P^T dO,
 //           dK += dS^T Q  (the k index of an MFMA may be enumerated in any order as long as both operands agree)
 // so no score tile is ever transposed or written anywhere.  The owned rows live in registers as B operands (k = d enumerated as
-// d = s + 32 * (lane / 32)); the other side's 32 x 64 tiles are staged in LDS with a 65-float pitch: rows along lanes and rows
-// along the k index are both conflict-free ds_read_b32.  Deterministic: every output element has one owner, fixed order.
+// d = s + 32 * (lane / 32)); the other side's 32 x 64 tiles are staged in LDS with a 68-float pitch: rows along lanes are read
+// with ds_read_b128 (4 k-steps per read), rows along the k index with ds_read_b32, both conflict-free, and always in batches of
+// 8 - 16 reads ahead of the 16 - 32 MFMAs that consume them (one read per MFMA behind an lgkmcnt(0) leaves the matrix pipe 60 % idle).
+// Deterministic: every output element has one owner, fixed order.
 #include "common.h"
 #include <math.h>
 
@@ -22,7 +24,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kDh = 64;
-constexpr int kPitch = 65;
+constexpr int kPitch = 68;  // floats: 16-byte aligned rows; 16 consecutive rows hit 64 distinct banks with ds_read_b128, and a row's
+                           // consecutive floats are conflict-free ds_read_b32
 constexpr int kTile = 32 * kPitch;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -46,16 +49,24 @@ __device__ __forceinline__ f32x16 zero16() {
 // result-layout row of accumulator register i for this lane's half
 __device__ __forceinline__ int crow(int i, int lh) { return (i & 3) + 8 * (i >> 2) + 4 * lh; }
 
-// stage rows [row0, row0 + 32) x 64 floats of a (T, ld) matrix (column offset folded into src) into LDS, rows clamped to len - 1
-__device__ __forceinline__ void stage_tile(const float* __restrict__ src, int64_t ld, int row0, int len, float* __restrict__ dst) {
+// staging of rows [row0, row0 + 32) x 64 floats of a (T, ld) matrix (column offset folded into src), rows clamped to len - 1, in two
+// halves so that the global loads of the NEXT tile are in flight while the current one is being multiplied:
+//   fetch_tile: this thread's 8 floats -> registers;   put_tile: registers -> LDS (65-float pitch)
+struct TileRegs { float4 a, b; };
+__device__ __forceinline__ TileRegs fetch_tile(const float* __restrict__ src, int64_t ld, int row0, int len) {
     const int r = threadIdx.x >> 3, c = (threadIdx.x & 7) * 8;
     int row = row0 + r;
     row = row < len ? row : len - 1;
-    const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c);
-    const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c + 4);
+    TileRegs t;
+    t.a = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c);
+    t.b = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c + 4);
+    return t;
+}
+__device__ __forceinline__ void put_tile(const TileRegs& t, float* __restrict__ dst) {
+    const int r = threadIdx.x >> 3, c = (threadIdx.x & 7) * 8;
     float* d = dst + r * kPitch + c;
-    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
-    d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    *reinterpret_cast<float4*>(d) = t.a;
+    *reinterpret_cast<float4*>(d + 4) = t.b;
 }
 
 // the owned 32 rows as an MFMA B operand: lane (lr, lh) holds row lr, d = s + 32 lh for s = 0 .. 31
@@ -68,13 +79,53 @@ __device__ __forceinline__ void load_owned(const float* __restrict__ src, int64_
     }
 }
 
-// acc += T O^T: T = the staged tile (rows along lanes), O = the owned rows (registers)
+// acc = T O^T: T = the staged tile (rows along lanes), O = the owned rows (registers).  The lane's 32 k-values of row lr are 8
+// ds_read_b128, issued 4 at a time ahead of the 16 MFMAs that consume them.
 __device__ __forceinline__ f32x16 tile_times_owned(const float* __restrict__ tile, int lr, int lh, const float (&own)[32]) {
     f32x16 acc = zero16();
-    const float* a = tile + lr * kPitch + 32 * lh;
+    const float4* a = reinterpret_cast<const float4*>(tile + lr * kPitch + 32 * lh);
 #pragma unroll
-    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], own[s], acc, 0, 0, 0);
+    for (int hf = 0; hf < 2; ++hf) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = a[4 * hf + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s = 16 * hf + 4 * j;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, own[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, own[s + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, own[s + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, own[s + 3], acc, 0, 0, 0);
+        }
+    }
     return acc;
+}
+
+// two products against the same lanes' rows at once (S and dP): independent accumulator chains interleaved, reads batched as above
+__device__ __forceinline__ void two_tiles_times_owned(const float* __restrict__ t0, const float (&own0)[32], const float* __restrict__ t1,
+                                                      const float (&own1)[32], int lr, int lh, f32x16& acc0, f32x16& acc1) {
+    acc0 = zero16();
+    acc1 = zero16();
+    const float4* a0 = reinterpret_cast<const float4*>(t0 + lr * kPitch + 32 * lh);
+    const float4* a1 = reinterpret_cast<const float4*>(t1 + lr * kPitch + 32 * lh);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        float4 v0[4], v1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] = a0[4 * hf + j]; v1[j] = a1[4 * hf + j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s = 16 * hf + 4 * j;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j].x, own0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j].x, own1[s], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j].y, own0[s + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j].y, own1[s + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j].z, own0[s + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j].z, own1[s + 2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[j].w, own0[s + 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[j].w, own1[s + 3], acc1, 0, 0, 0);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- query-owned
@@ -107,19 +158,35 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_q_kernel(const float* __
     }
     float m = -INFINITY, l = 0.f;
     f32x16 dq0 = zero16(), dq1 = zero16();
-    for (int j0 = 0; j0 < len; j0 += 32) {
-        if (!tile_needed(Q0, 128, j0, window)) continue;  // uniform over the workgroup
+    // key tiles this workgroup needs, in order (uniform over the workgroup); the next tile's global loads overlap this tile's MFMAs
+    auto next_tile = [&](int j) {
+        while (j < len && !tile_needed(Q0, 128, j, window)) j += 32;
+        return j;
+    };
+    int j0 = next_tile(0);
+    TileRegs kt = fetch_tile(Kb, ld, j0, len), vt = kt;
+    if constexpr (!STATS) vt = fetch_tile(Vb, ld, j0, len);
+    while (j0 < len) {
         __syncthreads();
-        stage_tile(Kb, ld, j0, len, ks);
-        if constexpr (!STATS) stage_tile(Vb, ld, j0, len, vs);
+        put_tile(kt, ks);
+        if constexpr (!STATS) put_tile(vt, vs);
         __syncthreads();
-        if (q0 >= len || !tile_needed(q0, 32, j0, window)) continue;  // uniform over the wave (no barrier below)
-        f32x16 st = tile_times_owned(ks, lr, lh, qr);  // S^T[key crow(i)][query lr]
+        const int jn = next_tile(j0 + 32);
+        if (jn < len) {
+            kt = fetch_tile(Kb, ld, jn, len);
+            if constexpr (!STATS) vt = fetch_tile(Vb, ld, jn, len);
+        }
+        const int jc = j0;
+        j0 = jn;
+        if (q0 >= len || !tile_needed(q0, 32, jc, window)) continue;  // uniform over the wave (no barrier below)
+        f32x16 st, dpt;  // S^T[key crow(i)][query lr], dP^T[key][query]
+        if constexpr (STATS) st = tile_times_owned(ks, lr, lh, qr);
+        else two_tiles_times_owned(ks, qr, vs, gr, lr, lh, st, dpt);
         if constexpr (STATS) {
             float sv[16], tm = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int key = j0 + crow(i, lh);
+                const int key = jc + crow(i, lh);
                 const bool ok = key < len && allowed(q, key, window);
                 sv[i] = ok ? st[i] * scale : -INFINITY;
                 tm = fmaxf(tm, sv[i]);
@@ -133,21 +200,30 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_q_kernel(const float* __
                 m = mn;
             }
         } else {
-            f32x16 dpt = tile_times_owned(vs, lr, lh, gr);  // dP^T[key][query]
             float ds[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int key = j0 + crow(i, lh);
+                const int key = jc + crow(i, lh);
                 const bool ok = key < len && allowed(q, key, window);
                 const float p = ok ? __expf(st[i] * scale - lse) : 0.f;
                 ds[i] = p * (dpt[i] - dl) * scale;
             }
-            // dQ[query lr][d] += sum_key dS[query][key] K[key][d]: A = dS^T in its result layout, k = key crow(i, lh)
+            // dQ[query lr][d] += sum_key dS[query][key] K[key][d]: A = dS^T in its result layout, k = key crow(i, lh).  Registers
+            // 4 b .. 4 b + 3 are four consecutive keys: their 8 K values are read together ahead of the 8 MFMAs
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float* kr = ks + crow(i, lh) * kPitch + lr;
-                dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[i], kr[0], dq0, 0, 0, 0);
-                dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[i], kr[32], dq1, 0, 0, 0);
+            for (int bq = 0; bq < 4; ++bq) {
+                float k0v[4], k1v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* kr = ks + (8 * bq + 4 * lh + j) * kPitch + lr;
+                    k0v[j] = kr[0];
+                    k1v[j] = kr[32];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[4 * bq + j], k0v[j], dq0, 0, 0, 0);
+                    dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[4 * bq + j], k1v[j], dq1, 0, 0, 0);
+                }
             }
         }
     }
@@ -205,40 +281,65 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_kv_kernel(const float* _
     load_owned(Kb, ld, kc, lh, kr);
     load_owned(Vb, ld, kc, lh, vr);
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-    for (int i0 = 0; i0 < len; i0 += 32) {
-        // "needed" is symmetric in the band part; the global key 0 column makes every query tile needed for the first key tile
-        const bool wg_need = window < 0 || K0 == 0 || (i0 <= K0 + 127 + window && i0 + 31 >= K0 - window);
-        if (!wg_need) continue;
+    // query tiles this workgroup needs ("needed" is symmetric in the band part; the global key 0 column makes every query tile needed
+    // for the first key tile); the next tile's global loads overlap this tile's MFMAs
+    auto next_tile = [&](int i) {
+        while (i < len && !(window < 0 || K0 == 0 || (i <= K0 + 127 + window && i + 31 >= K0 - window))) i += 32;
+        return i;
+    };
+    auto fetch_stat = [&](int i0) {
+        const int ir = (threadIdx.x & 63) >> 1, i = i0 + ir < len ? i0 + ir : len - 1;
+        return rowstat[((int64_t)(t0 + i) * H + h) * 2 + (threadIdx.x & 1)];
+    };
+    int i0 = next_tile(0);
+    TileRegs qt = fetch_tile(Qb, ld, i0, len), gt = fetch_tile(Gb, ldc, i0, len);
+    float stv = fetch_stat(i0);
+    while (i0 < len) {
         __syncthreads();
-        stage_tile(Qb, ld, i0, len, qs);
-        stage_tile(Gb, ldc, i0, len, gs);
-        if (threadIdx.x < 64) {
-            const int ir = threadIdx.x >> 1, i = i0 + ir < len ? i0 + ir : len - 1;
-            stat[ir][threadIdx.x & 1] = rowstat[((int64_t)(t0 + i) * H + h) * 2 + (threadIdx.x & 1)];
+        put_tile(qt, qs);
+        put_tile(gt, gs);
+        if (threadIdx.x < 64) stat[threadIdx.x >> 1][threadIdx.x & 1] = stv;
+        __syncthreads();
+        const int in = next_tile(i0 + 32);
+        if (in < len) {
+            qt = fetch_tile(Qb, ld, in, len);
+            gt = fetch_tile(Gb, ldc, in, len);
+            stv = fetch_stat(in);
         }
-        __syncthreads();
-        const bool w_need = window < 0 || k0 == 0 || (i0 <= k0 + 31 + window && i0 + 31 >= k0 - window);
+        const int ic = i0;
+        i0 = in;
+        const bool w_need = window < 0 || k0 == 0 || (ic <= k0 + 31 + window && ic + 31 >= k0 - window);
         if (k0 >= len || !w_need) continue;
-        f32x16 s = tile_times_owned(qs, lr, lh, kr);   // S[query crow(i)][key lr]
-        f32x16 dp = tile_times_owned(gs, lr, lh, vr);  // dP[query][key]
+        f32x16 s, dp;  // S[query crow(i)][key lr], dP[query][key]
+        two_tiles_times_owned(qs, kr, gs, vr, lr, lh, s, dp);
         float p[16], ds[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int r = crow(i, lh), qi = i0 + r;
+            const int r = crow(i, lh), qi = ic + r;
             const bool ok = qi < len && allowed(qi, key, window);
             p[i] = ok ? __expf(s[i] * scale - stat[r][0]) : 0.f;
             ds[i] = p[i] * (dp[i] - stat[r][1]) * scale;
         }
         // dV[key lr][d] += sum_query P[query][key] dO[query][d];  dK[key][d] += sum_query dS[query][key] Q[query][d]
+        // (registers 4 b .. 4 b + 3 are four consecutive queries: their 16 operand values are read together ahead of the 16 MFMAs)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = crow(i, lh);
-            const float* gr = gs + r * kPitch + lr;
-            const float* qr = qs + r * kPitch + lr;
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p[i], gr[0], dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p[i], gr[32], dv1, 0, 0, 0);
-            dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[i], qr[0], dk0, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[i], qr[32], dk1, 0, 0, 0);
+        for (int bq = 0; bq < 4; ++bq) {
+            float g0[4], g1[4], q0v[4], q1v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 8 * bq + 4 * lh + j;
+                const float* gr = gs + r * kPitch + lr;
+                const float* qr = qs + r * kPitch + lr;
+                g0[j] = gr[0]; g1[j] = gr[32];
+                q0v[j] = qr[0]; q1v[j] = qr[32];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p[4 * bq + j], g0[j], dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p[4 * bq + j], g1[j], dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[4 * bq + j], q0v[j], dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[4 * bq + j], q1v[j], dk1, 0, 0, 0);
+            }
         }
     }
 #pragma unroll

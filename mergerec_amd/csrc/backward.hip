@@ -78,6 +78,35 @@ __global__ __launch_bounds__(kThreads) void chunk_reduce_kernel(const float* __r
     }
 }
 
+// out[r] = sum_c x[r][c]: one workgroup per row, threads stride the row (coalesced), fixed-order wave + LDS combine.  The bias gradient of
+// a Linear is the row sum of dY^T, which the weight-gradient GEMM needs in that layout anyway.
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void rowsum_kernel(const float* __restrict__ x, int64_t ldx, int C, float* __restrict__ out) {
+    __shared__ float part[kThreads / 64];
+    const float* row = x + (int64_t)blockIdx.x * ldx;
+    float s = 0.f;
+    if (VEC) {  // 16-byte loads, four running sums per thread
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+        for (int c = threadIdx.x; c < (C >> 2); c += kThreads) {
+            const float4 v = r4[c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        s = (a.x + a.y) + (a.z + a.w);
+    } else {
+        for (int c = threadIdx.x; c < C; c += kThreads) s += row[c];
+    }
+    s = mr::wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = part[0];
+#pragma unroll
+        for (int k = 1; k < kThreads / 64; ++k) t += part[k];
+        out[blockIdx.x] = t;
+    }
+}
+
 // h = gelu_erf(u) (the forward of the training graph keeps the pre-activation, so the GEMM epilogue's fused GELU is not used)
 __global__ __launch_bounds__(kThreads) void gelu_fwd_kernel(const float* __restrict__ u, int64_t n, float* __restrict__ h) {
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
@@ -287,6 +316,15 @@ extern "C" int mr_colsum_f32(const float* x, int64_t ldx, int R, int C, float* o
     hipLaunchKernelGGL(colsum_kernel, dim3((C + kColW - 1) / kColW, n), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, R, C, part);
     if (n > 1)
         hipLaunchKernelGGL(chunk_reduce_kernel, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, part, n, C, 1, out, out);
+    return mr::check_launch();
+}
+
+extern "C" int mr_rowsum_f32(const float* x, int64_t ldx, int R, int C, float* out, mr_stream_t stream) {
+    if (!x || !out || R < 0 || C < 0 || ldx < C) return MR_EINVAL;
+    if (R == 0) return MR_OK;
+    const bool vec = !(C & 3) && !(ldx & 3) && mr::aligned16(x);
+    if (vec) hipLaunchKernelGGL(rowsum_kernel<true>, dim3(R), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, C, out);
+    else hipLaunchKernelGGL(rowsum_kernel<false>, dim3(R), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, C, out);
     return mr::check_launch();
 }
 

@@ -212,20 +212,23 @@ class EncoderTrainGraph:
             do = ops.layernorm_bwd(s["o"], dx, w[lp + "output.LayerNorm.weight"], sp.ln_eps, g[lp + "output.LayerNorm.weight"],
                                    g[lp + "output.LayerNorm.bias"])
             # o = i W2^T + b2 + h
-            ops.colsum(do, g[lp + "output.dense.bias"])
-            self._wgrad(self._tpad(do), self._xt(s["i"]), g[lp + "output.dense.weight"])
+            do_t = self._tpad(do)
+            ops.rowsum(do_t, g[lp + "output.dense.bias"])  # bias gradient = row sums of dY^T
+            self._wgrad(do_t, self._xt(s["i"]), g[lp + "output.dense.weight"])
             di = self._dgrad(do, w, l, "output.dense")
             # i = gelu(u), u = h W1^T + b1
             du = ops.gelu_bwd(s["u"], di)
-            ops.colsum(du, g[lp + "intermediate.dense.bias"])
-            self._wgrad(self._tpad(du), self._xt(s["h"]), g[lp + "intermediate.dense.weight"])
+            du_t = self._tpad(du)
+            ops.rowsum(du_t, g[lp + "intermediate.dense.bias"])
+            self._wgrad(du_t, self._xt(s["h"]), g[lp + "intermediate.dense.weight"])
             dh = self._dgrad(du, w, l, "intermediate.dense", residual=do)  # + the residual path of o
             # h = LN1(a)
             da = ops.layernorm_bwd(s["a"], dh, w[lp + "attention.output.LayerNorm.weight"], sp.ln_eps,
                                    g[lp + "attention.output.LayerNorm.weight"], g[lp + "attention.output.LayerNorm.bias"])
             # a = ctx Wo^T + bo + x
-            ops.colsum(da, g[lp + "attention.output.dense.bias"])
-            self._wgrad(self._tpad(da), self._xt(s["ctx"]), g[lp + "attention.output.dense.weight"])
+            da_t = self._tpad(da)
+            ops.rowsum(da_t, g[lp + "attention.output.dense.bias"])
+            self._wgrad(da_t, self._xt(s["ctx"]), g[lp + "attention.output.dense.weight"])
             dctx = self._dgrad(da, w, l, "attention.output.dense")
             dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window, max_len=pb.max_len)
             xt = self._xt(s["x"])
@@ -234,7 +237,7 @@ class EncoderTrainGraph:
                                                          pb.cu_seqlens, pb.B, sp.heads)
                 # key_global / value_global read every token
                 dkvg_t = self._tpad(dkvg)
-                bs2 = ops.colsum(dkvg)
+                bs2 = ops.rowsum(dkvg_t)
                 for k, n in enumerate(("key_global", "value_global")):
                     name = f"{lp}attention.self.{n}"
                     g[name + ".bias"].copy_(bs2[k * d:(k + 1) * d])
@@ -247,7 +250,7 @@ class EncoderTrainGraph:
                 ops.scatter_add_rows(ops.gemm_nt_train(dqg, ops.transpose_pad(w[name + ".weight"])), pb.cls_rows, da)
             # qkv = x [Wq; Wk; Wv]^T + b
             dqkv_t = self._tpad(dqkv)  # (3 d, T_pad)
-            bsum = ops.colsum(dqkv)
+            bsum = ops.rowsum(dqkv_t)
             for k, n in enumerate(("query", "key", "value")):
                 name = f"{lp}attention.self.{n}"
                 g[name + ".bias"].copy_(bsum[k * d:(k + 1) * d])

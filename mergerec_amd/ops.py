@@ -505,6 +505,16 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     return out
 
 
+def rowsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[r] = sum_c x[r][c] for a (R, C) matrix with unit inner stride."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise ValueError("x must be a (R, C) fp32 GPU matrix with unit inner stride (the HIP path has no CPU fallback)")
+    R, C = x.shape
+    out = torch.empty(R, dtype=torch.float32, device=x.device) if out is None else out
+    check(_lib.load().mr_rowsum_f32(ptr(x), x.stride(0), R, C, ptr(out), _stream(x)), "mr_rowsum_f32")
+    return out
+
+
 def gelu_fwd(u: torch.Tensor) -> torch.Tensor:
     _dev(u, "u", torch.float32)
     if not u.is_contiguous():

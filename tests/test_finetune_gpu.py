@@ -190,6 +190,31 @@ def test_negative_sampling_modes_match_reference_scores():
         torch.testing.assert_close(reps.grad.cpu(), reps_cpu.grad, rtol=1e-4, atol=1e-6)
 
 
+def test_full_catalog_training_step_matches_oracle():
+    """NegativeSampleOption.FULL: BatchSequence against a frozen catalog (ItemEncodingCallback.on_train_epoch_start), module.py:133-139,183"""
+    from mergerec_amd.configs import NegativeSampleConfig
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.model_batch import BatchSequence
+    from mergerec_amd.module import RecModule
+
+    g = torch.Generator().manual_seed(12)
+    B, M, d = 7, 333, 64
+    reps_cpu = torch.nn.functional.normalize(torch.randn(B, d, generator=g), dim=-1).requires_grad_(True)
+    E = torch.nn.functional.normalize(torch.randn(M, d, generator=g), dim=-1)
+    labels = torch.randint(0, M, (B,), generator=g)
+    want = O.finetune_loss(reps_cpu @ E.T, labels, 0.05)
+    want.backward()
+    reps = reps_cpu.detach().to(DEV).requires_grad_(True)
+    mod = RecModule(model=_FixedReps(reps), evaluator=Evaluator(["NDCG"], [1]), negative_sample=NegativeSampleConfig(), similarity="dot", temperature=0.05)
+    mod.item_embeddings = torch.nn.Parameter(E.to(DEV), requires_grad=False)
+    mod.train()
+    ids = {"input_ids": torch.ones(B, 3, dtype=torch.int64), "attention_mask": torch.ones(B, 3, dtype=torch.int64)}
+    loss = mod.training_step(BatchSequence(sequence=ids, labels=labels.to(DEV)), 0)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), want.detach(), rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(reps.grad.cpu(), reps_cpu.grad, rtol=1e-4, atol=1e-6)
+
+
 def _tiny_blair(seed=3):
     from mergerec_amd.module import ModelType
 

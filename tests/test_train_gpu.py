@@ -36,6 +36,7 @@ def test_backward_kernels_match_torch():
     # token-sized (fine-tuning) shapes: several 256-row chunks through the two-stage reductions
     xt = torch.randn(1000, 100, generator=g)
     assert torch.allclose(ops.colsum(xt.to(DEV)).cpu(), xt.sum(0), atol=1e-4)
+    assert torch.allclose(ops.rowsum(xt.to(DEV)[:, :77]).cpu(), xt[:, :77].sum(1), atol=1e-4)
     xx = (torch.randn(777, 128, generator=g) * 3 + 1).requires_grad_(True)
     dy = torch.randn(777, 128, generator=g)
     gam.grad = bet.grad = None
