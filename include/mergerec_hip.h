@@ -312,10 +312,10 @@ int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t l
 /* Softmax self-attention backward on packed sequences: qkv (T, 3 H dh) = [Q | K | V] and ctx (T, H dh) as in mr_attn_f32,
  * dctx = d loss / d ctx; rowstat (T, H, 2) is workspace; dqkv (T, 3 H dh) receives [dQ | dK | dV].  dh must be 64.
  * window < 0: full attention; window >= 0: Longformer band |i - j| <= window plus the global key 0, query row 0 excluded (it
- * belongs to the global-row kernel).  max_len >= the longest sequence (sizes the grid: one workgroup per 128 rows, head, sequence).
+ * belongs to the global-row kernel).  seq_order (B sequence ids, longest first; may be NULL) sets the dispatch order.  max_len >= the longest sequence (sizes the grid: one workgroup per 128 rows, head, sequence).
  * fp32 matrix-core products (v_mfma_f32_32x32x2_f32), one owner per output element, fixed summation order. */
-int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, int B, int H, int dh, int max_len,
-                    float scale, int window, float* rowstat, float* dqkv, mr_stream_t stream);
+int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H,
+                    int dh, int max_len, float scale, int window, float* rowstat, float* dqkv, mr_stream_t stream);
 
 /* Longformer global row (mr_attn_global_row_f32) backward: qg (B, H dh), kvg (T, 2 H dh) = [Kg | Vg], ctx_cls / dctx_cls (B, H dh) the
  * forward output and its gradient at the CLS rows; dqg (B, H dh), dkvg (T, 2 H dh). */

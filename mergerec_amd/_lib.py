@@ -56,7 +56,7 @@ SIGNATURES = {
     "mr_gelu_bwd_f32": (c_i, [c_p, c_p, c_i64, c_p, c_p]),
     "mr_layernorm_bwd_ws_bytes": (c_sz, [c_i, c_i]),
     "mr_layernorm_bwd_f32": (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_f, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p, c_sz, c_p]),
-    "mr_attn_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p]),
+    "mr_attn_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p]),
     "mr_attn_global_row_bwd_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
     "mr_scatter_add_rows_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_p, c_i64, c_p]),
     "mr_split_tokens_kblock_f32": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p]),

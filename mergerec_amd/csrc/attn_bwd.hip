@@ -7,7 +7,8 @@
 // Longformer mode (window >= 0): query i sees key j iff j == 0 (global key) or |i - j| <= window; query row 0 belongs to the
 // global-row kernel and sees nothing here.
 //
-// Three launches over (128-row tile, head, sequence), four waves per workgroup, each wave owning 32 rows:
+// Three launches over (128-row tile, head, sequence; sequences in the caller's order -- longest first), four waves per workgroup,
+// each wave owning 32 rows:
 //   stats   query-owned: S^T = K Q^T tile by tile -> online logsumexp per query (one lane per query, 16 keys per lane and step)
 //   dq      query-owned: S^T and dP^T = V dO^T  -> dS^T, which in the MFMA result layout IS the A operand of dQ += dS K
 //   dkv     key-owned:   S = Q K^T and dP = dO V^T -> P, dS, which in the result layout ARE the A operands of dV += P^T dO,
@@ -19,6 +20,7 @@
 // Deterministic: every output element has one owner, fixed order.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -52,21 +54,30 @@ __device__ __forceinline__ int crow(int i, int lh) { return (i & 3) + 8 * (i >> 
 // staging of rows [row0, row0 + 32) x 64 floats of a (T, ld) matrix (column offset folded into src), rows clamped to len - 1, in two
 // halves so that the global loads of the NEXT tile are in flight while the current one is being multiplied:
 //   fetch_tile: this thread's 8 floats -> registers;   put_tile: registers -> LDS (65-float pitch)
-struct TileRegs { float4 a, b; };
-__device__ __forceinline__ TileRegs fetch_tile(const float* __restrict__ src, int64_t ld, int row0, int len) {
+template <int NW>
+struct TileRegs { float4 a[4 / NW], b[4 / NW]; };  // NW = waves per workgroup (4 or 2): 64 * NW threads cover 8 * NW rows per pass
+template <int NW>
+__device__ __forceinline__ TileRegs<NW> fetch_tile(const float* __restrict__ src, int64_t ld, int row0, int len) {
     const int r = threadIdx.x >> 3, c = (threadIdx.x & 7) * 8;
-    int row = row0 + r;
-    row = row < len ? row : len - 1;
-    TileRegs t;
-    t.a = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c);
-    t.b = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c + 4);
+    TileRegs<NW> t;
+#pragma unroll
+    for (int q = 0; q < 4 / NW; ++q) {
+        int row = row0 + r + 8 * NW * q;
+        row = row < len ? row : len - 1;
+        t.a[q] = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c);
+        t.b[q] = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + c + 4);
+    }
     return t;
 }
-__device__ __forceinline__ void put_tile(const TileRegs& t, float* __restrict__ dst) {
+template <int NW>
+__device__ __forceinline__ void put_tile(const TileRegs<NW>& t, float* __restrict__ dst) {
     const int r = threadIdx.x >> 3, c = (threadIdx.x & 7) * 8;
-    float* d = dst + r * kPitch + c;
-    *reinterpret_cast<float4*>(d) = t.a;
-    *reinterpret_cast<float4*>(d + 4) = t.b;
+#pragma unroll
+    for (int q = 0; q < 4 / NW; ++q) {
+        float* d = dst + (r + 8 * NW * q) * kPitch + c;
+        *reinterpret_cast<float4*>(d) = t.a[q];
+        *reinterpret_cast<float4*>(d + 4) = t.b[q];
+    }
 }
 
 // the owned 32 rows as an MFMA B operand: lane (lr, lh) holds row lr, d = s + 32 lh for s = 0 .. 31
@@ -129,15 +140,16 @@ __device__ __forceinline__ void two_tiles_times_owned(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------- query-owned
-template <bool STATS>
-__global__ __launch_bounds__(kThreads, 2) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
-                                                                const float* __restrict__ dctx, const int32_t* __restrict__ cu, int H,
-                                                                float scale, int window, float* __restrict__ rowstat,
-                                                                float* __restrict__ dqkv) {
+template <bool STATS, int NW>
+__global__ __launch_bounds__(64 * NW, (STATS ? 4 : 3)) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                                const float* __restrict__ dctx, const int32_t* __restrict__ cu,
+                                                                const int32_t* __restrict__ order, int H, float scale, int window,
+                                                                float* __restrict__ rowstat, float* __restrict__ dqkv) {
     __shared__ float ks[kTile], vs[STATS ? 1 : kTile];
-    const int b = blockIdx.z, h = blockIdx.y;
+    const int b = order ? order[blockIdx.z] : blockIdx.z, h = blockIdx.y;  // longest sequences first when the caller passes the order
     const int t0 = cu[b], len = cu[b + 1] - t0;
-    const int Q0 = blockIdx.x * 128;
+    constexpr int kRows = 32 * NW;  // rows owned by this workgroup
+    const int Q0 = blockIdx.x * kRows;
     if (Q0 >= len) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
@@ -160,12 +172,12 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_q_kernel(const float* __
     f32x16 dq0 = zero16(), dq1 = zero16();
     // key tiles this workgroup needs, in order (uniform over the workgroup); the next tile's global loads overlap this tile's MFMAs
     auto next_tile = [&](int j) {
-        while (j < len && !tile_needed(Q0, 128, j, window)) j += 32;
+        while (j < len && !tile_needed(Q0, kRows, j, window)) j += 32;
         return j;
     };
     int j0 = next_tile(0);
-    TileRegs kt = fetch_tile(Kb, ld, j0, len), vt = kt;
-    if constexpr (!STATS) vt = fetch_tile(Vb, ld, j0, len);
+    TileRegs<NW> kt = fetch_tile<NW>(Kb, ld, j0, len), vt = kt;
+    if constexpr (!STATS) vt = fetch_tile<NW>(Vb, ld, j0, len);
     while (j0 < len) {
         __syncthreads();
         put_tile(kt, ks);
@@ -173,8 +185,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_q_kernel(const float* __
         __syncthreads();
         const int jn = next_tile(j0 + 32);
         if (jn < len) {
-            kt = fetch_tile(Kb, ld, jn, len);
-            if constexpr (!STATS) vt = fetch_tile(Vb, ld, jn, len);
+            kt = fetch_tile<NW>(Kb, ld, jn, len);
+            if constexpr (!STATS) vt = fetch_tile<NW>(Vb, ld, jn, len);
         }
         const int jc = j0;
         j0 = jn;
@@ -261,13 +273,16 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_q_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------------------------ key-owned
-__global__ __launch_bounds__(kThreads, 2) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
-                                                                 const float* __restrict__ rowstat, const int32_t* __restrict__ cu, int H,
-                                                                 float scale, int window, float* __restrict__ dqkv) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                                 const float* __restrict__ rowstat, const int32_t* __restrict__ cu,
+                                                                 const int32_t* __restrict__ order, int H, float scale, int window,
+                                                                 float* __restrict__ dqkv) {
     __shared__ float qs[kTile], gs[kTile], stat[32][2];
-    const int b = blockIdx.z, h = blockIdx.y;
+    const int b = order ? order[blockIdx.z] : blockIdx.z, h = blockIdx.y;
     const int t0 = cu[b], len = cu[b + 1] - t0;
-    const int K0 = blockIdx.x * 128;
+    constexpr int kRows = 32 * NW;
+    const int K0 = blockIdx.x * kRows;
     if (K0 >= len) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_kv_kernel(const float* _
     // query tiles this workgroup needs ("needed" is symmetric in the band part; the global key 0 column makes every query tile needed
     // for the first key tile); the next tile's global loads overlap this tile's MFMAs
     auto next_tile = [&](int i) {
-        while (i < len && !(window < 0 || K0 == 0 || (i <= K0 + 127 + window && i + 31 >= K0 - window))) i += 32;
+        while (i < len && !(window < 0 || K0 == 0 || (i <= K0 + kRows - 1 + window && i + 31 >= K0 - window))) i += 32;
         return i;
     };
     auto fetch_stat = [&](int i0) {
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_kv_kernel(const float* _
         return rowstat[((int64_t)(t0 + i) * H + h) * 2 + (threadIdx.x & 1)];
     };
     int i0 = next_tile(0);
-    TileRegs qt = fetch_tile(Qb, ld, i0, len), gt = fetch_tile(Gb, ldc, i0, len);
+    TileRegs<NW> qt = fetch_tile<NW>(Qb, ld, i0, len), gt = fetch_tile<NW>(Gb, ldc, i0, len);
     float stv = fetch_stat(i0);
     while (i0 < len) {
         __syncthreads();
@@ -302,8 +317,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_kv_kernel(const float* _
         __syncthreads();
         const int in = next_tile(i0 + 32);
         if (in < len) {
-            qt = fetch_tile(Qb, ld, in, len);
-            gt = fetch_tile(Gb, ldc, in, len);
+            qt = fetch_tile<NW>(Qb, ld, in, len);
+            gt = fetch_tile<NW>(Gb, ldc, in, len);
             stv = fetch_stat(in);
         }
         const int ic = i0;
@@ -358,17 +373,27 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_kv_kernel(const float* _
 
 }  // namespace
 
-extern "C" int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, int B, int H, int dh,
-                               int max_len, float scale, int window, float* rowstat, float* dqkv, mr_stream_t stream) {
+extern "C" int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order, int B,
+                               int H, int dh, int max_len, float scale, int window, float* rowstat, float* dqkv, mr_stream_t stream) {
     if (!qkv || !ctx || !dctx || !cu_seqlens || !rowstat || !dqkv || B < 0 || H < 1 || max_len < 0) return MR_EINVAL;
     if (dh != kDh) return MR_EUNSUPPORTED;
     if (!mr::aligned16(qkv) || !mr::aligned16(ctx) || !mr::aligned16(dctx)) return MR_EALIGN;
     if (B == 0 || max_len == 0) return MR_OK;
     if (H > 65535 || B > 65535) return MR_EUNSUPPORTED;
-    const dim3 grid((max_len + 127) / 128, H, B);
+    // 128-row workgroups (four waves) by default; MR_ATTNBWD_ROWS=64 selects two-wave workgroups (finer granularity at sequence ends, twice
+    // the staging per MFMA: measured equal or slightly slower on uniform and on Amazon-shaped ragged batches)
+    static const int rows = [] { const char* e = getenv("MR_ATTNBWD_ROWS"); return e ? atoi(e) : 128; }();
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((attn_bwd_q_kernel<true>), grid, dim3(kThreads), 0, st, qkv, ctx, dctx, cu_seqlens, H, scale, window, rowstat, dqkv);
-    hipLaunchKernelGGL((attn_bwd_q_kernel<false>), grid, dim3(kThreads), 0, st, qkv, ctx, dctx, cu_seqlens, H, scale, window, rowstat, dqkv);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(kThreads), 0, st, qkv, dctx, rowstat, cu_seqlens, H, scale, window, dqkv);
+    if (rows == 128) {
+        const dim3 grid((max_len + 127) / 128, H, B);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<true, 4>), grid, dim3(256), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<false, 4>), grid, dim3(256), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv);
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<4>), grid, dim3(256), 0, st, qkv, dctx, rowstat, cu_seqlens, seq_order, H, scale, window, dqkv);
+    } else {
+        const dim3 grid((max_len + 63) / 64, H, B);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<true, 2>), grid, dim3(128), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<false, 2>), grid, dim3(128), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv);
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<2>), grid, dim3(128), 0, st, qkv, dctx, rowstat, cu_seqlens, seq_order, H, scale, window, dqkv);
+    }
     return mr::check_launch();
 }

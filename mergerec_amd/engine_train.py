@@ -230,7 +230,7 @@ class EncoderTrainGraph:
             ops.rowsum(da_t, g[lp + "attention.output.dense.bias"])
             self._wgrad(da_t, self._xt(s["ctx"]), g[lp + "attention.output.dense.weight"])
             dctx = self._dgrad(da, w, l, "attention.output.dense")
-            dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window, max_len=pb.max_len)
+            dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window, max_len=pb.max_len, seq_order=pb.seq_order)
             xt = self._xt(s["x"])
             if self.rec:
                 dqg, dkvg = ops.attention_global_row_bwd(s["qg"], s["kvg"], ops.gather_rows(s["ctx"], pb.cls_rows), ops.gather_rows(dctx, pb.cls_rows),

@@ -549,7 +549,7 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
 
 
 def attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, scale: Optional[float] = None,
-                  window: int = -1, max_len: Optional[int] = None):
+                  window: int = -1, max_len: Optional[int] = None, seq_order: Optional[torch.Tensor] = None):
     _dev(qkv, "qkv", torch.float32), _dev(ctx, "ctx", torch.float32), _dev(dctx, "dctx", torch.float32)
     T = qkv.shape[0]
     if not (qkv.is_contiguous() and ctx.is_contiguous() and dctx.is_contiguous()) or qkv.shape[1] != 3 * H * 64:
@@ -559,7 +559,7 @@ def attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, cu_s
     if max_len is None:  # (one small D2H sync; the training graph passes the packed batch's own maximum)
         max_len = int((cu_seqlens[1:] - cu_seqlens[:-1]).max()) if B else 0
     ev = PROF.begin(qkv.device)
-    check(_lib.load().mr_attn_bwd_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), B, H, 64, max_len, 0.125 if scale is None else scale, window,
+    check(_lib.load().mr_attn_bwd_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), ptr(seq_order), B, H, 64, max_len, 0.125 if scale is None else scale, window,
                                       ptr(rowstat), ptr(dqkv), _stream(qkv)), "mr_attn_bwd_f32")
     PROF.end(ev, qkv.device, "attention_bwd", flops=0.0, nbytes=4.0 * T * H * 64 * 8)
     return dqkv
