@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--gemm-mode", choices=["bf16x6", "bf16x3", "f32"], default=None,
                     help="encoder GEMM arithmetic: bf16x3 (bench default) / bf16x6 = 3 / 6 bf16 MFMA products per fp32 product, "
                          "f32 = exact fp32 MFMA.  The in-run `parity` object reports the distance to the CPU oracle for the chosen mode.")
+    ap.add_argument("--merge-placement", choices=["replicated", "sliced"], default="replicated",
+                    help="N > 1: 'replicated' = every rank holds all task vectors and merges the whole arena locally (no collective: HBM streams "
+                         "the 5 GB of a merge in under 1 ms, xGMI would need longer for the 0.5 GB all-gather alone); 'sliced' = each rank "
+                         "merges 1/N of the arena and one all-gather assembles it (task vectors could then be sharded too: memory / N)")
     return ap.parse_args()
 
 
@@ -107,7 +111,8 @@ def main():
 
     spec = EncoderSpec.blair_base()
     layout = ArenaLayout(spec.param_shapes("model."))
-    plan = parallel.SlicePlan(layout.padded_numel, world)
+    sliced = world > 1 and args.merge_placement == "sliced"
+    plan = parallel.SlicePlan(layout.padded_numel, world if sliced else 1)
     runner = EncoderRunner(spec)
     n_dom, M, d = args.domains, args.catalog, spec.hidden
     U_step, I_step = args.users_per_step, args.items_per_step
@@ -120,11 +125,17 @@ def main():
     # (bf16x3: measured 1.1e-6 on embeddings, 6e-7 on logits); MERGEREC_GEMM_MODE / --gemm-mode select the others
     gemm_mode = args.gemm_mode or os.environ.get("MERGEREC_GEMM_MODE") or "bf16x3"
     W = WeightSet(layout, arena[: layout.padded_numel], gemm_mode)
-    lo, hi = plan.bounds(rank)
-    scratch = torch.empty(hi - lo, dtype=torch.float32, device=dev) if world > 1 else None
+    lo, hi = plan.bounds(rank if sliced else 0)
+    scratch = torch.empty(hi - lo, dtype=torch.float32, device=dev) if sliced else None
 
     def merge_slice(p_begin, p_count, out_slice):
         ops.merge_nway(base, tv, alpha, None, out=out_slice, p_begin=p_begin, p_count=p_count, out_is_slice=True)
+
+    def merge_arena():
+        if sliced:  # this rank's slice, then ONE all-gather of the merged slices
+            parallel.sharded_merge(merge_slice, arena, plan, scratch)
+        else:  # whole arena from the rank's own copy of the task vectors (the N = 1 path on every rank)
+            merge_slice(0, plan.padded, arena)
 
     n_total = args.steps + args.warmup
     g = torch.Generator().manual_seed(1234 + rank)
@@ -149,7 +160,7 @@ def main():
     avg_item_tokens = float(torch.cat([l for _, l in item_batches]).float().mean())
 
     # full catalog encoded once with the merged model (setup): E (M, d), row == item id
-    parallel.sharded_merge(merge_slice, arena, plan, scratch)
+    merge_arena()
     W.refresh()
     E = torch.empty(M, d, dtype=torch.float32, device=dev)
     gi = torch.Generator().manual_seed(99)
@@ -164,8 +175,8 @@ def main():
     state = {"cursor": 0}
 
     def step(i):
-        # (1) merge (this rank's slice) [+ all-gather]
-        parallel.sharded_merge(merge_slice, arena, plan, scratch)
+        # (1) merge (replicated: the whole arena locally; sliced: this rank's slice + all-gather)
+        merge_arena()
         W.refresh()  # bf16x6 mode: re-split the freshly merged arena into its three bf16 piece arenas
         # (2)+(3) ONE packed encoder pass over [catalog slice ; user sequences] (varlen: no padding is computed)
         mb, ml = mixed_batches[i]
@@ -263,7 +274,8 @@ def main():
                 workload=f"{n_dom}-domain merged BLaIR-base (alpha=1/{n_dom}), full-catalog scoring, Arts-sized catalog",
                 domains_merged=n_dom, catalog_items=M, users_per_step_per_gpu=U_step, items_per_step_per_gpu=I_step,
                 avg_user_tokens=avg_user_tokens, avg_item_tokens=avg_item_tokens, topk=50, params=layout.numel,
-                parallelism=f"dp{world}: arena-slice merge + all-gather, catalog rows sharded + all-gather, users data-parallel",
+                parallelism=(f"dp{world}: " + ("arena-slice merge + all-gather" if sliced else "task vectors replicated, whole-arena merge per rank (no collective)")
+                             + ", catalog rows sharded + all-gather, users data-parallel"),
             ),
             roofline=roofline, cpu_baseline=cpu_baseline, kernels=kernels, parity=parity,
         )
