@@ -166,9 +166,11 @@ class ItemSequenceCollator(SingleItemCollator):
         negatives = None
         if self.num_negative is not None:
             neg = []
-            for seq in batch:  # as the reference: set() of the (index, items) tuple -- raises TypeError there too (sampled negatives
-                # are a fine-tuning option, not on the inference path)
-                neg.extend(random.sample(list(self._all_items - set(seq)), self.num_negative))
+            for _, items in batch:
+                # negatives = catalog items the user never interacted with.  (The reference takes set() of the whole (index, items)
+                # sample -- recommender.py:107-109 -- which raises TypeError on the inner list, so its sampled modes cannot run; the
+                # evident intent is followed here.)
+                neg.extend(random.sample(sorted(self._all_items - set(items)), self.num_negative))
             negatives = self._encode([self.item_prompt + self.item_text[n] for n in neg])
         return BatchSequenceWithNegative(sequence=sequence, target=target, negatives=negatives)
 
@@ -311,8 +313,8 @@ class RecformerItemSequenceCollator(RecformerSingleItemCollator):
         negatives = None
         if self.num_negative is not None:
             neg = []
-            for seq in batch:
-                neg.extend(random.sample(list(self._all_items - set(seq)), self.num_negative))
+            for _, items in batch:  # (same repair as the text collator: the reference's set() of the sample tuple cannot run)
+                neg.extend(random.sample(sorted(self._all_items - set(items)), self.num_negative))
             negatives = self._encode([[n] for n in neg])
         return BatchSequenceWithNegative(sequence=sequence, target=target, negatives=negatives)
 

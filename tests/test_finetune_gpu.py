@@ -286,7 +286,8 @@ def test_training_steps_match_oracle_autograd_and_adamw():
         assert float(diff.abs().mean()) <= 0.02 * LR, float(diff.abs().mean())
 
 
-@pytest.mark.parametrize("kind,negatives", [("blair_base", "in_batch"), ("recformer_base", "in_batch"), ("blair_base", "full")])
+@pytest.mark.parametrize("kind,negatives", [("blair_base", "in_batch"), ("recformer_base", "in_batch"), ("blair_base", "full"),
+                                            ("blair_base", "in_batch_sample"), ("recformer_base", "sample")])
 def test_finetune_train_cli_end_to_end(tmp_path, kind, negatives):
     """finetune_train.py (scripts/1_finetune/blair_base.sh / recformer_base.sh) on the mini JSON dataset with the local tokenizer:
     in-batch fine-tuning lowers the training loss, writes the best checkpoint in the layout scripts/extract.py reads, and the
@@ -299,7 +300,8 @@ def test_finetune_train_cli_end_to_end(tmp_path, kind, negatives):
 
     root = tmp_path / "run"
     argv = ["--model_type", kind, "--model_kwargs", "init_seed", "7", "--tokenizer_path", str(GOLDEN / "mini_tokenizer"),
-            "--data_path", str(GOLDEN / "mini_dataset"), "--batch_size", "8", *(["--negative_sample.in_batch"] if negatives == "in_batch" else []),
+            "--data_path", str(GOLDEN / "mini_dataset"), "--batch_size", "8", *(["--negative_sample.in_batch"] if negatives.startswith("in_batch") else []),
+            *(["--negative_sample.k", "3"] if negatives.endswith("sample") else []),
             "--temperature", "0.05",
             "--warmup_steps", "2", "--learning_rate", "1e-3", "--gradient_accumulation_steps", "2", "--gradient_clip_val", "1.0",
             "--max_epochs", "3", "--max_seq_len", "96", "--max_attribute_len", "12", "--max_items", "20", "--precision", "bf16-mixed",
@@ -335,7 +337,7 @@ def test_finetune_train_cli_end_to_end(tmp_path, kind, negatives):
                                     str(out / "state_dict.pt"), "--data_path", str(GOLDEN / "mini_dataset"), "--tokenizer_path",
                                     str(GOLDEN / "mini_tokenizer"), "--batch_size", "8", "--max_seq_len", "96", "--max_attribute_len", "12",
                                     "--max_items", "20"])
-        if negatives == "in_batch":  # (FULL mode scores against the catalog frozen at the epoch's START -- callbacks.py:57-59 -- which the
+        if negatives != "full":  # (FULL mode scores against the catalog frozen at the epoch's START -- callbacks.py:57-59 -- which the
             # checkpoint carries; finetune_test.py re-encodes it with the final weights, so the two differ by design)
             assert abs(again[0]["test/NDCG@10"] - metrics[0]["test/NDCG@10"]) <= 1e-6
     finally:
