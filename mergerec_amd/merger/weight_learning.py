@@ -116,13 +116,22 @@ class TaskVectorMergingModuleBase(nn.Module):
         self.load_weights()
         return self.model(batch)
 
-    def forward_with_grad(self, batch):
-        from ..engine_train import RobertaTrainGraph, encode_with_grad
+    train_mode = "f32"  # "bf16x3": split-precision MFMA products in the training graph (DistillTrainer sets it for bf16-mixed / 16-mixed)
 
-        if getattr(self, "_train_graph", None) is None:
-            self._train_graph = RobertaTrainGraph(self.model.spec, self.layout, prefix=self.model.runner.prefix)
+    def forward_with_grad(self, batch):
+        from ..engine_train import RobertaTrainGraph, SplitWeights, encode_with_grad
+
+        merged = self.merged_params()
+        sw = None
+        mode = self.train_mode if self.model.spec.hidden % 128 == 0 else "f32"
+        if mode == "bf16x3":  # the merged weights are new every step: re-split them (and their transposes) from the merged arena
+            sw = getattr(self, "_split_weights", None)
+            if sw is None:
+                sw = self._split_weights = SplitWeights(self.model.spec, self.layout, self.model.runner.prefix, self.base_model_tensor.device)
+            sw.refresh(merged.detach())
+        graph = RobertaTrainGraph(self.model.spec, self.layout, prefix=self.model.runner.prefix, mode=mode, split_weights=sw)
         pb = self.model.runner.pack(batch, self.base_model_tensor.device)
-        return encode_with_grad(self._train_graph, self.merged_params(), pb)
+        return encode_with_grad(graph, merged, pb)
 
     # -- merge -----------------------------------------------------------------------------------
     def effective_alpha(self) -> torch.Tensor:

@@ -118,8 +118,8 @@ def test_encoder_backward_matches_oracle_autograd():
     assert worst > 0.0
 
 
-@pytest.mark.parametrize("learn", ["TASK_WISE", "LAYER_WISE"])
-def test_alpha_gradient_end_to_end_matches_oracle_autograd(learn):
+@pytest.mark.parametrize("learn,mode", [("TASK_WISE", "f32"), ("LAYER_WISE", "f32"), ("TASK_WISE", "bf16x3"), ("LAYER_WISE", "bf16x3")])
+def test_alpha_gradient_end_to_end_matches_oracle_autograd(learn, mode):
     """alpha -> merge -> encoder -> cosine logits -> SINGLE_PSEUDO_LABEL_KD, all on the device, against torch autograd through
     the CPU oracle of every stage (the reference's merge_train.py step, module/distiller/sequence/module.py:59-79)"""
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
@@ -142,6 +142,7 @@ def test_alpha_gradient_end_to_end_matches_oracle_autograd(learn):
 
     mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[learn], _tiny_model(cfgd), g2["pretrain"], [dict(f) for f in g2["finetunes"]], set(),
                              disable_softmax=True, initial_per_weight=0.3)
+    mm.train_mode = mode  # exact-fp32 products, or the split-precision graph merge_train.py uses under --precision bf16-mixed
     mod = DistillSequenceModule(mm, teachers, SinglePseudoLabelKDLoss(T, COEF), "cosine",
                                 trainable_args_kwargs={"freeze_global_weight": True, "freeze_global_bias": True})
     mod.item_embeddings = items

@@ -25,6 +25,7 @@ for i in range(N):
     g = torch.Generator().manual_seed(100 + i)
     fts.append(OrderedDict((k, v if k.endswith("position_ids") else v + 1e-3 * torch.randn(v.shape, generator=g)) for k, v in pre.items()))
 mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[learn], model, pre, fts, set(), disable_softmax=True, initial_per_weight=0.2)
+mm.train_mode = os.environ.get("TB_MODE", "f32")
 del fts
 g = torch.Generator().manual_seed(1)
 D = model.spec.hidden
@@ -71,7 +72,7 @@ for _ in range(K):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 1e3 / K
 P = mm.layout.numel
-print(f"{MODEL} {learn}: N={N} domains, B={B} sequences ({int(lens.sum())} tokens), P={P/1e6:.1f} M parameters, M={M}: {ms:.2f} ms/step "
+print(f"{MODEL} {learn} [{mm.train_mode}]: N={N} domains, B={B} sequences ({int(lens.sum())} tokens), P={P/1e6:.1f} M parameters, M={M}: {ms:.2f} ms/step "
       f"({1e3/ms:.1f} steps/s, {B*1e3/ms:.0f} sequences/s); loss {loss.item():.4f}")
 print(f"  parameter-sized streams per step: merge fwd {(N+2)*P*4/1e9:.2f} GB + alpha-gradient {(N+1)*P*4/1e9:.2f} GB "
       f"-> {((2*N+3)*P*4/1e9)/(ms/1e3)/1e3:.2f} TB/s of the step if nothing else moved")
