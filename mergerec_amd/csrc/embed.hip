@@ -85,6 +85,11 @@ __device__ __forceinline__ void ln_row_store(float4 (&x)[NV], int d, const float
     }
 }
 
+// kTokPerWave consecutive tokens per wave: LayerNorm's gamma / beta and (RoBERTa mode) the single token-type row are loaded once per wave
+// and kept in registers -- per token that leaves the word row (HBM) and the position row (L2) instead of five rows through L2, which is
+// what bounded the one-token-per-wave form (1.3 GB of L2 reads per 0.2 GB of HBM reads at 69 k tokens).
+constexpr int kTokPerWave = 2;
+
 template <int NV>
 __global__ __launch_bounds__(kThreads) void embed_gather_ln_kernel(
     const int32_t* __restrict__ tok_word, const int32_t* __restrict__ tok_pos, const int32_t* __restrict__ tok_tt,
@@ -93,28 +98,65 @@ __global__ __launch_bounds__(kThreads) void embed_gather_ln_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int T, int d, int mode,
     float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (t >= T) return;
-    const float* wr = word + (int64_t)clampi(tok_word[t], n_word) * d;
-    const float* pr = pos + (int64_t)clampi(tok_pos[t], n_pos) * d;
-    const float* tr = type + (int64_t)clampi(tok_tt ? tok_tt[t] : 0, n_type) * d;
-    const float* ir = (mode == MR_EMBED_RECFORMER) ? itempos + (int64_t)clampi(tok_ip[t], n_ip) * d : nullptr;
-    float4 x[NV];
+    const int t0 = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * kTokPerWave;
+    if (t0 >= T) return;
+    float4 g[NV], b[NV], ty0[NV];
+    const bool fixed_type = (tok_tt == nullptr);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = (j * MR_WAVE + lane) * 4;
-        if (c < d) {
-            const float4 w = ld4(wr + c), p = ld4(pr + c), ty = ld4(tr + c);
-            if (mode == MR_EMBED_RECFORMER) {
-                x[j] = add4(add4(add4(w, p), ty), ld4(ir + c));  // recformer/models.py:131
+        const bool in = c < d;
+        g[j] = in ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        b[j] = in ? ld4(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ty0[j] = (in && fixed_type) ? ld4(type + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int u = 0; u < kTokPerWave; ++u) {
+        const int t = t0 + u;
+        if (t >= T) break;
+        const float* wr = word + (int64_t)clampi(tok_word[t], n_word) * d;
+        const float* pr = pos + (int64_t)clampi(tok_pos[t], n_pos) * d;
+        const float* tr = fixed_type ? nullptr : type + (int64_t)clampi(tok_tt[t], n_type) * d;
+        const float* ir = (mode == MR_EMBED_RECFORMER) ? itempos + (int64_t)clampi(tok_ip[t], n_ip) * d : nullptr;
+        float4 x[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (j * MR_WAVE + lane) * 4;
+            if (c < d) {
+                const float4 w = ld4(wr + c), p = ld4(pr + c), ty = fixed_type ? ty0[j] : ld4(tr + c);
+                if (mode == MR_EMBED_RECFORMER) x[j] = add4(add4(add4(w, p), ty), ld4(ir + c));  // recformer/models.py:131
+                else x[j] = add4(add4(w, ty), p);  // RobertaEmbeddings: (inputs + token_type) + position
+                s += (x[j].x + x[j].y) + (x[j].z + x[j].w);
             } else {
-                x[j] = add4(add4(w, ty), p);  // RobertaEmbeddings: (inputs + token_type) + position
+                x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        } else {
-            x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // two-pass mean / variance exactly as ln_row_store
+        const float mean = mr::wave_sum(s) / (float)d;
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (j * MR_WAVE + lane) * 4;
+            if (c < d) {
+                const float a0 = x[j].x - mean, a1 = x[j].y - mean, a2 = x[j].z - mean, a3 = x[j].w - mean;
+                v += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(mr::wave_sum(v) / (float)d + eps);
+        float* o = out + (int64_t)t * d;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (j * MR_WAVE + lane) * 4;
+            if (c < d) {
+                float4 r;
+                r.x = (x[j].x - mean) * rstd * g[j].x + b[j].x;
+                r.y = (x[j].y - mean) * rstd * g[j].y + b[j].y;
+                r.z = (x[j].z - mean) * rstd * g[j].z + b[j].z;
+                r.w = (x[j].w - mean) * rstd * g[j].w + b[j].w;
+                *reinterpret_cast<float4*>(o + c) = r;
+            }
         }
     }
-    ln_row_store<NV>(x, d, gamma, beta, eps, out + (int64_t)t * d);
 }
 
 template <int NV>
@@ -224,7 +266,7 @@ extern "C" int mr_embed_gather_ln_f32(const int32_t* tok_word, const int32_t* to
         !mr::aligned16(beta) || !mr::aligned16(out) || (itempos && !mr::aligned16(itempos)))
         return MR_EALIGN;
     if (T == 0) return MR_OK;
-    const unsigned blocks = (unsigned)((T + kWavesPerBlock - 1) / kWavesPerBlock);
+    const unsigned blocks = (unsigned)((T + kWavesPerBlock * kTokPerWave - 1) / (kWavesPerBlock * kTokPerWave));
     MR_DISPATCH_NV(d, hipLaunchKernelGGL((embed_gather_ln_kernel<NV>), dim3(blocks), dim3(kThreads), 0,
                                          (hipStream_t)stream, tok_word, tok_pos, tok_tt, tok_ip, word, pos, type, itempos,
                                          n_word, n_pos, n_type, n_ip, gamma, beta, eps, T, d, mode, out));
