@@ -139,10 +139,22 @@ def main():
 
     n_total = args.steps + args.warmup
     g = torch.Generator().manual_seed(1234 + rank)
+    # N > 1: token-balanced sharding (parallel.balanced_share).  Every rank draws the SAME global pool of lengths (N x the per-GPU batch, one
+    # shared seed) and takes its snake-dealt share: equal sequence counts and near-equal token totals per rank, so no rank waits for another
+    # at the step's all-gather.  (Independent random shards differ by a few % in tokens: the slowest of 8 sets the pace.)
+    g_pool = torch.Generator().manual_seed(4321)
+
+    def my_share(lengths_fn, per_rank):
+        if world == 1:
+            return lengths_fn(per_rank, g)
+        pool = lengths_fn(per_rank * world, g_pool)
+        mine = pool[parallel.balanced_share(pool, world, rank)]
+        return mine[torch.randperm(per_rank, generator=g)]       # batch order is not length order
+
     user_batches, item_batches, label_batches = [], [], []
     for s in range(n_total):
-        ul = blair_sequence_lengths(U_step, g)
-        il = blair_item_lengths(I_step, g)
+        ul = my_share(blair_sequence_lengths, U_step)
+        il = my_share(blair_item_lengths, I_step)
         ub = _ids_from_lengths(ul, spec.vocab, g)
         ib = _ids_from_lengths(il, spec.vocab, g)
         user_batches.append(({k: v.to(dev) for k, v in ub.items()}, ul))
@@ -275,7 +287,7 @@ def main():
                 domains_merged=n_dom, catalog_items=M, users_per_step_per_gpu=U_step, items_per_step_per_gpu=I_step,
                 avg_user_tokens=avg_user_tokens, avg_item_tokens=avg_item_tokens, topk=50, params=layout.numel,
                 parallelism=(f"dp{world}: " + ("arena-slice merge + all-gather" if sliced else "task vectors replicated, whole-arena merge per rank (no collective)")
-                             + ", catalog rows sharded + all-gather, users data-parallel"),
+                             + ", catalog rows sharded + all-gather, users data-parallel (token-balanced shards)"),
             ),
             roofline=roofline, cpu_baseline=cpu_baseline, kernels=kernels, parity=parity,
         )

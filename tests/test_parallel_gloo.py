@@ -118,3 +118,22 @@ def test_data_parallel_alpha_gradients_and_sharding():
         assert g0 == [1.5, 1.5, 1.5] and g1 == [[0.0, 1.5], [3.0, 4.5]] and g2 is None
     a, b = out[0][3], out[1][3]
     assert len(a) == len(b) == 6 and set(a) | set(b) == set(range(11))  # every sample seen, equal batch counts (one wrap-around)
+
+
+def test_balanced_share_equalises_tokens():
+    """token-balanced sharding of Amazon-shaped lengths: a partition of the pool, equal counts, totals within 0.5 % (independent draws: > 5 %)"""
+    from mergerec_amd.parallel import balanced_share
+    from mergerec_amd.synthetic import blair_sequence_lengths
+
+    world, per = 8, 256
+    pool = blair_sequence_lengths(world * per, torch.Generator().manual_seed(4321))
+    shares = [balanced_share(pool, world, r) for r in range(world)]
+    assert all(s.numel() == per for s in shares)
+    assert sorted(torch.cat(shares).tolist()) == list(range(world * per))
+    tokens = [int(pool[s].sum()) for s in shares]
+    assert max(tokens) <= 1.005 * min(tokens), tokens
+    squares = [float((pool[s].double() ** 2).sum()) for s in shares]  # attention work
+    assert max(squares) <= 1.01 * min(squares), squares
+    with pytest.raises(ValueError):
+        balanced_share(pool[:-1], world, 0)
+
