@@ -139,7 +139,47 @@ def main():
         optim_cases.append(dict(warmup_steps=warmup, weight_decay=wd, gradient_clip_val=clip, estimated_stepping_batches=total, learning_rate=1e-2,
                                 group_weight_decay=[grp["weight_decay"] for grp in opt.param_groups], group_names=groups, init=init, steps=rec,
                                 betas=opt.defaults["betas"], eps=opt.defaults["eps"], temperature=0.05))
-    torch.save(dict(scores=score_cases, optim=optim_cases, toy=dict(vocab=vocab, d=d, seed=5)), OUT / "g9_finetune.pt")
+    # ---------------------------------------------------------------- the WHOLE training step of the reference on the real encoder family:
+    # RecModule (reference) around transformers' RobertaModel (the library the reference delegates the encoder to; tiny config with the
+    # true head size, seeded weights): in-batch negatives, cosine similarity, temperature 0.05 -> loss and d loss / d every parameter.
+    from transformers import RobertaConfig, RobertaModel
+
+    from oracle import ref_cpu as O
+
+    cfg = O.EncoderConfig(hidden=128, heads=2, layers=2, intermediate=256, vocab=300, max_pos=130)
+    hc = RobertaConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                       intermediate_size=cfg.intermediate, max_position_embeddings=cfg.max_pos, type_vocab_size=cfg.token_type_size,
+                       pad_token_id=cfg.pad_id, layer_norm_eps=cfg.ln_eps, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = O.random_state_dict(O.roberta_param_shapes(cfg), seed=2025, std=0.05)
+
+    class Wrapper(nn.Module):  # rec_retrieval/module/models/encoder/_base.py:32-49 with pooling_method="cls"
+        def __init__(self):
+            super().__init__()
+            self.tokenizer = None
+            self.model = RobertaModel(hc, add_pooling_layer=True)
+            self.model.load_state_dict({k[len("model."):]: v for k, v in sd.items()}, strict=True)
+
+        def forward(self, batch):
+            return self.model(**batch).last_hidden_state[:, 0, :]
+
+    def text_batch(B, L):
+        lens = torch.randint(3, L + 1, (B,), generator=g)
+        ids = torch.randint(3, cfg.vocab, (B, L), generator=g)
+        ids[:, 0] = 0
+        mask = (torch.arange(L).view(1, L) < lens.view(B, 1)).long()
+        return {"input_ids": ids * mask + cfg.pad_id * (1 - mask), "attention_mask": mask}
+
+    wrapper = Wrapper().train()
+    rm = mod.RecModule(model=wrapper, evaluator=Evaluator(metrics=["NDCG"], ks=[1]), negative_sample=NegativeSampleConfig(in_batch=True),
+                       similarity="cosine", temperature=0.05)
+    seq_b, tgt_b = text_batch(10, 40), text_batch(10, 12)
+    loss = rm.training_step(BatchSequenceWithNegative(sequence=enc(seq_b), target=enc(tgt_b), negatives=None), 0)
+    loss.backward()
+    grads = OrderedDict(("model." + k, (p.grad.detach().clone() if p.grad is not None else None)) for k, p in wrapper.model.named_parameters())
+    step = dict(cfg=cfg.__dict__, state_dict=OrderedDict(("model." + k, v.detach().clone()) for k, v in wrapper.model.state_dict().items()),
+                sequence=seq_b, target=tgt_b, loss=loss.detach(), grads=grads, temperature=0.05)
+    torch.save(dict(scores=score_cases, optim=optim_cases, toy=dict(vocab=vocab, d=d, seed=5), roberta_step=step), OUT / "g9_finetune.pt")
+    print("roberta step loss", float(loss))
     print("wrote", OUT / "g9_finetune.pt", [c["mode"] for c in score_cases], [len(c["steps"]) for c in optim_cases])
 
 

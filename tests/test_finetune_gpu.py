@@ -147,6 +147,40 @@ def test_bf16x3_training_graph_matches_exact_fp32_graph():
     assert float((a - b).norm()) <= 1e-3 * float(a.norm())
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_whole_training_step_matches_reference_on_hf_roberta(mode):
+    """g9 roberta_step: loss and d loss / d every parameter of the reference's own RecModule.training_step around transformers'
+    RobertaModel (recorded in the build container) against the HIP training step -- no oracle in between"""
+    from mergerec_amd.configs import NegativeSampleConfig
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.model_batch import BatchSequenceWithNegative
+    from mergerec_amd.module import ModelType, RecModule
+
+    st = load_golden("g9_finetune.pt")["roberta_step"]
+    c = st["cfg"]
+    over = dict(hidden=c["hidden"], heads=c["heads"], layers=c["layers"], intermediate=c["intermediate"], vocab=c["vocab"], max_pos=c["max_pos"])
+    model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "spec_overrides": over, "device": DEV, "gemm_mode": "f32"})
+    model.load_state_dict(st["state_dict"])
+    model.train_mode = mode
+    mod = RecModule(model=model, evaluator=Evaluator(["NDCG"], [1]), negative_sample=NegativeSampleConfig(in_batch=True), similarity="cosine",
+                    temperature=st["temperature"])
+    mod.train()
+    leaf = model.train_leaf()
+    leaf.grad = None
+    loss = mod.training_step(BatchSequenceWithNegative(sequence=st["sequence"], target=st["target"]).to(DEV), 0)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), st["loss"], rtol=2e-5, atol=2e-5)
+    got = model._weights.layout.views(leaf.grad)
+    gmax = max(float(g.abs().max()) for g in st["grads"].values() if g is not None)
+    for k, g in st["grads"].items():
+        if g is None:
+            assert float(got[k].abs().max()) == 0.0, k
+            continue
+        err = float((got[k].cpu() - g).abs().max())
+        # (key biases have a mathematically zero gradient: their scale is floored, as in test_train_gpu)
+        assert err <= 3e-3 * max(float(g.abs().max()), 1e-3 * gmax), (k, err, float(g.abs().max()))
+
+
 class _FixedReps(torch.nn.Module):
     """stands where the encoder stands: hands back preset rows (with an autograd edge) for whatever batch arrives"""
 

@@ -200,3 +200,23 @@ def test_optimizer_groups_schedule_and_adamw_match_reference():
             for n in names:
                 O.adamw_step(p[n], rec["grads"][n] * coef, m[n], v[n], lr, wd[n], s + 1, c["betas"], c["eps"])
                 torch.testing.assert_close(p[n], rec["params"][n], rtol=1e-6, atol=1e-7, msg=lambda e: f"step {s} {n}: {e}")
+
+
+def test_whole_training_step_matches_reference_on_hf_roberta():
+    """g9 roberta_step: the reference's RecModule.training_step around transformers' RobertaModel (in-batch negatives, cosine, T = 0.05):
+    loss and d loss / d every parameter, against torch autograd through the oracle's encoder restatement"""
+    st = load_golden("g9_finetune.pt")["roberta_step"]
+    cfg = O.EncoderConfig(**{k: v for k, v in st["cfg"].items() if k in O.EncoderConfig.__dataclass_fields__})
+    p = OrderedDict((k, v.clone().requires_grad_(v.is_floating_point())) for k, v in st["state_dict"].items())
+    enc = lambda b: O.maybe_normalize(O.roberta_encode(p, b["input_ids"], b["attention_mask"], cfg, prefix="model."))
+    scores, labels = O.negative_sample_scores(enc(st["sequence"]), enc(st["target"]), None, "IN_BATCH", None)
+    loss = O.finetune_loss(scores, labels, st["temperature"])
+    torch.testing.assert_close(loss.detach(), st["loss"], rtol=1e-5, atol=1e-5)
+    loss.backward()
+    gmax = max(float(g.abs().max()) for g in st["grads"].values() if g is not None)
+    for k, g in st["grads"].items():
+        if g is None:  # pooler: not on the CLS path
+            assert p[k].grad is None or float(p[k].grad.abs().max()) == 0.0, k
+            continue
+        err = float((p[k].grad - g).abs().max())
+        assert err <= 2e-4 * max(float(g.abs().max()), 1e-3 * gmax), (k, err)
