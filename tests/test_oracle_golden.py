@@ -220,3 +220,45 @@ def test_whole_training_step_matches_reference_on_hf_roberta():
             continue
         err = float((p[k].grad - g).abs().max())
         assert err <= 2e-4 * max(float(g.abs().max()), 1e-3 * gmax), (k, err)
+
+
+def _g10_finetunes(g10):
+    fts = [O.perturbed_state_dict(g10["pretrain"], seed=s, std=g10["finetune_std"]) for s in g10["finetune_seeds"]]
+    assert abs(float(sum(v.double().sum() for ft in fts for v in ft.values())) - g10["finetune_checksum"]) < 1e-6 * abs(g10["finetune_checksum"]) + 1e-6
+    return fts
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_whole_merge_train_step_matches_reference(case):
+    """g10: one collaborative-merging step of the reference itself (load_merging_module + DistillSequenceModule.training_step around
+    transformers' RobertaModel, SINGLE_PSEUDO_LABEL_KD) -- loss and d loss / d alpha -- against autograd through the oracle's merge +
+    encoder + loss restatements"""
+    g10 = load_golden("g10_merge_train_step.pt")
+    c = g10["cases"][case]
+    cfg = O.EncoderConfig(**{k: v for k, v in g10["cfg"].items() if k in O.EncoderConfig.__dataclass_fields__})
+    pre, fts = g10["pretrain"], _g10_finetunes(g10)
+    pre_a, fts_a = O.align_state_dicts(pre, fts)
+    base, shapes = O.flatten_model(pre_a)
+    tv = O.get_task_vectors(base, [O.flatten_model(ft)[0] for ft in fts_a])
+    N = len(fts)
+    groups = O.group_parameters_by_layer(shapes) if c["learn_type"] == "LAYER_WISE" else None
+    keys = c["groups"]
+    per = {k: torch.full((N,), g10["initial_per_weight"], requires_grad=True) for k in keys}
+    gw = {k: torch.ones(1, requires_grad=True) for k in keys}
+    gb = {k: torch.zeros(1, requires_grad=True) for k in keys}
+    if groups is None:
+        merged = O.merge_task_wise(base, tv, O.effective_alpha(gw["all"], gb["all"], per["all"], True))
+    else:
+        assert list(groups.keys()) == keys
+        merged = O.merge_layer_wise(base, tv, groups, {k: O.effective_alpha(gw[k], gb[k], per[k], True) for k in keys})
+    sd = O.get_state_dict(merged, shapes)
+    reps = O.maybe_normalize(O.roberta_encode(sd, g10["input_ids"], g10["attention_mask"], cfg, prefix="model."))
+    loss = O.forward_distill(reps, g10["item_embeddings"], g10["score_embeddings"], g10["dataset_indexes"], g10["sequence_ids"],
+                             lambda z, t: O.distill_loss("SINGLE_PSEUDO_LABEL_KD", z, t, g10["temperature"], g10["coefficient"]))
+    torch.testing.assert_close(loss.detach(), c["loss"], rtol=2e-5, atol=2e-5)
+    loss.backward()
+    for name, mine in (("per_weights", per), ("global_weights", gw), ("global_biases", gb)):
+        for k in keys:
+            want = c["grads"][name][k]
+            scale = max(float(want.abs().max()), 1e-3)
+            assert float((mine[k].grad - want).abs().max()) <= 2e-3 * scale, (name, k, mine[k].grad, want)

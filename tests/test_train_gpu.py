@@ -293,3 +293,38 @@ def test_merge_train_cli_recformer(tmp_path):
     per = res["weights"]["per_weights"]
     assert set(per) >= {"others", "0", "1"} and any(abs(w - 0.2) > 1e-4 for ws in per.values() for w in ws), per
     assert "test/dataset_0/test/NDCG@10" in res["test_metrics"]
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_whole_merge_train_step_matches_reference(case):
+    """g10: one collaborative-merging step of the reference ITSELF (its load_merging_module + DistillSequenceModule.training_step around
+    transformers' RobertaModel, recorded in the build container): loss and d loss / d (per_weights, global_weights, global_biases),
+    task-wise and layer-wise, against the HIP step -- no oracle in between"""
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchDistillationSequence
+    from mergerec_amd.module import DistillSequenceModule, ModelType
+    from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
+
+    g10 = load_golden("g10_merge_train_step.pt")
+    c = g10["cases"][case]
+    cfgd = g10["cfg"]
+    fts = [O.perturbed_state_dict(g10["pretrain"], seed=s, std=g10["finetune_std"]) for s in g10["finetune_seeds"]]
+    over = dict(hidden=cfgd["hidden"], heads=cfgd["heads"], layers=cfgd["layers"], intermediate=cfgd["intermediate"], vocab=cfgd["vocab"],
+                max_pos=cfgd["max_pos"])
+    model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 1, "spec_overrides": over, "device": DEV})
+    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[c["learn_type"]], model, g10["pretrain"], [dict(f) for f in fts], set(),
+                             disable_softmax=True, initial_per_weight=g10["initial_per_weight"])
+    assert list(mm.per_weights.keys()) == c["groups"]
+    mod = DistillSequenceModule(mm, g10["score_embeddings"], SinglePseudoLabelKDLoss(g10["temperature"], g10["coefficient"]), "cosine")
+    mod.item_embeddings = g10["item_embeddings"]
+    batch = BatchDistillationSequence(dataset_indexes=g10["dataset_indexes"], sequence_ids=torch.tensor(g10["sequence_ids"]),
+                                      sequence={"input_ids": g10["input_ids"], "attention_mask": g10["attention_mask"]})
+    mod.train()
+    loss = mod.training_step(batch.to(DEV), 0)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), c["loss"], rtol=5e-5, atol=5e-5)
+    for name in ("per_weights", "global_weights", "global_biases"):
+        for k in c["groups"]:
+            want, got = c["grads"][name][k], getattr(mm, name)[k].grad.cpu()
+            scale = max(float(want.abs().max()), 1e-3)
+            assert float((got - want).abs().max()) <= 5e-3 * scale, (name, k, got, want)
