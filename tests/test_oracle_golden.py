@@ -262,3 +262,23 @@ def test_whole_merge_train_step_matches_reference(case):
             want = c["grads"][name][k]
             scale = max(float(want.abs().max()), 1e-3)
             assert float((mine[k].grad - want).abs().max()) <= 2e-3 * scale, (name, k, mine[k].grad, want)
+
+
+def test_recformer_parameter_gradients_match_reference():
+    """g11: d sum(normalize(CLS) * R) / d every parameter of the reference's RecformerModel (its embeddings / mask helpers driving the
+    library's LongformerEncoder, as for g4) against autograd through the oracle's restatement"""
+    g4, g11 = load_golden("g4_recformer.pt"), load_golden("g11_recformer_grads.pt")
+    for case, gr in zip(g4["cases"], g11["cases"]):
+        cfgd, sd, b = case["cfg"], case["state_dict"], case["batch"]
+        cfg = O.EncoderConfig(**{k: cfgd[k] for k in cfgd if k in O.EncoderConfig.__dataclass_fields__})
+        p = OrderedDict((k, v.clone().float().requires_grad_(v.is_floating_point())) for k, v in sd.items())
+        cls = O.recformer_encode(p, b["input_ids"], b["attention_mask"], b["global_attention_mask"], b["token_type_ids"], b["item_position_ids"], cfg,
+                                 prefix="model.")
+        (O.maybe_normalize(cls) * gr["R"]).sum().backward()
+        gmax = max(float(g.abs().max()) for g in gr["grads"].values() if g is not None)
+        for k, g in gr["grads"].items():
+            if g is None:
+                assert p[k].grad is None or float(p[k].grad.abs().max()) == 0.0, k
+                continue
+            err = float((p[k].grad - g).abs().max())
+            assert err <= 5e-4 * max(float(g.abs().max()), 1e-3 * gmax), (k, err, float(g.abs().max()))

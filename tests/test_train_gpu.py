@@ -264,6 +264,32 @@ def test_recformer_backward_matches_oracle_autograd():
             assert err <= 3e-3, (k, err, scale)
 
 
+def test_recformer_backward_matches_reference_gradients():
+    """g11: every parameter gradient of the reference's RecformerModel (its own embeddings / mask helpers driving the library's
+    LongformerEncoder under autograd, recorded in the build container) against the HIP training graph -- no oracle in between"""
+    from mergerec_amd.engine import ArenaLayout, EncoderRunner
+    from mergerec_amd.engine_train import EncoderTrainGraph, encode_with_grad
+    from tests.test_path_gpu import _spec
+
+    for case, gr in zip(load_golden("g4_recformer.pt")["cases"], load_golden("g11_recformer_grads.pt")["cases"]):
+        cfgd, sd, b = case["cfg"], case["state_dict"], case["batch"]
+        views = OrderedDict((k, v.to(torch.float32)) for k, v in sd.items())
+        layout = ArenaLayout(OrderedDict((k, tuple(v.shape)) for k, v in views.items()))
+        flat = layout.pack(views, DEV).requires_grad_(True)
+        spec = _spec(cfgd, "recformer")
+        out = encode_with_grad(EncoderTrainGraph(spec, layout), flat, EncoderRunner(spec).pack(b, DEV))
+        (torch.nn.functional.normalize(out, dim=-1) * gr["R"].to(DEV)).sum().backward()
+        got = layout.views(flat.grad)
+        gmax = max(float(g.abs().max()) for g in gr["grads"].values() if g is not None)
+        for k, g in gr["grads"].items():
+            if g is None:
+                assert float(got[k].abs().max()) == 0.0, k
+                continue
+            scale = max(float(g.abs().max()), 1e-3 * gmax)
+            err = float((got[k].cpu() - g).abs().max()) / scale
+            assert err <= 3e-3, (k, err, scale)
+
+
 def test_merge_train_cli_recformer(tmp_path):
     """the optimisation loop on a Recformer-shaped model: pre-tokenised item sequences, Longformer attention backward, layer-wise alpha"""
     import sys
