@@ -1,12 +1,14 @@
 """One-process-per-GPU sharding of the path over the 8 GPUs of a node (RCCL over xGMI via
 torch.distributed backend "nccl").  The reference is single-GPU; this partitioning is new.
 
-  merge      : rank r merges arena elements [lo_r, hi_r) (64-float aligned slices) with the same kernel,
-               then ONE all-gather of the merged slices fills every rank's arena (P_pad/8 * 4 B = 62 MB per
-               rank for BLaIR-base).  No other collective touches parameters.
+  merge      : two placements.  "replicated" (bench default): every rank keeps all task vectors (8 x 0.5 GB of 288 GB) and merges the
+               whole arena locally with the N = 1 kernel call -- no collective (HBM streams a merge in < 1 ms; the all-gather below alone
+               would take longer over xGMI).  "sliced" (``sharded_merge``): rank r merges arena elements [lo_r, hi_r) (64-float aligned
+               slices) with the same kernel, then ONE all-gather of the merged slices fills every rank's arena (P_pad/8 * 4 B = 62 MB per
+               rank for BLaIR-base) -- for task vectors that do not fit replicated.  No other collective touches parameters.
   catalog    : item rows are split in contiguous blocks; each rank encodes its block, one all-gather of the
                (M/world, d) embedding blocks gives every rank the full E (row index == item id is kept).
-  users      : data-parallel over test sequences; scoring is local against the full E.
+  users      : data-parallel over test sequences, token-balanced across ranks (``balanced_share``); scoring is local against the full E.
   metrics    : label ranks / lse / label logits are all-gathered (a few bytes per user); the metric sums
                are then evaluated identically on every rank.
 
