@@ -18,8 +18,26 @@ B, ACC, K = int(os.environ.get("FB_B", 64)), int(os.environ.get("FB_ACC", 4)), i
 torch.manual_seed(0)
 model = ModelType[MODEL].value(model_kwargs={"init_seed": 7})
 model.train_mode = os.environ.get("FB_MODE", "bf16x3")  # the reference recipe's precision is bf16-mixed
-if MODEL.startswith("RECFORMER"):
-    raise SystemExit("synthetic Recformer batches: use tests/tools/train_bench.py's generator (not wired here)")
+REC = MODEL.startswith("RECFORMER")
+
+
+def recformer_fields(enc, item_len=38):
+    """token types (0 <s>, 1 attribute-name tokens = the first 3 of every item, 2 value tokens, 3 padding), item positions 1.. (50 max) and
+    the global mask on <s> for a batch that came out of _ids_from_lengths (sequence = <s> + items, recformer_utils.py:45-68)"""
+    ids, mask = enc["input_ids"], enc["attention_mask"]
+    L = ids.shape[1]
+    pos = torch.arange(L).view(1, L).expand_as(ids)
+    within = (pos - 1) % item_len
+    tt = torch.where(within < 3, torch.ones_like(ids), torch.full_like(ids, 2))
+    tt[:, 0] = 0
+    tt = torch.where(mask.bool(), tt, torch.full_like(ids, 3))
+    ip = (1 + (pos - 1) // item_len).clamp(max=50)
+    ip[:, 0] = 0
+    ip = ip * mask
+    ga = torch.zeros_like(ids)
+    ga[:, 0] = 1
+    return dict(enc, token_type_ids=tt, item_position_ids=ip, global_attention_mask=ga)
+
 mod = RecModule(model=model, evaluator=Evaluator(["NDCG"], [10]), negative_sample=NegativeSampleConfig(in_batch=True), similarity="cosine",
                 temperature=0.05, learning_rate=5e-5, warmup_steps=100, weight_decay=0.0)
 mod.trainer = type("Tr", (), {"estimated_stepping_batches": 10000, "gradient_clip_val": float(os.environ.get("FB_CLIP", 1.0))})()
@@ -30,8 +48,10 @@ g = torch.Generator().manual_seed(1)
 batches = []
 for _ in range(ACC):
     ul, il = blair_sequence_lengths(B, g), blair_item_lengths(B, g)
-    batches.append((BatchSequenceWithNegative(sequence=_ids_from_lengths(ul, model.spec.vocab, g), target=_ids_from_lengths(il, model.spec.vocab, g)).to(DEV),
-                    int(ul.sum() + il.sum())))
+    seq_e, tgt_e = _ids_from_lengths(ul, model.spec.vocab, g), _ids_from_lengths(il, model.spec.vocab, g)
+    if REC:
+        seq_e, tgt_e = recformer_fields(seq_e), recformer_fields(tgt_e)
+    batches.append((BatchSequenceWithNegative(sequence=seq_e, target=tgt_e).to(DEV), int(ul.sum() + il.sum())))
 tokens = sum(t for _, t in batches) / ACC
 
 
@@ -69,9 +89,10 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 opt_ms = e0.elapsed_time(e1) / 10
-flops = 3 * 2 * 7.08e6 * 12 * tokens  # forward + 2x backward of the 12 layers' linear maps (attention extra)
+sp = model.spec
+per_tok = 2.0 * sp.layers * (4 * sp.hidden * sp.hidden + 2 * sp.hidden * sp.intermediate + (2 * sp.hidden * sp.hidden if REC else 0))  # + key/value_global
 print(f"{MODEL} [{model.train_mode}]: batch {B} sequences + {B} targets ({tokens:.0f} tokens / micro-step), accumulation {ACC}, P = {P/1e6:.1f} M: "
-      f"{ms:.1f} ms / optimizer step = {ms/ACC:.1f} ms / micro-step ({B*ACC*1e3/ms:.0f} sequences/s, {3*2*7.08e6*12*tokens*ACC/ms/1e9:.0f} TFLOP/s of linear-map math); loss {float(loss.detach()):.4f}")
+      f"{ms:.1f} ms / optimizer step = {ms/ACC:.1f} ms / micro-step ({B*ACC*1e3/ms:.0f} sequences/s, {3*per_tok*tokens*ACC/ms/1e9:.0f} TFLOP/s of linear-map math); loss {float(loss.detach()):.4f}")
 print(f"  clip + AdamW over the arena: {opt_ms:.3f} ms (sum of squares 4 B + step 28 B per parameter -> {32*P/opt_ms/1e9:.2f} TB/s)")
 if os.environ.get("FB_CPU", "0") == "1":
     from oracle import ref_cpu as O
@@ -79,6 +100,7 @@ if os.environ.get("FB_CPU", "0") == "1":
     p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     b = batches[0][0].to("cpu")
     t0 = time.perf_counter()
+    assert not REC, "FB_CPU: BLaIR only"
     u = O.maybe_normalize(O.roberta_encode(p, b.sequence["input_ids"], b.sequence["attention_mask"], O.EncoderConfig(), prefix="model."))
     t = O.maybe_normalize(O.roberta_encode(p, b.target["input_ids"], b.target["attention_mask"], O.EncoderConfig(), prefix="model."))
     s, l = O.negative_sample_scores(u, t, None, "IN_BATCH", None)
