@@ -120,6 +120,37 @@ def _split_sequences(batch, reverse: bool):
     return inputs, targets
 
 
+def _encode_texts(owner, texts):
+    """``owner.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=owner.max_seq_len)`` -- through a private
+    copy of the fast tokenizer's Rust backend with right-truncation to max_seq_len and pad-to-longest switched on (what that call
+    configures per call).  Going to the backend directly skips transformers' python-side BatchEncoding assembly, which costs 4x the
+    tokenisation itself (3.5 s of the 5.2 s evaluation loop of a 14 k-user domain was ``convert_to_tensors``): with it the loop is bound by
+    the GPU, not by the collator.  Tokenizers without a fast backend / with left padding take the transformers route unchanged."""
+    if not hasattr(owner, "_backend"):
+        owner._backend = None
+        tok = owner.tokenizer
+        be = getattr(tok, "backend_tokenizer", None)
+        pad_id, pad_tok = getattr(tok, "pad_token_id", None), getattr(tok, "pad_token", None)
+        side_ok = getattr(tok, "padding_side", "right") == "right" and getattr(tok, "truncation_side", "right") == "right"
+        if be is not None and pad_id is not None and pad_tok is not None and side_ok:
+            try:
+                from tokenizers import Tokenizer
+
+                fast = Tokenizer.from_str(be.to_str())
+                fast.enable_truncation(max_length=owner.max_seq_len)
+                fast.enable_padding(pad_id=pad_id, pad_token=pad_tok)
+                owner._backend = fast
+            except Exception:  # noqa: BLE001 - any tokenizer the shortcut does not understand takes the transformers route
+                owner._backend = None
+    if owner._backend is None:
+        return owner.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=owner.max_seq_len)
+    from transformers import BatchEncoding
+
+    encs = owner._backend.encode_batch(list(texts))
+    return BatchEncoding({"input_ids": torch.tensor([e.ids for e in encs], dtype=torch.int64),
+                          "attention_mask": torch.tensor([e.attention_mask for e in encs], dtype=torch.int64)})
+
+
 # ------------------------------------------------------------------------------------------------ text (BLaIR) collators
 class SingleItemCollator:
     """recommender.py:14-35."""
@@ -128,7 +159,7 @@ class SingleItemCollator:
         self.tokenizer, self.item_text, self.max_seq_len, self.item_prompt = tokenizer, item_text, max_seq_len, item_prompt
 
     def _encode(self, texts):
-        return self.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=self.max_seq_len)
+        return _encode_texts(self, texts)
 
     def __call__(self, batch: List[int]) -> BatchItem:
         return BatchItem(items=self._encode([self.item_prompt + self.item_text[i] for i in batch]))
@@ -452,7 +483,7 @@ class DistillSequenceCollator:
             ds_idx.append(d)
             seq_ids.append(sid)
             texts.append(self.sequence_prompt + self.separator.join(self.item_texts[d][i] for i in seq))
-        enc = self.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=self.max_seq_len)
+        enc = _encode_texts(self, texts)
         return BatchDistillationSequence(dataset_indexes=ds_idx, sequence_ids=torch.tensor(seq_ids, device=torch.device("cpu")), sequence=enc)
 
 
