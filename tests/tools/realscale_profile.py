@@ -8,7 +8,8 @@ import realscale_cli_check as R
 import merge_test
 tmp = Path(tempfile.mkdtemp(prefix="realscale_"))
 R.make_domain(tmp / "PantryLike", 4968, 14178)
-argv = ["--model_type", "blair_base", "--model_kwargs", "init_seed", "7", "--finetune_checkpoint_paths", "synthetic:1", "synthetic:2",
+MODEL = os.environ.get("RS_MODEL", "blair_base")
+argv = ["--model_type", MODEL, "--model_kwargs", "init_seed", "7", "--finetune_checkpoint_paths", "synthetic:1", "synthetic:2",
         "--merge_type", "task_vector", "--learn_type", "task_wise", "--weight_file", "average", "--data_paths", str(tmp / "PantryLike"),
         "--tokenizer_path", str(ROOT / "tests" / "golden" / "mini_tokenizer"), "--batch_size", "32", "--test_data_split", "test"]
 os.environ["MERGEREC_GEMM_MODE"] = "bf16x3"
