@@ -132,7 +132,9 @@ def _encode_texts(owner, texts):
         be = getattr(tok, "backend_tokenizer", None)
         pad_id, pad_tok = getattr(tok, "pad_token_id", None), getattr(tok, "pad_token", None)
         side_ok = getattr(tok, "padding_side", "right") == "right" and getattr(tok, "truncation_side", "right") == "right"
-        if be is not None and pad_id is not None and pad_tok is not None and side_ok:
+        names = list(getattr(tok, "model_input_names", ["input_ids", "attention_mask"]))
+        plain = set(names) <= {"input_ids", "attention_mask"}  # (BERT-style tokenizers also emit token_type_ids: transformers route)
+        if be is not None and pad_id is not None and pad_tok is not None and side_ok and plain:
             try:
                 from tokenizers import Tokenizer
 
