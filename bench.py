@@ -7,23 +7,31 @@ torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 Workload (BASELINE.json metric: "sequences/sec full-catalog scoring, 8-domain merged BLaIR-base"):
   8 synthetic fine-tuned BLaIR-base checkpoints (theta_pre ~ N(0, 0.02^2), tau_i ~ N(0, 1e-3^2)) merged with
   fixed alpha = 1/8 ("average", merge_test.py:47-55); catalog of an Arts-sized domain (M = 22,855);
-  Amazon-shaped synthetic sequences; fp32 end to end (the parity configuration).
+  Amazon-shaped synthetic sequences; fp32-grade arithmetic end to end (the parity configuration).
+The step runs through the PRODUCT objects with their defaults -- `load_merging_module(...)` (sliced over the ranks when
+N > 1: each rank holds 1/N of the base vector and of every task vector), `RecModule.forward(BatchItem)`,
+`RecModule.test_step(BatchSequence)`, `on_test_epoch_end()` -- i.e. the calls merge_test.py / utils.test_model make.
+Input checks run inside the packing kernel; sequence lengths ride along from the collator side of `.to(device)`.
 A "step" is one pass of the WHOLE hot path over one batch, per rank:
-  (1) N-way alpha-weighted merge of this rank's arena slice (+ all-gather of slices when N > 1),
+  (1) N-way alpha-weighted merge of the parameter arena (this rank's slice + ONE all-gather when N > 1),
   (2) encode `items_per_step` catalog items and refresh those rows of the item-embedding matrix
       (+ all-gather of the refreshed rows when N > 1) -- users_per_step / items_per_step = 2 matches the
       measured users:items ratio of the Amazon domains, so U/users_per_step steps re-encode one full catalog,
   (3) encode `users_per_step` user sequences (CLS pooled, L2-normalised),
-  (4) score them against the FULL catalog and take the canonical top-50 (+ CE terms, label ranks).
+  (4) score them against the FULL catalog and take the canonical top-50 (+ CE terms, label ranks);
+after the K steps the evaluation epoch ends inside the timed region (metric gather + Recall / NDCG).
 Nothing is cached across steps; inputs are resident in HBM before the timed region.
 value = users_per_step * N * K / max-over-ranks wall time (weak scaling: per-GPU work is fixed).
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 from collections import OrderedDict
 
@@ -36,7 +44,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak
-SUSTAINED_CLOCK_GHZ = {"bf16x3": 1.1, "bf16x6": 1.44}  # measured inside the encoder GEMM kernels (profiles/r01_inkernel_clock.txt)
+PROFILE_ROUND = "r02"
 
 
 def parse():
@@ -53,89 +61,126 @@ def parse():
     ap.add_argument("--cpu-items", type=int, default=128)
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP-event timing")
     ap.add_argument("--gemm-mode", choices=["bf16x6", "bf16x3", "f32"], default=None,
-                    help="encoder GEMM arithmetic: bf16x3 (bench default) / bf16x6 = 3 / 6 bf16 MFMA products per fp32 product, "
+                    help="encoder arithmetic: bf16x3 (bench default) / bf16x6 = 3 / 6 bf16 MFMA products per fp32 product, "
                          "f32 = exact fp32 MFMA.  The in-run `parity` object reports the distance to the CPU oracle for the chosen mode.")
-    ap.add_argument("--merge-placement", choices=["replicated", "sliced"], default="replicated",
-                    help="N > 1: 'replicated' = every rank holds all task vectors and merges the whole arena locally (no collective: HBM streams "
-                         "the 5 GB of a merge in under 1 ms, xGMI would need longer for the 0.5 GB all-gather alone); 'sliced' = each rank "
-                         "merges 1/N of the arena and one all-gather assembles it (task vectors could then be sharded too: memory / N)")
+    ap.add_argument("--merge-placement", choices=["sliced", "replicated"], default=None,
+                    help="N > 1: 'sliced' (default; north_star's split) = each rank holds 1/N of the base vector and of every task vector, merges "
+                         "that arena slice, ONE all-gather assembles the arena; 'replicated' = every rank holds everything and merges alone")
     return ap.parse_args()
 
 
-def synth_arena(layout, padded, n_dom, device, seed=1000):
-    """Seeded synthetic weights generated directly in arena layout on the device (plumbing, untimed)."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    base = torch.zeros(padded, dtype=torch.float32, device=device)
-    for k in layout.shapes:
-        v = layout.view(base, k)
-        if "LayerNorm.weight" in k:
-            v.fill_(1.0)
-        elif "LayerNorm.bias" in k:
-            v.zero_()
-        else:
-            v.copy_(torch.randn(v.shape, generator=g, device=device) * 0.02)
-    tv = torch.zeros(n_dom, padded, dtype=torch.float32, device=device)
+# ------------------------------------------------------------------------------------------------ power / clock sampling
+class DeviceSampler(threading.Thread):
+    """Samples the GPU's shader clock and socket power from the amdgpu hwmon files while the timed region runs (a host thread
+    reading sysfs every few ms: no GPU work, no sync).  Evidence for / against a power-limited clock in THIS run."""
+
+    def __init__(self, pci_bus_id: str | None, period_s: float = 0.004):
+        super().__init__(daemon=True)
+        self.period = period_s
+        self.stop_flag = threading.Event()
+        self.sclk, self.power = [], []
+        self.dir, self.cap_w, self.note = None, None, None
+        cands = []
+        if pci_bus_id:
+            cands += glob.glob(f"/sys/bus/pci/devices/{pci_bus_id.lower()}/hwmon/hwmon*")
+        cands += sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        for c in cands:
+            if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input")) or os.path.exists(os.path.join(c, "freq1_input")):
+                self.dir = c
+                break
+        if self.dir is None:
+            self.note = "no readable amdgpu hwmon directory"
+            return
+        self.f_power = next((os.path.join(self.dir, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(self.dir, n))), None)
+        self.f_sclk = os.path.join(self.dir, "freq1_input") if os.path.exists(os.path.join(self.dir, "freq1_input")) else None
+        cap = self._read(os.path.join(self.dir, "power1_cap"))
+        self.cap_w = cap / 1e6 if cap else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:  # noqa: BLE001
+            return None
+
+    def run(self):
+        if self.dir is None:
+            return
+        while not self.stop_flag.is_set():
+            if self.f_sclk:
+                v = self._read(self.f_sclk)
+                if v:
+                    self.sclk.append(v / 1e6)  # Hz -> MHz
+            if self.f_power:
+                v = self._read(self.f_power)
+                if v:
+                    self.power.append(v / 1e6)  # uW -> W
+            time.sleep(self.period)
+
+    def summary(self):
+        mean = lambda xs: (sum(xs) / len(xs)) if xs else None
+        return dict(sclk_mhz_mean=mean(self.sclk), sclk_mhz_min=min(self.sclk) if self.sclk else None, power_w_mean=mean(self.power),
+                    power_w_max=max(self.power) if self.power else None, power_cap_w=self.cap_w, samples=max(len(self.sclk), len(self.power)),
+                    source=(self.dir or self.note))
+
+
+def _sha16(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def synth_state_dicts(model, n_dom, device, seed=1001):
+    """Seeded synthetic fine-tuned checkpoints, generated on the device (plumbing, untimed): theta_i = theta_pre + N(0, 1e-3^2)."""
+    pre = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
+    fts = []
     for i in range(n_dom):
-        gi = torch.Generator(device=device).manual_seed(seed + 1 + i)
-        for k in layout.shapes:
-            layout.view(tv[i], k).copy_(torch.randn(layout.shapes[k], generator=gi, device=device) * 1e-3)
-    return base, tv
+        g = torch.Generator(device=device).manual_seed(seed + i)
+        fts.append(OrderedDict((k, v if k.endswith("position_ids") else v + 1e-3 * torch.randn(v.shape, generator=g, device=device)) for k, v in pre.items()))
+    return pre, fts
 
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env == 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
 
-    # one rank per GPU; MERGEREC_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals of the N > 1 path
-    backend = os.environ.get("MERGEREC_DIST_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
-    if backend == "nccl" and world > ndev:
-        raise SystemExit(f"{world} ranks need {world} GPUs, {ndev} visible")
-    local_dev = local_rank % max(ndev, 1)
-    torch.cuda.set_device(local_dev)
-    dev = torch.device("cuda", local_dev)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
     from mergerec_amd import ops, parallel
-    from mergerec_amd.engine import ArenaLayout, EncoderRunner, EncoderSpec, WeightSet
+
+    rank, world = parallel.init_from_env(verbose=False)  # one rank per GPU; MERGEREC_DIST_BACKEND=gloo rehearses several ranks on one GPU
+    backend = dist.get_backend() if world > 1 else None
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchItem, BatchSequence
+    from mergerec_amd.module import ModelType, RecModule
     from mergerec_amd.synthetic import blair_item_lengths, blair_sequence_lengths, _ids_from_lengths
 
-    spec = EncoderSpec.blair_base()
-    layout = ArenaLayout(spec.param_shapes("model."))
-    sliced = world > 1 and args.merge_placement == "sliced"
-    plan = parallel.SlicePlan(layout.padded_numel, world if sliced else 1)
-    runner = EncoderRunner(spec)
-    n_dom, M, d = args.domains, args.catalog, spec.hidden
+    n_dom, M = args.domains, args.catalog
     U_step, I_step = args.users_per_step, args.items_per_step
-
-    # ---------------- resident state (untimed setup) ----------------
-    base, tv = synth_arena(layout, plan.padded, n_dom, dev)
-    alpha = torch.full((1, n_dom), 1.0 / n_dom, dtype=torch.float32, device=dev)  # "average" weights
-    arena = torch.zeros(plan.padded, dtype=torch.float32, device=dev)
     # bench default: the fastest arithmetic that meets the path's 1e-4 logit tolerance with >= 50x margin on these dims
     # (bf16x3: measured 1.1e-6 on embeddings, 6e-7 on logits); MERGEREC_GEMM_MODE / --gemm-mode select the others
     gemm_mode = args.gemm_mode or os.environ.get("MERGEREC_GEMM_MODE") or "bf16x3"
-    W = WeightSet(layout, arena[: layout.padded_numel], gemm_mode)
-    lo, hi = plan.bounds(rank if sliced else 0)
-    scratch = torch.empty(hi - lo, dtype=torch.float32, device=dev) if sliced else None
 
-    def merge_slice(p_begin, p_count, out_slice):
-        ops.merge_nway(base, tv, alpha, None, out=out_slice, p_begin=p_begin, p_count=p_count, out_is_slice=True)
-
-    def merge_arena():
-        if sliced:  # this rank's slice, then ONE all-gather of the merged slices
-            parallel.sharded_merge(merge_slice, arena, plan, scratch)
-        else:  # whole arena from the rank's own copy of the task vectors (the N = 1 path on every rank)
-            merge_slice(0, plan.padded, arena)
+    # ---------------- resident state (untimed setup), through the drop-in API ----------------
+    model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 1000, "gemm_mode": gemm_mode})
+    spec, d = model.spec, model.spec.hidden
+    pre, fts = synth_state_dicts(model, n_dom, dev)
+    merged_model = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, pre, fts, set(), disable_softmax=True,
+                                       placement=args.merge_placement)
+    sliced = merged_model.slice_plan is not None
+    del fts
+    torch.cuda.empty_cache()
+    merged_model.load_weights_from_dict({"global_weights": {"all": [1.0]}, "global_biases": {"all": [0.0]},
+                                         "per_weights": {"all": [1.0 / n_dom] * n_dom}})  # "average" (merge_test.py:47-55)
+    module = RecModule(model=model, evaluator=Evaluator(["NDCG", "RECALL"], [1, 5, 10, 50]), similarity="cosine")
+    module.eval()
 
     n_total = args.steps + args.warmup
     g = torch.Generator().manual_seed(1234 + rank)
@@ -151,76 +196,85 @@ def main():
         mine = pool[parallel.balanced_share(pool, world, rank)]
         return mine[torch.randperm(per_rank, generator=g)]       # batch order is not length order
 
-    user_batches, item_batches, label_batches = [], [], []
+    # the collator side: CPU batches in the reference's dataclasses; `.to(dev)` (what the Trainer does per batch) happens HERE, before
+    # the timed region, so inputs are HBM-resident; the per-row lengths travel with the moved batch (model_batch.Encoding.host_lens)
+    user_batches, item_batches = [], []
+    tok_u = tok_i = 0
     for s in range(n_total):
-        ul = my_share(blair_sequence_lengths, U_step)
-        il = my_share(blair_item_lengths, I_step)
-        ub = _ids_from_lengths(ul, spec.vocab, g)
-        ib = _ids_from_lengths(il, spec.vocab, g)
-        user_batches.append(({k: v.to(dev) for k, v in ub.items()}, ul))
-        item_batches.append(({k: v.to(dev) for k, v in ib.items()}, il))
-        label_batches.append(torch.randint(0, M, (U_step,), generator=g).to(dev))
-    # items first, then users, padded to a common length on the host (padding never reaches a kernel)
-    mixed_batches = []
-    for (ib, il), (ub, ul) in zip(item_batches, user_batches):
-        L = max(ib["input_ids"].shape[1], ub["input_ids"].shape[1])
-        pad = lambda t, v: torch.nn.functional.pad(t, (0, L - t.shape[1]), value=v)
-        mixed_batches.append(({"input_ids": torch.cat([pad(ib["input_ids"], spec.pad_id), pad(ub["input_ids"], spec.pad_id)]),
-                               "attention_mask": torch.cat([pad(ib["attention_mask"], 0), pad(ub["attention_mask"], 0)])},
-                              torch.cat([il, ul])))
-    avg_user_tokens = float(torch.cat([l for _, l in user_batches]).float().mean())
-    avg_item_tokens = float(torch.cat([l for _, l in item_batches]).float().mean())
+        ul, il = my_share(blair_sequence_lengths, U_step), my_share(blair_item_lengths, I_step)
+        tok_u, tok_i = tok_u + int(ul.sum()), tok_i + int(il.sum())
+        labels = torch.randint(0, M, (U_step,), generator=g)
+        user_batches.append(BatchSequence(sequence=_ids_from_lengths(ul, spec.vocab, g), labels=labels).to(dev))
+        item_batches.append(BatchItem(items=_ids_from_lengths(il, spec.vocab, g)).to(dev))
+    avg_user_tokens, avg_item_tokens = tok_u / (n_total * U_step), tok_i / (n_total * I_step)
 
     # full catalog encoded once with the merged model (setup): E (M, d), row == item id
-    merge_arena()
-    W.refresh()
+    merged_model.load_weights()
     E = torch.empty(M, d, dtype=torch.float32, device=dev)
     gi = torch.Generator().manual_seed(99)
-    for s0 in range(0, M, 512):
-        n = min(512, M - s0)
-        il = blair_item_lengths(n, gi)
-        ib = {k: v.to(dev) for k, v in _ids_from_lengths(il, spec.vocab, gi).items()}
-        E[s0 : s0 + n] = runner.encode(W, ib, dev, normalize=True, lens=il, validate=False)
+    with torch.no_grad():
+        for s0 in range(0, M, 1024):
+            n = min(1024, M - s0)
+            E[s0 : s0 + n] = module.forward(BatchItem(items=_ids_from_lengths(blair_item_lengths(n, gi), spec.vocab, gi)).to(dev))
+    module.item_embeddings = torch.nn.Parameter(E, requires_grad=False)
+    model.check_inputs()
     torch.cuda.synchronize()
 
     item_blocks = [(r * I_step, (r + 1) * I_step) for r in range(world)]
     state = {"cursor": 0}
 
+    @torch.no_grad()
     def step(i):
-        # (1) merge (replicated: the whole arena locally; sliced: this rank's slice + all-gather)
-        merge_arena()
-        W.refresh()  # bf16x6 mode: re-split the freshly merged arena into its three bf16 piece arenas
-        # (2)+(3) ONE packed encoder pass over [catalog slice ; user sequences] (varlen: no padding is computed)
-        mb, ml = mixed_batches[i]
-        emb = runner.encode(W, mb, dev, normalize=True, lens=ml, validate=False)
-        e_new, u = emb[:I_step], emb[I_step:]
-        e_all = parallel.all_gather_rows(e_new.contiguous(), item_blocks) if world > 1 else e_new
+        # (1) the merge, as TaskVectorMergingModuleBase.forward does it on every call (_base.py:78-81): into the arena the model reads
+        merged_model.load_weights(force=True)
+        # (2) catalog rows: RecModule.forward(BatchItem) -> normalised embeddings; refresh those rows before scoring
+        e_new = module.forward(item_batches[i])
+        e_all = parallel.all_gather_rows(e_new, item_blocks) if world > 1 else e_new
         c = state["cursor"]
         n = e_all.shape[0]
         if c + n > M:
             c = 0
-        E[c : c + n] = e_all  # refresh those catalog rows before scoring
+        module.item_embeddings.data[c : c + n] = e_all
         state["cursor"] = c + n
-        # (4) full-catalog scoring + canonical top-50 + CE terms
-        return ops.score_topk(u.contiguous(), E, 50, label_batches[i], 1.0 / 0.05)
+        # (3) + (4) RecModule.test_step: encode users, full-catalog scoring, canonical top-50, CE terms
+        module.test_step(user_batches[i], i)
 
-    for i in range(args.warmup):
-        step(i)
+    def epoch(lo, hi):
+        module.on_test_epoch_start()
+        for i in range(lo, hi):
+            step(i)
+        if world > 1:  # per-user label ranks meet on every rank (a few bytes per user), as utils.Trainer.test gathers them
+            parallel.all_gather_vector(torch.cat(module._ranks))
+        return module.on_test_epoch_end()
+
+    epoch(0, args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    sampler = None
+    if rank == 0:
+        bus = getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)
+        bus_id = None
+        try:
+            p = torch.cuda.get_device_properties(dev)
+            bus_id = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        except Exception:  # noqa: BLE001
+            bus_id = None
+        sampler = DeviceSampler(bus_id)
+        sampler.start()
     ops.PROF.enabled = not args.no_profile
     ops.PROF.records.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    last = None
-    for i in range(args.warmup, n_total):
-        last = step(i)
+    metrics = epoch(args.warmup, n_total)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.PROF.enabled = False
+    if sampler is not None:
+        sampler.stop_flag.set()
+        sampler.join(timeout=1.0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -231,12 +285,13 @@ def main():
     kernels = {}
     roofline = None
     if not args.no_profile:
-        for name, r in ops.PROF.summary().items():
+        summ = ops.PROF.summary()
+        for name, r in summ.items():
             sec = r["ms"] / 1e3
             ent = dict(launches=r["launches"], avg_ms=r["ms"] / max(r["launches"], 1), share_of_step=r["ms"] / (elapsed * 1e3))
             if r["flops"] > 0:
-                if name.endswith(("bf16x6", "bf16x3")):  # 6 (3) bf16 MFMA flops are executed per algorithmic flop; peak = dense bf16 MFMA
-                    np_ = 6 if name.endswith("x6") else 3
+                if "bf16x" in name:  # 6 (3) bf16 MFMA flops are executed per algorithmic flop; peak = dense bf16 MFMA
+                    np_ = 6 if "bf16x6" in name else 3
                     ent.update(bound="mfma", achieved=r["flops"] / sec / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
                                mfma_flops_per_algorithmic_flop=np_, mfma_utilization=np_ * r["flops"] / sec / 1e12 / MFMA_BF16_PEAK_TF)
                 else:
@@ -246,60 +301,71 @@ def main():
             ent["frac"] = ent["achieved"] / ent["peak"]
             kernels[name] = ent
         dom = max(kernels.items(), key=lambda kv: kv[1]["share_of_step"])
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-        # (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950; tools/pmc_summary.py) -- PMC cannot be
-        # collected from inside the timed run.
-        traffic, traffic_src, traffic_raw = None, None, None
-        tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{gemm_mode}.json")
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command (separate FETCH_SIZE /
+        # WRITE_SIZE passes, FETCH_SIZE x2 on gfx950; tools/pmc_summary.py) -- PMC cannot be collected from inside the timed run.  The pass
+        # records the sha of the kernel sources it profiled: a different sha here means the figure is STALE and is reported as such.
+        traffic = traffic_raw = traffic_src = None
+        traffic_stale = None
+        tpath = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_traffic_{gemm_mode}.json")
+        src_sha = _sha16(sorted(glob.glob(os.path.join(ROOT, "mergerec_amd", "csrc", "*.hip"))))
         if world == 1 and os.path.exists(tpath):
-            t = json.load(open(tpath)).get("gemm_nt_bf16x" if dom[0].startswith("gemm_nt_bf16x") else dom[0])
+            tj = json.load(open(tpath))
+            t = tj.get(dom[0]) or tj.get(dom[0].split("/")[0])
             if t:
                 traffic = t["fetch_bytes_x2_per_launch"] + t["write_bytes_per_launch"]
-                traffic_raw = t["fetch_bytes_raw_per_launch"] + t["write_bytes_per_launch"]  # uncorrected FETCH_SIZE: exact if 64-B row fragments are tallied exactly
-                traffic_src = f"profiles/r01_pmc_traffic_{gemm_mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
-        roofline = dict(kernel=dom[0], **{k: dom[1][k] for k in ("mfma_flops_per_algorithmic_flop", "mfma_utilization") if k in dom[1]}, bound=dom[1]["bound"], achieved=dom[1]["achieved"], peak=dom[1]["peak"], unit=dom[1]["unit"],
-                        frac=dom[1]["frac"], traffic=traffic, traffic_uncorrected=traffic_raw, traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
-                        algorithmic_bytes_per_launch=ops.PROF.summary()[dom[0]]["bytes"] / max(dom[1]["launches"], 1),
+                traffic_raw = t["fetch_bytes_raw_per_launch"] + t["write_bytes_per_launch"]
+                traffic_src = f"profiles/{PROFILE_ROUND}_pmc_traffic_{gemm_mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+                traffic_stale = tj.get("_csrc_sha16") != src_sha
+        roofline = dict(kernel=dom[0], **{k: dom[1][k] for k in ("mfma_flops_per_algorithmic_flop", "mfma_utilization") if k in dom[1]},
+                        bound=dom[1]["bound"], achieved=dom[1]["achieved"], peak=dom[1]["peak"], unit=dom[1]["unit"], frac=dom[1]["frac"],
+                        traffic=traffic, traffic_uncorrected=traffic_raw, traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
+                        traffic_stale=traffic_stale, csrc_sha16=src_sha,
+                        algorithmic_bytes_per_launch=summ[dom[0]]["bytes"] / max(dom[1]["launches"], 1),
+                        algorithmic_flops_per_launch=summ[dom[0]]["flops"] / max(dom[1]["launches"], 1),
                         launches=dom[1]["launches"], avg_launch_ms=dom[1]["avg_ms"])
-        if "mfma_utilization" in roofline:
-            # the dense peak assumes 2.4 GHz; under this kernel the chip sustains ~1.1 GHz (in-kernel s_memtime / s_memrealtime of the same
-            # kernel, profiles/r01_inkernel_clock.txt: 1.04-1.16 GHz on two devices) -- the matrix pipe's busy fraction at THAT clock:
-            roofline["sustained_clock_ghz"] = SUSTAINED_CLOCK_GHZ.get(gemm_mode)
-            roofline["sustained_clock_source"] = "profiles/r01_inkernel_clock.txt (exp/gemm_phases.hip)"
-            if roofline["sustained_clock_ghz"]:
-                roofline["mfma_busy_at_sustained_clock"] = roofline["mfma_utilization"] * 2.4 / roofline["sustained_clock_ghz"]
+        if sampler is not None:  # measured in THIS process over the timed region (amdgpu hwmon); not a model
+            roofline.update(sampler.summary())
 
     # ---------------- CPU baseline (oracle port, rank 0, N == 1 only) ----------------
     cpu_baseline = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline, parity = run_cpu_baseline(args, spec, layout, base, tv, alpha, W, runner, dev, M, E)
+        cpu_baseline, parity = run_cpu_baseline(args, spec, merged_model, module, dev, M)
 
     if rank == 0:
+        arith = {"f32": "f32 (exact fp32 MFMA in every kernel)",
+                 "bf16x6": "f32 via bf16x6 split MFMA (encoder GEMMs and attention: 6 bf16 products per fp32 product, fp32 accumulation; merge, embedding, LayerNorm and scoring in f32)",
+                 "bf16x3": "f32 via bf16x3 split MFMA (encoder GEMMs and attention: 3 bf16 products per fp32 product, fp32 accumulation; merge, embedding, LayerNorm and scoring in f32)"}
         out = OrderedDict(
             metric="sequences/sec full-catalog scoring, 8-domain merged BLaIR-base; NDCG@10 parity",
             value=value, unit="sequences/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype="f32" if gemm_mode == "f32" else f"f32 via {gemm_mode} split MFMA (encoder GEMMs: {gemm_mode[-1]} bf16 products per fp32 product; merge, attention, scoring in f32)",
-            data="synthetic",
+            dtype=arith[gemm_mode], data="synthetic",
             config=dict(
                 workload=f"{n_dom}-domain merged BLaIR-base (alpha=1/{n_dom}), full-catalog scoring, Arts-sized catalog",
                 domains_merged=n_dom, catalog_items=M, users_per_step_per_gpu=U_step, items_per_step_per_gpu=I_step,
-                avg_user_tokens=avg_user_tokens, avg_item_tokens=avg_item_tokens, topk=50, params=layout.numel,
-                parallelism=(f"dp{world}: " + ("arena-slice merge + all-gather" if sliced else "task vectors replicated, whole-arena merge per rank (no collective)")
-                             + ", catalog rows sharded + all-gather, users data-parallel (token-balanced shards)"),
+                avg_user_tokens=avg_user_tokens, avg_item_tokens=avg_item_tokens, topk=50, params=merged_model.layout.numel,
+                path="product objects with defaults: load_merging_module -> RecModule.forward(BatchItem) / test_step(BatchSequence) / on_test_epoch_end; "
+                     "input checks in the packing kernel, no per-step host sync",
+                parallelism=(f"dp{world}: " + ("task vectors + base sliced 1/N per rank, arena-slice merge + all-gather" if sliced else
+                                               "task vectors replicated, whole-arena merge per rank (no collective)")
+                             + ", catalog rows sharded + all-gather, users data-parallel (token-balanced shards), label ranks gathered"),
             ),
             roofline=roofline, cpu_baseline=cpu_baseline, kernels=kernels, parity=parity,
+            epoch_metrics_sample={k: round(v, 6) for k, v in list(metrics.items())[:3]},
         )
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def run_cpu_baseline(args, spec, layout, base, tv, alpha, W, runner, dev, M, E):
-    """Times the oracle (oracle/ref_cpu.py, fp32 torch on the host cores) on a bounded sample of the same
-    step and scales it to the step's composition.  Also cross-checks the GPU embeddings of the sample."""
+def run_cpu_baseline(args, spec, merged_model, module, dev, M):
+    """Times the oracle (oracle/ref_cpu.py, fp32 torch on the host cores) on a bounded sample of the same step and scales it to the
+    step's composition.  Also the in-run parity record: the GPU path against the oracle on the very same sample -- merged parameters,
+    embeddings, logits, ranked indices and NDCG@10 (sample users scored against the sample items; the committed real-scale fixture
+    tests/golden/g12 is the full-size proof)."""
     from oracle import ref_cpu as O
+    from mergerec_amd.model_batch import BatchItem, BatchSequence
     from mergerec_amd.synthetic import blair_item_lengths, blair_sequence_lengths, _ids_from_lengths
 
     # threads actually used: this process's CPU share (the GPU box exposes 256 logical CPUs but grants a
@@ -310,8 +376,10 @@ def run_cpu_baseline(args, spec, layout, base, tv, alpha, W, runner, dev, M, E):
         avail = os.cpu_count() or 1
     cores = min(avail, 16)
     torch.set_num_threads(cores)
-    n_dom = tv.shape[0]
-    base_c, tv_c, a_c = base.cpu(), tv.cpu(), alpha.cpu().reshape(-1)
+    layout = merged_model.layout
+    n_dom = merged_model.task_vectors_tensor.shape[0]
+    base_c, tv_c = merged_model.base_model_tensor.data.cpu(), merged_model.task_vectors_tensor.data.cpu()
+    a_c = merged_model.effective_alpha().detach().cpu().reshape(-1)
     t0 = time.perf_counter()
     merged = O.merge_task_wise(base_c, tv_c, a_c)  # the reference's 3-op expression (task_wise.py:43-47)
     t_merge = time.perf_counter() - t0
@@ -329,7 +397,7 @@ def run_cpu_baseline(args, spec, layout, base, tv, alpha, W, runner, dev, M, E):
         t0 = time.perf_counter()
         e_c = O.maybe_normalize(O.roberta_encode(sd, ib["input_ids"], ib["attention_mask"], cfg, "model."))
         t_items = time.perf_counter() - t0
-        E_c = E.cpu()
+        E_c = module.item_embeddings.detach().cpu()
         nU = 32  # the reference's per-batch scoring shape (module.py:137 at --batch_size 32)
         Uc = O.maybe_normalize(torch.randn(nU, spec.hidden, generator=g))
         t0 = time.perf_counter()
@@ -338,15 +406,35 @@ def run_cpu_baseline(args, spec, layout, base, tv, alpha, W, runner, dev, M, E):
         t_score = time.perf_counter() - t0
     U_step, I_step = args.users_per_step, args.items_per_step
     t_step = t_merge + I_step * (t_items / args.cpu_items) + U_step * (t_users / args.cpu_seqs) + (U_step / nU) * t_score
-    # parity of the GPU path on the very same sample
-    u_g = runner.encode(W, {k: v.to(dev) for k, v in ub.items()}, dev, normalize=True).cpu()
-    e_g = runner.encode(W, {k: v.to(dev) for k, v in ib.items()}, dev, normalize=True).cpu()
-    merged_g = torch.cat([v.reshape(-1) for v in W.views.values()]).cpu()
+
+    # ---- parity of the GPU product path on the very same sample
+    with torch.no_grad():
+        e_g = module.forward(BatchItem(items=ib).to(dev))
+        ref_scores = O.score(u_c, e_c)
+        k = min(50, args.cpu_items)
+        ref_top = torch.topk(ref_scores, k, dim=1)
+        pos = (torch.exp(torch.rand(args.cpu_seqs, generator=g) * torch.log(torch.tensor(float(k)))).floor().long() - 1).clamp(0, k - 1)
+        labels = ref_top.indices[torch.arange(args.cpu_seqs), pos]  # labels the oracle ranks log-uniformly inside the list (NDCG@10 ~ 0.5)
+        probe = type(module)(model=module.model, evaluator=module.evaluator, similarity="cosine")
+        probe.eval()
+        probe.item_embeddings = torch.nn.Parameter(e_g, requires_grad=False)
+        probe.on_test_epoch_start()
+        probe.test_step(BatchSequence(sequence=ub, labels=labels).to(dev), 0)
+        got = probe.on_test_epoch_end()
+    u_g, idx_g = probe.eval_user_embeddings, probe.eval_topk_indices
+    _, ref_idx = O.topk_canonical(ref_scores, k)
+    want = O.evaluate(ref_scores, labels, ["NDCG", "RECALL"], [1, 5, 10, 50], "test/")
+    sa, sb = torch.gather(ref_scores, 1, idx_g), torch.gather(ref_scores, 1, ref_idx)
+    merged_g = torch.cat([v.reshape(-1) for v in module.model.state_dict().values()]).cpu()
     merged_cc = torch.cat([v.reshape(-1) for v in sd.values()])
     parity = dict(
         merged_params_bit_exact=bool(torch.equal(merged_g, merged_cc)),
-        user_embedding_max_abs_diff=float((u_g - u_c).abs().max()), item_embedding_max_abs_diff=float((e_g - e_c).abs().max()),
-        logit_max_abs_diff=float((u_g @ e_g.T - u_c @ e_c.T).abs().max()), tolerance=1e-4,
+        user_embedding_max_abs_diff=float((u_g - u_c).abs().max()), item_embedding_max_abs_diff=float((e_g.cpu() - e_c).abs().max()),
+        logit_max_abs_diff=float((u_g @ e_g.cpu().T - ref_scores).abs().max()), tolerance=1e-4,
+        ndcg10_abs_diff=abs(got["test/NDCG@10"] - want["test/NDCG@10"]), ndcg10_oracle=want["test/NDCG@10"], ndcg10_tolerance=1e-3,
+        topk_rows_mismatched=int((idx_g != ref_idx).any(1).sum()),
+        topk_rows_mismatched_beyond_near_ties=int((((idx_g != ref_idx) & ((sa - sb).abs() > 2e-6)).any(1)).sum()), near_tie=2e-6,
+        sample=f"{args.cpu_seqs} users x {args.cpu_items} items of this run, top-{k}; full-size proof: tests/test_realscale_gpu.py (tests/golden/g12)",
     )
     base_out = dict(
         value=U_step / t_step, unit="sequences/s", cores=cores, kind="port",

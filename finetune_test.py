@@ -32,11 +32,12 @@ def main(argv=None):
     if len(config.data_paths) != 1 or len(config.finetune_checkpoint_paths) != 1:
         raise SystemExit("finetune_test.py takes exactly one --data_path and one --finetune_checkpoint_path")
 
-    from mergerec_amd.data import load_domain
+    from mergerec_amd import parallel
     from mergerec_amd.evaluator import Evaluator
     from mergerec_amd.module import ModelType, RecModule
-    from mergerec_amd.utils import remove_duplicate_prefix, test_model, test_model_from_paths
+    from mergerec_amd.utils import remove_duplicate_prefix, test_model
 
+    rank, _ = parallel.init_from_env()
     torch.manual_seed(config.seed)
     model = ModelType[config.model_type].value(
         model_name_or_path=config.model_path, tokenizer_name_or_path=config.tokenizer_path, lora_config=None,
@@ -51,25 +52,24 @@ def main(argv=None):
         model.load_state_dict(remove_duplicate_prefix(sd))
 
     path = config.data_paths[0]
-    out = dict(metrics_path=config.metrics_path, predictions_path=config.predictions_path, item_embeddings_path=config.item_embeddings_path,
-               user_embeddings_path=config.user_embeddings_path)
+    tokenizer = model.tokenizer
     if (Path(path) / "train.json").exists():
         from mergerec_amd.datamodule import load_tokenizer
 
         if not config.tokenizer_path:
             raise SystemExit("--tokenizer_path <local tokenizer directory> is required for JSON dataset directories (the box is offline)")
-        _, metrics, _, _ = test_model_from_paths(
-            module, ModelType[config.model_type], [Path(path)], load_tokenizer(config.tokenizer_path), config.batch_size, config.max_seq_len,
-            config.max_attribute_len, config.max_items, config.num_workers, config.sequence_prompt, config.item_prompt,
-            str(config.reverse_sequence).lower() in ("1", "true", "yes"), config.precision, config.test_data_split, **out)
-        name = Path(path).name
-    else:
-        kind = "recformer" if config.model_type.startswith("RECFORMER") else "roberta"
-        d = load_domain(path, kind=kind, vocab=model.spec.vocab)
-        _, metrics, _, _ = test_model(module, [d.item_dataloader(config.batch_size)], [d.sequence_dataloader(config.batch_size)], [d.name],
-                                      precision=config.precision, **out)
-        name = d.name
-    print(name, {k: round(v, 5) for k, v in metrics[0].items()})
+        tokenizer = load_tokenizer(config.tokenizer_path)
+    # finetune_test.py:36-55
+    _, metrics, _, _ = test_model(
+        module=module, model_type=ModelType[config.model_type], data_paths=[path], model_tokenizer=tokenizer, batch_size=config.batch_size,
+        max_seq_len=config.max_seq_len, max_attribute_len=config.max_attribute_len, max_items=config.max_items, num_workers=config.num_workers,
+        sequence_prompt=config.sequence_prompt, item_prompt=config.item_prompt,
+        reverse_sequence=str(config.reverse_sequence).lower() in ("1", "true", "yes"), precision=config.precision,
+        data_split=config.test_data_split, metrics_path=config.metrics_path, predictions_path=config.predictions_path,
+        item_embeddings_path=config.item_embeddings_path, user_embeddings_path=config.user_embeddings_path)
+    name = str(path).split(":")[1] if str(path).startswith("synthetic:") else Path(path).name
+    if rank == 0:
+        print(name, {k: round(v, 5) for k, v in metrics[0].items()})
     return metrics
 
 

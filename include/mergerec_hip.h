@@ -136,6 +136,24 @@ int mr_pack_tokens(const int64_t* input_ids, const int64_t* attention_mask, cons
                    const int64_t* item_position_ids, int B, int L, int pad_id, const int32_t* cu_seqlens,
                    int32_t* tok_word, int32_t* tok_pos, int32_t* tok_tt, int32_t* tok_ip, mr_stream_t stream);
 
+/* mr_pack_tokens with the input checks of the host layer folded in (no device -> host sync per batch): violations are OR-ed into
+ * *err_bits (int32, device, caller-zeroed) as MR_IN_* bits and read back by the caller at its next synchronisation point.
+ * Checked: ids in [0, vocab); position 0 attended (CLS pooling reads it, encoder/_base.py:45); token_type_ids / item_position_ids
+ * of attended tokens inside their tables; global_attention_mask (may be NULL) == 1 at position 0 and 0 elsewhere (the only
+ * pattern the reference's collators emit, utils/recformer_utils.py:51,59); per-row mask count == cu_seqlens span.
+ * err_bits == NULL: no checks (== mr_pack_tokens).  The embedding gather clamps indices, so bad ids never fault.
+ * replaces: the index errors torch raises inside nn.Embedding for the same inputs (recformer/models.py:121-131). */
+#define MR_IN_BAD_ID 1
+#define MR_IN_NO_CLS 2
+#define MR_IN_BAD_TOKEN_TYPE 4
+#define MR_IN_BAD_ITEM_POS 8
+#define MR_IN_GLOBAL_PATTERN 16
+#define MR_IN_LEN_MISMATCH 32
+int mr_pack_tokens_checked(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
+                           const int64_t* item_position_ids, const int64_t* global_attention_mask, int B, int L, int pad_id,
+                           int vocab, int n_type, int n_ip, const int32_t* cu_seqlens, int32_t* tok_word, int32_t* tok_pos,
+                           int32_t* tok_tt, int32_t* tok_ip, int32_t* err_bits, mr_stream_t stream);
+
 /* out[t, :] = LayerNorm(sum of gathered rows) * gamma + beta, one wavefront per token.
  * mode MR_EMBED_ROBERTA:   (word[tok_word] + type[tok_tt or 0]) + pos[tok_pos]
  * mode MR_EMBED_RECFORMER: ((word[tok_word] + pos[tok_pos]) + type[tok_tt]) + itempos[tok_ip]

@@ -2,7 +2,8 @@
 """Drop-in for the reference's merge_test.py (merge_test.py:16-110) on MI355X: same flag names (TestMergeConfig,
 configs/base.py:22-108, configs/test.py:34-43), argparse instead of tyro.  Flags of subsystems outside the path
 (--lora.*) are accepted and ignored with a note; --data_paths may be dataset directories in the reference's JSON format
-(then --tokenizer_path must be a local tokenizer directory) or the pre-tokenised / synthetic specs of mergerec_amd/data.py; --precision 32-true keeps the model's arithmetic (default bf16x6, fp32-grade); bf16-mixed (the reference's default) selects bf16x3.
+(then --tokenizer_path must be a local tokenizer directory) or the pre-tokenised / synthetic specs of mergerec_amd/data.py;
+`python -m torch.distributed.run --nproc-per-node N merge_test.py ...` shards the run over N GPUs (same outputs); --precision 32-true keeps the model's arithmetic (default bf16x6, fp32-grade); bf16-mixed (the reference's default) selects bf16x3.
 
 Example (synthetic weights + data, 2-domain merge):
   python merge_test.py --model_type BLAIR_BASE --model_kwargs init_seed 7 \
@@ -90,12 +91,15 @@ def parse(argv=None):
 
 def main(argv=None):
     config = parse(argv)
-    from mergerec_amd.data import load_domain
+    from mergerec_amd import parallel
     from mergerec_amd.evaluator import Evaluator
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
     from mergerec_amd.module import ModelType, RecModule
     from mergerec_amd.utils import load_alpha_file, remove_duplicate_prefix, test_model
 
+    # one process per GPU under `python -m torch.distributed.run --nproc-per-node N merge_test.py ...`: the arena slices, the catalog rows
+    # and the user sequences are dealt over the ranks (RCCL all-gathers); a plain `python merge_test.py ...` is the single-GPU run
+    rank, world_size = parallel.init_from_env()
     torch.manual_seed(config.seed)
     model = ModelType[config.model_type].value(
         model_name_or_path=config.model_path, tokenizer_name_or_path=config.tokenizer_path, lora_config=None,
@@ -141,34 +145,30 @@ def main(argv=None):
     model.load_state_dict(state_dict)
     module = RecModule(model=model, evaluator=Evaluator(metrics=config.metric_names, ks=config.ks), negative_sample=None, similarity=config.similarity)
 
-    if all((Path(p) / "train.json").exists() for p in config.test_data_paths):
-        # dataset directories in the reference's JSON format: the datamodule route (needs a local tokenizer directory)
-        from mergerec_amd.datamodule import load_tokenizer
-        from mergerec_amd.utils import test_model_from_paths
-
-        if not config.tokenizer_path:
-            raise SystemExit("--tokenizer_path <local tokenizer directory> is required for JSON dataset directories (the box is offline)")
-        tokenizer = load_tokenizer(config.tokenizer_path)
-        _, metrics, scores, labels = test_model_from_paths(
-            module, ModelType[config.model_type], [Path(p) for p in config.test_data_paths], tokenizer, config.batch_size, config.max_seq_len,
-            config.max_attribute_len, config.max_items, config.num_workers, config.sequence_prompt, config.item_prompt,
-            str(config.reverse_sequence).lower() in ("1", "true", "yes"), config.precision, config.test_data_split,
-            metrics_path=config.metrics_path, predictions_path=config.predictions_path, item_embeddings_path=config.item_embeddings_path,
-            user_embeddings_path=config.user_embeddings_path,
-        )
-        for p, m in zip(config.test_data_paths, metrics):
-            print(Path(p).name, {k: round(v, 5) for k, v in m.items()})
-        return metrics
-
-    kind = "recformer" if config.model_type.startswith("RECFORMER") else "roberta"
-    domains = [load_domain(p, kind=kind, vocab=model.spec.vocab) for p in config.test_data_paths]
+    # merge_test.py:91-110, argument for argument
     _, metrics, scores, labels = test_model(
-        module, [d.item_dataloader(config.batch_size) for d in domains], [d.sequence_dataloader(config.batch_size) for d in domains],
-        [d.name for d in domains], precision=config.precision, metrics_path=config.metrics_path, predictions_path=config.predictions_path,
-        item_embeddings_path=config.item_embeddings_path, user_embeddings_path=config.user_embeddings_path,
+        module=module,
+        model_type=ModelType[config.model_type],
+        data_paths=config.test_data_paths,
+        model_tokenizer=model.tokenizer,
+        batch_size=config.batch_size,
+        max_seq_len=config.max_seq_len,
+        max_attribute_len=config.max_attribute_len,
+        max_items=config.max_items,
+        num_workers=config.num_workers,
+        sequence_prompt=config.sequence_prompt,
+        item_prompt=config.item_prompt,
+        reverse_sequence=str(config.reverse_sequence).lower() in ("1", "true", "yes"),
+        precision=config.precision,
+        data_split=config.test_data_split,
+        metrics_path=config.metrics_path,
+        predictions_path=config.predictions_path,
+        item_embeddings_path=config.item_embeddings_path,
+        user_embeddings_path=config.user_embeddings_path,
     )
-    for d, m in zip(domains, metrics):
-        print(d.name, {k: round(v, 5) for k, v in m.items()})
+    if rank == 0:
+        for p, m in zip(config.test_data_paths, metrics):
+            print(str(p).split(":")[1] if str(p).startswith("synthetic:") else Path(p).name, {k: round(v, 5) for k, v in m.items()})
     return metrics
 
 

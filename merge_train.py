@@ -92,7 +92,7 @@ def main(argv=None):
     from mergerec_amd.module import (DistillSequenceModule, ModelType, MultiDatasetItemEncodingCallback, RecModule, SaveWeightsCallback,
                                      distill_loss_factory, teacher_scores)
     from mergerec_amd.module.callbacks import ItemEncoderMixin, WeightCheckpointCallback
-    from mergerec_amd.utils import DistillTrainer, remove_duplicate_prefix, test_model_from_paths
+    from mergerec_amd.utils import DistillTrainer, remove_duplicate_prefix, test_model
 
     torch.manual_seed(config.seed)
     recformer = config.model_type.startswith("RECFORMER")
@@ -146,7 +146,8 @@ def main(argv=None):
     merged_model = load_merging_module(
         merge_type=MergeType[config.merge_type], learn_type=LearnType[config.learn_type], model=model, pretrain_state_dict=pretrain,
         finetune_state_dicts=[{k: v for k, v in sd.items() if k != "item_embeddings"} for sd in finetune_state_dicts], ignore_keys=set(),
-        ties_density=config.ties_density, disable_softmax=not config.use_softmax, initial_per_weight=opt["initial_per_weight"])
+        ties_density=config.ties_density, disable_softmax=not config.use_softmax, initial_per_weight=opt["initial_per_weight"],
+        placement="replicated")  # d loss / d alpha contracts the whole gradient with every task vector: data parallel, nothing sliced
     kwargs = {"coefficient": opt["coefficient"]} if opt["loss_type"].endswith("_KD") else {}
     module = DistillSequenceModule(
         merged_model=merged_model, score_embeddings=score_embeddings,
@@ -185,16 +186,18 @@ def main(argv=None):
     if rank == 0:
         print(f"alpha after {trainer.global_step} steps on {world} rank(s): {result['weights']['per_weights']}")
         print(f"weights written to {save_cb.save_file}")
-    if not opt["skip_test"] and rank == 0:  # _test_after_train (merge_train.py:28-67)
-        print("Running test after training...")
+    if not opt["skip_test"]:  # _test_after_train (merge_train.py:28-67); with several ranks the test itself runs sharded over them
+        if rank == 0:
+            print("Running test after training...")
         final = new_model()
         final.load_state_dict({k: v.detach() for k, v in merged_model.get_state_dict().items()})
         rec = RecModule(model=final, evaluator=Evaluator(metrics=config.metric_names, ks=config.ks), negative_sample=None, similarity=config.similarity)
-        metric_dict, metrics, _, _ = test_model_from_paths(
+        metric_dict, metrics, _, _ = test_model(
             rec, ModelType[config.model_type], [Path(p) for p in config.test_data_paths], tokenizer, config.batch_size, config.max_seq_len,
             config.max_attribute_len, config.max_items, config.num_workers, config.sequence_prompt, config.item_prompt, reverse, config.precision,
             config.test_data_split, metrics_path=config.metrics_path, predictions_path=config.predictions_path)
-        print(f"Test metrics after training: {metric_dict}")
+        if rank == 0:
+            print(f"Test metrics after training: {metric_dict}")
         result["test_metrics"] = metric_dict
     if world > 1:
         import torch.distributed as dist

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mr_gemm_nt_bf16x3_splitk_f32": (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_i, c_p, c_sz, c_p]),
     "mr_adamw_step_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i, c_d, c_d, c_d, c_d, c_d, c_i64, c_p, c_f, c_p]),
     "mr_pack_tokens": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "mr_pack_tokens_checked": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mr_embed_gather_ln_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p]),
     "mr_gemm_nt_bias_act_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p]),
     "mr_gemm_nt_bf16x6_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_i, c_p]),

@@ -8,6 +8,9 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWavesPerBlock = kThreads / MR_WAVE;
 
+// Optional input checks (err != nullptr): what the host used to verify with min / max reductions and a D2H sync per batch is
+// tallied here as bits of one device word, read back at the next natural sync point (epoch end).  The gathers below clamp
+// their indices, so a bad id can never fault; it is reported instead.
 __global__ __launch_bounds__(MR_WAVE) void pack_tokens_kernel(const int64_t* __restrict__ ids,
                                                              const int64_t* __restrict__ mask,
                                                              const int64_t* __restrict__ tt,
@@ -16,11 +19,14 @@ __global__ __launch_bounds__(MR_WAVE) void pack_tokens_kernel(const int64_t* __r
                                                              int32_t* __restrict__ tok_word,
                                                              int32_t* __restrict__ tok_pos,
                                                              int32_t* __restrict__ tok_tt,
-                                                             int32_t* __restrict__ tok_ip) {
+                                                             int32_t* __restrict__ tok_ip,
+                                                             const int64_t* __restrict__ gmask, int vocab, int n_type,
+                                                             int n_ip, int32_t* __restrict__ err) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int64_t row = (int64_t)b * L;
     const int t0 = cu[b], t1 = cu[b + 1];
     int run_pos = 0, run_tok = 0;
+    int bad = 0;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int l0 = 0; l0 < L; l0 += MR_WAVE) {
         const int l = l0 + lane;
@@ -29,18 +35,32 @@ __global__ __launch_bounds__(MR_WAVE) void pack_tokens_kernel(const int64_t* __r
         const bool m = valid && mask[row + l] != 0;
         const bool nonpad = valid && id != (int64_t)pad_id;
         const unsigned long long bnp = __ballot(nonpad), bm = __ballot(m);
+        if (err && valid) {
+            if (id < 0 || id >= (int64_t)vocab) bad |= MR_IN_BAD_ID;
+            if (l == 0 && !m) bad |= MR_IN_NO_CLS;
+            if (gmask && (gmask[row + l] != (l == 0 ? 1 : 0))) bad |= MR_IN_GLOBAL_PATTERN;
+        }
         if (m) {
             const int t = t0 + run_tok + __popcll(bm & lt);
+            const int64_t ttv = tt ? tt[row + l] : 0, ipv = ip ? ip[row + l] : 0;
+            if (err) {
+                if (tt && (ttv < 0 || ttv >= (int64_t)n_type)) bad |= MR_IN_BAD_TOKEN_TYPE;
+                if (ip && (ipv < 0 || ipv >= (int64_t)n_ip)) bad |= MR_IN_BAD_ITEM_POS;
+            }
             if (t < t1) {  // cu_seqlens is caller data: never write past this row's slot
                 const int incl = run_pos + __popcll(bnp & lt) + 1;
                 tok_word[t] = (int32_t)id;
                 tok_pos[t] = nonpad ? incl + pad_id : pad_id;
-                if (tok_tt) tok_tt[t] = tt ? (int32_t)tt[row + l] : 0;
-                if (tok_ip) tok_ip[t] = ip ? (int32_t)ip[row + l] : 0;
+                if (tok_tt) tok_tt[t] = (int32_t)ttv;
+                if (tok_ip) tok_ip[t] = (int32_t)ipv;
             }
         }
         run_pos += __popcll(bnp);
         run_tok += __popcll(bm);
+    }
+    if (err) {
+        if (lane == 0 && run_tok != t1 - t0) bad |= MR_IN_LEN_MISMATCH;  // cu_seqlens disagrees with the mask
+        if (bad) atomicOr(err, bad);
     }
 }
 
@@ -241,15 +261,26 @@ __global__ __launch_bounds__(kThreads) void gather_rows_scalar_kernel(const floa
 
 }  // namespace
 
+extern "C" int mr_pack_tokens_checked(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
+                                      const int64_t* item_position_ids, const int64_t* global_attention_mask, int B, int L,
+                                      int pad_id, int vocab, int n_type, int n_ip, const int32_t* cu_seqlens, int32_t* tok_word,
+                                      int32_t* tok_pos, int32_t* tok_tt, int32_t* tok_ip, int32_t* err_bits,
+                                      mr_stream_t stream) {
+    if (!input_ids || !attention_mask || !cu_seqlens || !tok_word || !tok_pos || B < 0 || L < 0) return MR_EINVAL;
+    if (err_bits && (vocab < 1 || (token_type_ids && n_type < 1) || (item_position_ids && n_ip < 1))) return MR_EINVAL;
+    if (B == 0 || L == 0) return MR_OK;
+    hipLaunchKernelGGL(pack_tokens_kernel, dim3(B), dim3(MR_WAVE), 0, (hipStream_t)stream, input_ids, attention_mask,
+                       token_type_ids, item_position_ids, L, pad_id, cu_seqlens, tok_word, tok_pos, tok_tt, tok_ip,
+                       global_attention_mask, vocab, n_type, n_ip, err_bits);
+    return mr::check_launch();
+}
+
 extern "C" int mr_pack_tokens(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
                               const int64_t* item_position_ids, int B, int L, int pad_id, const int32_t* cu_seqlens,
                               int32_t* tok_word, int32_t* tok_pos, int32_t* tok_tt, int32_t* tok_ip,
                               mr_stream_t stream) {
-    if (!input_ids || !attention_mask || !cu_seqlens || !tok_word || !tok_pos || B < 0 || L < 0) return MR_EINVAL;
-    if (B == 0 || L == 0) return MR_OK;
-    hipLaunchKernelGGL(pack_tokens_kernel, dim3(B), dim3(MR_WAVE), 0, (hipStream_t)stream, input_ids, attention_mask,
-                       token_type_ids, item_position_ids, L, pad_id, cu_seqlens, tok_word, tok_pos, tok_tt, tok_ip);
-    return mr::check_launch();
+    return mr_pack_tokens_checked(input_ids, attention_mask, token_type_ids, item_position_ids, nullptr, B, L, pad_id, 0, 0, 0,
+                                  cu_seqlens, tok_word, tok_pos, tok_tt, tok_ip, nullptr, stream);
 }
 
 extern "C" int mr_embed_gather_ln_f32(const int32_t* tok_word, const int32_t* tok_pos, const int32_t* tok_tt,

@@ -23,24 +23,29 @@ from . import synthetic
 
 class TokenizedBatches:
     """DataLoader stand-in: yields BatchItem / BatchSequence, each batch trimmed to its own max length
-    (the reference tokenises with padding=True per batch, collator/recommender/recommender.py:30,93)."""
+    (the reference tokenises with padding=True per batch, collator/recommender/recommender.py:30,93).
+    ``rows``: an explicit ascending row-id list instead of the [lo, hi) range (one rank's share, ``parallel.ShardedLoader``)."""
 
     def __init__(self, enc: Dict[str, torch.Tensor], batch_size: int, labels: Optional[torch.Tensor] = None,
-                 lo: int = 0, hi: Optional[int] = None):
+                 lo: int = 0, hi: Optional[int] = None, rows: Optional[torch.Tensor] = None):
         self.enc, self.bs, self.labels = enc, batch_size, labels
         n = enc["input_ids"].shape[0]
         self.lo, self.hi = lo, n if hi is None else hi
+        self.rows = rows
 
     def __len__(self):
-        return (self.hi - self.lo + self.bs - 1) // self.bs
+        n = self.hi - self.lo if self.rows is None else self.rows.numel()
+        return (n + self.bs - 1) // self.bs
 
     def __iter__(self) -> Iterator:
-        for s in range(self.lo, self.hi, self.bs):
-            e = min(s + self.bs, self.hi)
-            mask = self.enc["attention_mask"][s:e]
+        n = self.hi - self.lo if self.rows is None else self.rows.numel()
+        for s in range(0, n, self.bs):
+            e = min(s + self.bs, n)
+            sel = slice(self.lo + s, self.lo + e) if self.rows is None else self.rows[s:e]
+            mask = self.enc["attention_mask"][sel]
             L = int(mask.sum(1).max()) if e > s else 0
-            enc = {k: v[s:e, :L].contiguous() for k, v in self.enc.items()}
-            yield BatchItem(items=enc) if self.labels is None else BatchSequence(sequence=enc, labels=self.labels[s:e])
+            enc = {k: v[sel][:, :L].contiguous() for k, v in self.enc.items()}
+            yield BatchItem(items=enc) if self.labels is None else BatchSequence(sequence=enc, labels=self.labels[sel])
 
 
 class TokenizedDomain:

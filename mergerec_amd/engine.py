@@ -251,6 +251,10 @@ def _lens_from_mask(attention_mask: torch.Tensor) -> torch.Tensor:
     return attention_mask.ne(0).sum(dim=1).to("cpu", torch.int64)
 
 
+class InputError(ValueError):
+    """A batch violated the encoder's input contract (found by the packing kernel, reported at the next ``check_inputs``)."""
+
+
 class EncoderRunner:
     """Runs the BLaIR (RoBERTa) or Recformer (Longformer) forward on packed tokens with HIP kernels.
 
@@ -262,24 +266,42 @@ class EncoderRunner:
         self.spec = spec
         self.prefix = prefix
         self.fuse_qkv = spec.hidden % 128 == 0
+        self._err_bits: Dict[torch.device, torch.Tensor] = {}  # one int32 word per device, OR-ed into by the packing kernel
 
     # ---- batch preparation -----------------------------------------------------------------------
-    def pack(self, batch: Dict[str, torch.Tensor], device, lens: Optional[torch.Tensor] = None, validate: bool = True) -> PackedBatch:
+    def _err_word(self, device) -> torch.Tensor:
+        device = torch.device(device)
+        w = self._err_bits.get(device)
+        if w is None:
+            w = self._err_bits[device] = torch.zeros(1, dtype=torch.int32, device=device)
+        return w
+
+    def check_inputs(self) -> None:
+        """Raise InputError if any batch packed since the last call broke the input contract.  ONE device -> host read; the callers
+        place it where they synchronise anyway (end of a catalog encode, end of an evaluation epoch)."""
+        for w in self._err_bits.values():
+            bits = int(w.item())
+            if bits:
+                w.zero_()
+                raise InputError("; ".join(msg for bit, msg in ops.INPUT_ERRORS.items() if bits & bit))
+
+    def pack(self, batch: Dict[str, torch.Tensor], device, lens: Optional[torch.Tensor] = None, validate=True) -> PackedBatch:
+        """validate: True = range / pattern checks run inside the packing kernel and surface at the next ``check_inputs()`` (no host
+        sync here); "now" = the same, checked immediately (one sync); False = unchecked."""
         ids, mask = batch["input_ids"], batch["attention_mask"]
         if ids.dim() != 2 or ids.shape != mask.shape:
             raise ValueError("input_ids / attention_mask must be (B, L) and equal-shaped")
         B, L = ids.shape
         if lens is None:
+            lens = getattr(batch, "host_lens", None)  # stashed by ToDeviceMixin.to() while the mask was still on the host
+        if lens is None:
             lens = _lens_from_mask(mask)
         lens = lens.to(torch.int64).cpu()
+        if lens.numel() != B:
+            raise ValueError("lens must hold one length per row")
         if validate and B > 0:
             if int(lens.min()) < 1:
                 raise ValueError("every sequence needs at least one attended token (CLS)")
-            if bool((mask[:, 0] == 0).any()):
-                raise ValueError("position 0 (CLS) must be attended: CLS pooling reads it (encoder/_base.py:45)")
-            lo, hi = int(ids.min()), int(ids.max())
-            if lo < 0 or hi >= self.spec.vocab:
-                raise ValueError(f"input_ids out of range [0, {self.spec.vocab}): [{lo}, {hi}]")
             if L + self.spec.pad_id + 1 > self.spec.max_pos:
                 raise ValueError(f"sequence length {L} exceeds the position table ({self.spec.max_pos})")
         cu = torch.zeros(B + 1, dtype=torch.int32)
@@ -287,22 +309,18 @@ class EncoderRunner:
             cu[1:] = lens.cumsum(0).to(torch.int32)
         T = int(cu[-1])
         cu_d = cu.to(device, non_blocking=True)
-        tt = ip = None
+        tt = ip = gm = None
         if self.spec.kind == "recformer":
             for key in ("token_type_ids", "item_position_ids", "global_attention_mask"):
                 if key not in batch:
                     raise ValueError(f"Missing required key in batch: {key}")  # interface.py:71-74
-            tt, ip = batch["token_type_ids"], batch["item_position_ids"]
-            if validate and B > 0:
-                g = batch["global_attention_mask"]
-                if bool((g[:, 0] != 1).any()) or bool((g[:, 1:] != 0).any()):
-                    raise NotImplementedError("only the Recformer pattern (global attention on token 0 only) is built")
-                if int(tt.min()) < 0 or int(tt.max()) >= self.spec.token_type_size:
-                    raise ValueError("token_type_ids out of range")
-                if int(ip.min()) < 0 or int(ip.max()) >= self.spec.max_item_embeddings:
-                    raise ValueError("item_position_ids out of range")
+            tt, ip, gm = batch["token_type_ids"], batch["item_position_ids"], batch["global_attention_mask"]
         dev = lambda t: None if t is None else t.to(device, torch.int64, non_blocking=True).contiguous()
-        tw, tp, ttp, tip = ops.pack_tokens(dev(ids), dev(mask), cu_d, T, self.spec.pad_id, dev(tt), dev(ip))
+        err = self._err_word(device) if validate else None
+        tw, tp, ttp, tip = ops.pack_tokens(dev(ids), dev(mask), cu_d, T, self.spec.pad_id, dev(tt), dev(ip), dev(gm) if validate else None, err,
+                                           self.spec.vocab, self.spec.token_type_size, self.spec.max_item_embeddings)
+        if validate == "now":
+            self.check_inputs()
         return PackedBatch(B=B, T=T, max_len=int(lens.max()) if B else 0, cu_seqlens=cu_d, cls_rows=cu_d[:-1].contiguous(),
                            tok_word=tw, tok_pos=tp, tok_tt=ttp, tok_ip=tip, sum_len_sq=float((lens.double() ** 2).sum()) if B else 0.0,
                            seq_order=torch.argsort(lens, descending=True, stable=True).to(torch.int32).to(device, non_blocking=True) if B > 1 else None)

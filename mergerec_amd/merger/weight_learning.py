@@ -16,7 +16,9 @@ from typing import Dict, List, Optional
 import torch
 from torch import nn
 
-from .. import ops
+import os
+
+from .. import ops, parallel
 from ..engine import ArenaLayout
 from .enums import LearnType, MergeType
 
@@ -57,7 +59,8 @@ class TaskVectorMergingModuleBase(nn.Module):
     ((P_pad,) / (N, P_pad): each tensor 64-float aligned, pads zero); ``compact_*`` give the reference's
     contiguous (P,) / (N, P) forms."""
 
-    def __init__(self, base_model_tensor, task_vectors_tensor, model_without_params, layout: ArenaLayout, disable_softmax: bool = False):
+    def __init__(self, base_model_tensor, task_vectors_tensor, model_without_params, layout: ArenaLayout, disable_softmax: bool = False,
+                 slice_plan: Optional["parallel.SlicePlan"] = None):
         super().__init__()
         self.model = model_without_params
         self.layout = layout
@@ -68,8 +71,15 @@ class TaskVectorMergingModuleBase(nn.Module):
         self.global_weights = nn.ParameterDict()
         self.global_biases = nn.ParameterDict()
         self.per_weights = nn.ParameterDict()
+        # "sliced" placement (several ranks): this rank holds elements [lo, hi) of the base vector and of every task vector, merges
+        # that slice, and ONE all-gather assembles the arena on every rank (parallel.sharded_merge)
+        self.slice_plan = slice_plan
+        self._slice = slice_plan.bounds(parallel.world()[0]) if slice_plan is not None else None
         # the parameter arena the (param-less) model reads: merged weights are written here in place (a6)
-        self._merged = torch.zeros_like(base_model_tensor)
+        arena_len = layout.padded_numel if slice_plan is None else slice_plan.padded
+        self._arena = torch.zeros(arena_len, dtype=torch.float32, device=base_model_tensor.device)
+        self._merged = self._arena[: layout.padded_numel]
+        self._scratch = None
         self._seg_off: Optional[torch.Tensor] = None  # device int64 (S+1) or None for one segment
         self._seg_gid: List[int] = [0]
         self._groups: List[str] = ["all"]
@@ -121,6 +131,9 @@ class TaskVectorMergingModuleBase(nn.Module):
     def forward_with_grad(self, batch):
         from ..engine_train import RobertaTrainGraph, SplitWeights, encode_with_grad
 
+        if self.slice_plan is not None:
+            raise RuntimeError("alpha learning needs every task vector on every rank (d loss / d alpha contracts the full gradient with "
+                               "each of them): build the module with placement='replicated' (merge_train.py does)")
         merged = self.merged_params()
         sw = None
         mode = self.train_mode if self.model.spec.hidden % 128 == 0 else "f32"
@@ -148,9 +161,23 @@ class TaskVectorMergingModuleBase(nn.Module):
 
     @torch.no_grad()
     def _merge_task_vectors(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        out = self._merged if out is None else out
-        return ops.merge_nway(self.base_model_tensor.data, self.task_vectors_tensor.data, self.effective_alpha().detach(),
-                              self._seg_off, out=out)
+        """Writes the merged parameters into ``out`` (default: the model's arena) and returns the (P_pad,) vector."""
+        alpha = self.effective_alpha().detach()
+        if self.slice_plan is None:
+            out = self._merged if out is None else out
+            return ops.merge_nway(self.base_model_tensor.data, self.task_vectors_tensor.data, alpha, self._seg_off, out=out)
+        arena = self._arena if out is None else out
+        if arena.numel() != self.slice_plan.padded:
+            raise ValueError("sliced merge writes a whole arena of SlicePlan.padded elements")
+        if self._scratch is None:
+            self._scratch = torch.empty(self.slice_plan.slice_len, dtype=torch.float32, device=arena.device)
+
+        def merge_slice(p_begin, p_count, out_slice):
+            ops.merge_nway(self.base_model_tensor.data, self.task_vectors_tensor.data, alpha, self._seg_off, out=out_slice,
+                           p_begin=p_begin, p_count=p_count, out_is_slice=True, operands_are_slices=True)
+
+        parallel.sharded_merge(merge_slice, arena, self.slice_plan, self._scratch)
+        return arena[: self.layout.padded_numel]
 
     def merged_params(self) -> torch.Tensor:
         """Differentiable merge: returns the merged arena vector with an autograd edge back to
@@ -158,36 +185,46 @@ class TaskVectorMergingModuleBase(nn.Module):
         return _MergeFunction.apply(self.effective_alpha(), self.base_model_tensor.data, self.task_vectors_tensor.data,
                                     self._seg_off, torch.empty_like(self._merged))
 
-    def load_weights(self):
-        """Re-merge into the model's arena -- skipped when alpha is bit-identical to the one the arena was merged with (the
-        reference re-merges on every forward; a catalog encode is hundreds of forwards with the same alpha)."""
+    def load_weights(self, force: bool = False):
+        """Re-merge into the model's arena (``force``: unconditionally, as the reference does on every forward) -- skipped when alpha is bit-identical to the one the arena was merged with AND nothing
+        else has written the arena since (the model counts in-place writes: load_state_dict, optimizer steps).  The reference
+        re-merges on every forward; a catalog encode is hundreds of forwards with the same alpha."""
         alpha = self.effective_alpha().detach()
         cached = getattr(self, "_merged_alpha", None)
-        if cached is not None and cached.shape == alpha.shape and torch.equal(cached, alpha):
+        version = getattr(self.model, "_arena_version", 0)
+        if not force and cached is not None and cached.shape == alpha.shape and getattr(self, "_merged_version", None) == version \
+                and torch.equal(cached, alpha):
             return self.model
         self._merge_task_vectors()
         self._merged_alpha = alpha.clone()
         if hasattr(self.model, "weights_updated"):
             self.model.weights_updated()
+        self._merged_version = getattr(self.model, "_arena_version", 0)
         return self.model
 
     def get_state_dict(self) -> StateDict:
         """Named views of a freshly merged flat vector (utils.py:29-40); independent of later merges."""
-        merged = self._merge_task_vectors(out=torch.empty_like(self._merged))
+        merged = self._merge_task_vectors(out=torch.empty_like(self._arena))
         return self.layout.views(merged)
 
     # -- helpers ---------------------------------------------------------------------------------
     def compact_base(self) -> torch.Tensor:
+        self._need_whole("compact_base")
         return self.layout.compact(self.base_model_tensor.data)
 
     def compact_task_vectors(self) -> torch.Tensor:
+        self._need_whole("compact_task_vectors")
         return torch.stack([self.layout.compact(t) for t in self.task_vectors_tensor.data])
+
+    def _need_whole(self, what: str):
+        if self.slice_plan is not None:
+            raise RuntimeError(f"{what}() needs the whole vectors; this module holds arena slice {self._slice} (placement='sliced')")
 
 
 class TaskVectorMergingModuleTaskWise(TaskVectorMergingModuleBase):
     def __init__(self, base_model_tensor, task_vectors_tensor, model_without_params, layout, initial_global_weight=1.0,
-                 initial_global_bias=0.0, initial_per_weight=0.2, disable_softmax=True):
-        super().__init__(base_model_tensor, task_vectors_tensor, model_without_params, layout, disable_softmax)
+                 initial_global_bias=0.0, initial_per_weight=0.2, disable_softmax=True, slice_plan=None):
+        super().__init__(base_model_tensor, task_vectors_tensor, model_without_params, layout, disable_softmax, slice_plan)
         dev = base_model_tensor.device
         n = task_vectors_tensor.size(0)
         self.global_weights["all"] = nn.Parameter(torch.full((1,), float(initial_global_weight), device=dev))
@@ -197,11 +234,13 @@ class TaskVectorMergingModuleTaskWise(TaskVectorMergingModuleBase):
 
 class TaskVectorMergingModuleLayerWise(TaskVectorMergingModuleBase):
     def __init__(self, base_model_tensor, task_vectors_tensor, model_without_params, layout, initial_global_weight=1.0,
-                 initial_global_bias=0.0, initial_per_weight=0.2, disable_softmax=False):
-        super().__init__(base_model_tensor, task_vectors_tensor, model_without_params, layout, disable_softmax)
+                 initial_global_bias=0.0, initial_per_weight=0.2, disable_softmax=False, slice_plan=None):
+        super().__init__(base_model_tensor, task_vectors_tensor, model_without_params, layout, disable_softmax, slice_plan)
         dev = base_model_tensor.device
         n = task_vectors_tensor.size(0)
         groups, seg_off, seg_gid = layout.group_segments()
+        if slice_plan is not None:
+            seg_off[-1] = slice_plan.padded  # the last rank's slice runs past the arena into zero padding
         self._groups, self._seg_gid = groups, seg_gid
         self._seg_off = seg_off.to(dev) if len(seg_gid) > 1 else None
         self.layer_groups = groups
@@ -224,10 +263,16 @@ def load_merging_module(
     initial_per_weight: float = 0.2,
     disable_softmax: bool = False,
     device: Optional[torch.device] = None,
+    placement: Optional[str] = None,
 ) -> TaskVectorMergingModuleBase:
     """_factory.py:27-127.  Key order = the pretrained dict's insertion order restricted to keys also in
     ``finetune_state_dicts[0]``.  Like the reference (make_functional, :70) this takes the passed model
-    over: afterwards the model computes with the merged arena owned by the returned module."""
+    over: afterwards the model computes with the merged arena owned by the returned module.
+
+    ``placement`` (new; the reference is single-GPU): with ``torch.distributed`` initialised on several ranks, "sliced" (the default
+    there; MERGEREC_MERGE_PLACEMENT overrides) keeps only this rank's 1/world slice of the base vector and of every task vector on
+    the device -- ``get_state_dict()`` / ``load_weights()`` merge that slice and all-gather the arena; "replicated" keeps everything
+    on every rank (what alpha learning needs).  One rank: always "replicated"."""
     assert isinstance(merge_type, MergeType), f"Invalid merge type: {merge_type}"
     assert isinstance(learn_type, LearnType), f"Invalid learn type: {learn_type}"
     _check_isinstance_state_dict(pretrain_state_dict)
@@ -246,15 +291,35 @@ def load_merging_module(
         device = getattr(model, "device", None) or torch.device("cuda", torch.cuda.current_device())
     layout = ArenaLayout(OrderedDict((k, tuple(v.shape)) for k, v in pre.items()))
 
+    rank, world_size = parallel.world()
+    placement = placement or os.environ.get("MERGEREC_MERGE_PLACEMENT") or ("sliced" if world_size > 1 else "replicated")
+    if placement not in ("sliced", "replicated"):
+        raise ValueError(f"placement must be 'sliced' or 'replicated', got {placement!r}")
+    plan = parallel.SlicePlan(layout.padded_numel, world_size) if (placement == "sliced" and world_size > 1) else None
+
     print("Converting model to functional form...")
     print("Calculating task vectors...")
     base = layout.pack(pre, device)
     n = len(finetune_state_dicts)
-    tv = torch.empty(n, layout.padded_numel, dtype=torch.float32, device=device)
     stage = torch.empty(layout.padded_numel, dtype=torch.float32, device=device)
-    for i, ckpt in enumerate(finetune_state_dicts):
-        layout.pack(ckpt, device, out=stage)
-        ops.task_vector(stage, base, out=tv[i])  # algorithms/task_vector.py:8-10
+    direct_slices = plan is not None and merge_type is MergeType.TASK_VECTOR
+    if direct_slices:
+        # plain task vectors are elementwise: only this rank's slice [lo, hi) of each one is ever formed
+        lo, hi = plan.bounds(rank)
+        hi_c = min(hi, layout.padded_numel)
+        base_s = torch.zeros(plan.slice_len, dtype=torch.float32, device=device)
+        base_s[: hi_c - lo] = base[lo:hi_c]
+        tv = torch.zeros(n, plan.slice_len, dtype=torch.float32, device=device)
+        for i, ckpt in enumerate(finetune_state_dicts):
+            layout.pack(ckpt, device, out=stage)
+            if hi_c > lo:
+                ops.task_vector(stage[lo:hi_c], base[lo:hi_c], out=tv[i, : hi_c - lo])
+        base = base_s
+    else:
+        tv = torch.empty(n, layout.padded_numel, dtype=torch.float32, device=device)
+        for i, ckpt in enumerate(finetune_state_dicts):
+            layout.pack(ckpt, device, out=stage)
+            ops.task_vector(stage, base, out=tv[i])  # algorithms/task_vector.py:8-10
     del stage
     if merge_type is MergeType.TASK_VECTOR:
         pass
@@ -298,6 +363,16 @@ def load_merging_module(
     else:
         raise ValueError(f"Invalid merge type: {merge_type}")
 
+    if plan is not None and not direct_slices:
+        # TIES / L&S / PCB select over whole vectors (global order statistics): computed on every rank at init, then cut to the slice
+        lo, hi = plan.bounds(rank)
+        hi_c = min(hi, layout.padded_numel)
+        base_s = torch.zeros(plan.slice_len, dtype=torch.float32, device=device)
+        tv_s = torch.zeros(n, plan.slice_len, dtype=torch.float32, device=device)
+        base_s[: hi_c - lo] = base[lo:hi_c]
+        tv_s[:, : hi_c - lo] = tv[:, lo:hi_c]
+        base, tv = base_s, tv_s
+
     print("Creating merging module...")
     if learn_type is LearnType.TASK_WISE:
         cls = TaskVectorMergingModuleTaskWise
@@ -306,4 +381,4 @@ def load_merging_module(
     else:
         raise ValueError(f"Invalid learn type: {learn_type}")
     return cls(base, tv, model, layout, initial_global_weight=initial_global_weight, initial_global_bias=initial_global_bias,
-               initial_per_weight=initial_per_weight, disable_softmax=disable_softmax)
+               initial_per_weight=initial_per_weight, disable_softmax=disable_softmax, slice_plan=plan)

@@ -1,4 +1,5 @@
-"""Mirror of rec_retrieval/types/model_batch.py:19-66 (the input dataclasses of the hot path and of the distillation step)."""
+"""The input dataclasses of the hot path and of the distillation step (boundary: rec_retrieval/types/model_batch.py:19-66 -- same
+class names, field names and ``.to(device)``)."""
 from __future__ import annotations
 
 from dataclasses import dataclass, fields, replace
@@ -7,20 +8,33 @@ from typing import Any, Mapping
 import torch
 
 
+class Encoding(dict):
+    """A tokenizer output after ``.to(device)``: a plain dict of tensors plus ``host_lens`` -- the per-row attended-token counts,
+    taken while ``attention_mask`` was still in host memory.  The packing kernel needs them on the host (they size every launch);
+    carrying them along saves the device -> host round trip per batch that re-deriving them from the moved mask would cost."""
+
+    host_lens = None
+
+
+def _relocate(value, device):
+    if isinstance(value, torch.Tensor):
+        return value.to(device)
+    if isinstance(value, Mapping):  # dict / transformers.BatchEncoding
+        moved = Encoding((k, _relocate(v, device)) for k, v in value.items())
+        lens = getattr(value, "host_lens", None)
+        mask = value.get("attention_mask") if lens is None else None
+        if isinstance(mask, torch.Tensor) and not mask.is_cuda and mask.dim() == 2:
+            lens = mask.ne(0).sum(dim=1)
+        moved.host_lens = lens
+        return moved
+    if isinstance(value, (list, tuple)):
+        return type(value)(_relocate(v, device) for v in value)
+    return value.to(device) if hasattr(value, "to") else value
+
+
 class ToDeviceMixin:
     def to(self, device):
-        def _move(obj):
-            if isinstance(obj, torch.Tensor):
-                return obj.to(device)
-            if hasattr(obj, "to") and not isinstance(obj, (dict, list, tuple)):
-                return obj.to(device)  # transformers.BatchEncoding
-            if isinstance(obj, Mapping):
-                return {k: _move(v) for k, v in obj.items()}
-            if isinstance(obj, (list, tuple)):
-                return type(obj)(_move(v) for v in obj)
-            return obj
-
-        return replace(self, **{f.name: _move(getattr(self, f.name)) for f in fields(self)})
+        return replace(self, **{f.name: _relocate(getattr(self, f.name), device) for f in fields(self)})
 
 
 @dataclass

@@ -48,7 +48,12 @@ class BaseEncoderModel(nn.Module):
         self.model_name_or_path = model_name_or_path
         self.pooling_method = pooling_method
         spec = self.SPEC()
-        for k, v in dict(model_kwargs.pop("spec_overrides", {})).items():
+        overrides = dict(model_kwargs.pop("spec_overrides", {}))
+        for k in [k for k in model_kwargs if k.startswith("spec.")]:  # CLI form: --model_kwargs spec.layers 2 spec.hidden 128 ...
+            overrides[k[len("spec."):]] = model_kwargs.pop(k)
+        for k, v in overrides.items():
+            if not hasattr(spec, k):
+                raise ValueError(f"unknown architecture field {k!r}")
             setattr(spec, k, v)
         self.spec = spec
         self.device = _resolve_device(model_kwargs)
@@ -164,9 +169,15 @@ class BaseEncoderModel(nn.Module):
         graph = EncoderTrainGraph(self.spec, layout, prefix=self.runner.prefix, mode=self.train_mode, split_weights=sw)
         return encode_with_grad(graph, self.train_leaf(), self.runner.pack(batch, self.device))
 
-    def encode_normalized(self, batch, normalize: bool, lens=None, validate: bool = True) -> torch.Tensor:
+    def encode_normalized(self, batch, normalize: bool, lens=None, validate=True) -> torch.Tensor:
         """forward + F.normalize fused into the pooling kernel (module/recommender/module.py:74-77)."""
         return self.runner.encode(self._weights, batch, self.device, normalize=normalize, lens=lens, validate=validate)
+
+    def check_inputs(self) -> None:
+        """Raise ``engine.InputError`` if a batch since the last call had ids / token types / item positions out of range, an
+        unattended CLS position or an unsupported global-attention pattern.  The checks run inside the packing kernel (no host sync
+        per batch); this is the one device read that surfaces them -- the evaluation loops call it at their epoch ends."""
+        self.runner.check_inputs()
 
 
 def random_init_state_dict(spec: EncoderSpec, seed: int, std: float = 0.02) -> "OrderedDict[str, torch.Tensor]":

@@ -73,6 +73,7 @@ class RecModule(_Base):
         self._lse: List[torch.Tensor] = []
         self._lab: List[torch.Tensor] = []
         self.eval_topk_indices = []
+        self._shard = None  # parallel.ShardedLoader of the running evaluation epoch (several ranks), set by utils.Trainer.test
 
     # -- forward (module.py:74-77, 133-166) --------------------------------------------------------
     def _encode(self, batch) -> torch.Tensor:
@@ -167,6 +168,7 @@ class RecModule(_Base):
     def _eval_start(self):
         self.eval_scores, self.eval_labels, self.eval_user_embeddings = [], [], []
         self._ranks, self._lse, self._lab, self.eval_topk_indices = [], [], [], []
+        self._shard = None
 
     def _eval_step(self, batch: BatchSequence):
         user = self._encode(batch.sequence)
@@ -184,14 +186,35 @@ class RecModule(_Base):
             self.eval_scores.append(scores.cpu())
 
     def _eval_end(self, prefix: str, loss_key: str):
+        """Epoch end of the test / validation loop.  With several ranks (``self._shard`` set by the Trainer: each rank stepped through
+        its own share of the users) the per-user results are put back into the dataloader's row order on every rank first -- two
+        all-gathers: one float block (lse, label logit, user embedding), one int block (label rank, label, top-k ids) -- so the
+        metrics, the loss and every ``eval_*`` attribute are those of the single-process run, bit for bit."""
         cat = lambda xs, empty: torch.cat(xs, dim=0) if xs else empty
         dev = self.device
-        self.eval_labels = cat(self.eval_labels, torch.empty(0, dtype=torch.int64, device=dev)).cpu()
-        self.eval_user_embeddings = cat(self.eval_user_embeddings, torch.empty(0, 0, device=dev)).cpu()
-        self.eval_topk_indices = cat(self.eval_topk_indices, torch.empty(0, 0, dtype=torch.int64, device=dev)).cpu()
-        self.eval_scores = torch.cat(self.eval_scores, dim=0) if (self.keep_scores and self.eval_scores) else None
+        d = self.item_embeddings.shape[1] if self.item_embeddings is not None else 0
+        k = min(self.evaluator._max_k, self.item_embeddings.shape[0]) if self.item_embeddings is not None else 0
+        labels = cat(self.eval_labels, torch.empty(0, dtype=torch.int64, device=dev))
+        users = cat(self.eval_user_embeddings, torch.empty(0, d, device=dev))
+        topk = cat(self.eval_topk_indices, torch.empty(0, k, dtype=torch.int64, device=dev))
         ranks = cat(self._ranks, torch.empty(0, dtype=torch.int32, device=dev))
         lse, lab = cat(self._lse, torch.empty(0, device=dev)), cat(self._lab, torch.empty(0, device=dev))
+        scores = torch.cat(self.eval_scores, dim=0) if (self.keep_scores and self.eval_scores) else None
+        if hasattr(self.model, "check_inputs"):
+            self.model.check_inputs()
+        shard = getattr(self, "_shard", None)
+        if shard is not None and shard.world > 1:
+            fl = shard.gather_rows(torch.cat([lse.view(-1, 1), lab.view(-1, 1), users], dim=1))
+            it = shard.gather_rows(torch.cat([ranks.view(-1, 1).to(torch.int64), labels.view(-1, 1), topk], dim=1))
+            lse, lab, users = fl[:, 0].contiguous(), fl[:, 1].contiguous(), fl[:, 2:].contiguous()
+            ranks, labels, topk = it[:, 0].to(torch.int32).contiguous(), it[:, 1].contiguous(), it[:, 2:].contiguous()
+            if self.keep_scores:  # (U, M) fp32: gathered in column chunks through the device, kept on rank 0 only
+                M = self.item_embeddings.shape[0]
+                local = scores if scores is not None else torch.empty(0, M)
+                parts = [shard.gather_rows(local[:, c0:c0 + 4096].to(dev)) for c0 in range(0, M, 4096)]
+                scores = torch.cat([p_.cpu() for p_ in parts], dim=1) if shard.rank == 0 else None
+        self.eval_labels, self.eval_user_embeddings, self.eval_topk_indices = labels.cpu(), users.cpu(), topk.cpu()
+        self.eval_scores = scores
         # cross_entropy(scores / T, labels) = mean(logsumexp(row / T) - row[label] / T)   (module.py:318, 356)
         loss = float((lse.double() - lab.double()).mean()) if lse.numel() else float("nan")
         metrics = self.evaluator.from_ranks(ranks, metric_prefix=prefix)

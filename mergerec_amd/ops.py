@@ -82,10 +82,12 @@ def task_vector(theta: torch.Tensor, base: torch.Tensor, out: Optional[torch.Ten
 def merge_nway(
     base: torch.Tensor, tv: torch.Tensor, alpha: torch.Tensor, seg_off: Optional[torch.Tensor] = None,
     out: Optional[torch.Tensor] = None, p_begin: int = 0, p_count: Optional[int] = None, out_is_slice: bool = False,
+    operands_are_slices: bool = False,
 ) -> torch.Tensor:
     """out[p] = base[p] + sum_i alpha[s(p), i] * tv[i, p] for p in [p_begin, p_begin + p_count).
     out_is_slice: `out` holds only the slice (p_count floats; out[0] is element p_begin) -- used when a rank
-    merges its arena slice into a send buffer for the all-gather."""
+    merges its arena slice into a send buffer for the all-gather.
+    operands_are_slices: `base` / `tv` hold only that slice too (base[0], tv[i, 0] are element p_begin): the rank never stored the rest."""
     _dev(base, "base", torch.float32), _dev(tv, "tv", torch.float32), _dev(alpha, "alpha", torch.float32)
     if tv.dim() != 2 or tv.shape[1] != base.numel():
         raise ValueError("tv must be (N, P)")
@@ -96,15 +98,23 @@ def merge_nway(
     if seg_off is not None:
         _dev(seg_off, "seg_off", torch.int64)
     out = torch.empty_like(base) if out is None else _dev(out, "out", torch.float32)
-    p_count = P - p_begin if p_count is None else p_count
-    if p_begin < 0 or p_count < 0 or p_begin + p_count > P:
-        raise ValueError("slice out of range")
+    if operands_are_slices:
+        if p_count is None:
+            p_count = P
+        if p_begin < 0 or p_begin % 4 or p_count < 0 or p_count > P:
+            raise ValueError("slice out of range")
+    else:
+        p_count = P - p_begin if p_count is None else p_count
+        if p_begin < 0 or p_count < 0 or p_begin + p_count > P:
+            raise ValueError("slice out of range")
     if out.numel() < (p_count if out_is_slice else p_begin + p_count):
         raise ValueError("out is too small for the requested slice")
     out_ptr = out.data_ptr() - (4 * p_begin if out_is_slice else 0)
+    shift = 4 * p_begin if operands_are_slices else 0  # the kernel indexes with global p: rebase the slice-only operands
     ev = PROF.begin(base.device)
     check(
-        _lib.load().mr_merge_nway_f32(ptr(base), ptr(tv), tv.stride(0), ptr(alpha), ptr(seg_off), N, S, p_begin, p_count, out_ptr, _stream(base)),
+        _lib.load().mr_merge_nway_f32(base.data_ptr() - shift, tv.data_ptr() - shift, tv.stride(0), ptr(alpha), ptr(seg_off), N, S, p_begin, p_count,
+                                      out_ptr, _stream(base)),
         "mr_merge_nway_f32",
     )
     PROF.end(ev, base.device, "merge_nway", nbytes=(N + 2) * p_count * 4)
@@ -195,7 +205,16 @@ def lns_combine(tv: torch.Tensor, mask: torch.Tensor, out: Optional[torch.Tensor
 
 
 # ------------------------------------------------------------------------------------------ encoder
-def pack_tokens(input_ids, attention_mask, cu_seqlens, T: int, pad_id: int, token_type_ids=None, item_position_ids=None):
+INPUT_ERRORS = {1: "input_ids outside [0, vocab)", 2: "position 0 (CLS) must be attended: CLS pooling reads it (encoder/_base.py:45)",
+                4: "token_type_ids out of range", 8: "item_position_ids out of range",
+                16: "only the Recformer pattern (global attention on token 0 only) is built",
+                32: "attention_mask row counts disagree with the lengths handed to the packer"}
+
+
+def pack_tokens(input_ids, attention_mask, cu_seqlens, T: int, pad_id: int, token_type_ids=None, item_position_ids=None,
+                global_attention_mask=None, err_bits: Optional[torch.Tensor] = None, vocab: int = 0, n_type: int = 0, n_ip: int = 0):
+    """Padded (B, L) id tensors -> packed per-token index arrays.  ``err_bits`` (int32 device word, zeroed by the caller): the kernel
+    ORs INPUT_ERRORS bits into it instead of the host validating with reductions + a device sync per batch."""
     _dev(input_ids, "input_ids", torch.int64), _dev(attention_mask, "attention_mask", torch.int64)
     _dev(cu_seqlens, "cu_seqlens", torch.int32)
     B, L = input_ids.shape
@@ -204,14 +223,19 @@ def pack_tokens(input_ids, attention_mask, cu_seqlens, T: int, pad_id: int, toke
     tok_pos = torch.empty(T, dtype=torch.int32, device=dev)
     tok_tt = torch.empty(T, dtype=torch.int32, device=dev) if token_type_ids is not None else None
     tok_ip = torch.empty(T, dtype=torch.int32, device=dev) if item_position_ids is not None else None
-    if token_type_ids is not None:
-        _dev(token_type_ids, "token_type_ids", torch.int64)
-    if item_position_ids is not None:
-        _dev(item_position_ids, "item_position_ids", torch.int64)
+    for t, n in ((token_type_ids, "token_type_ids"), (item_position_ids, "item_position_ids"), (global_attention_mask, "global_attention_mask")):
+        if t is not None:
+            _dev(t, n, torch.int64)
+            if t.shape != input_ids.shape:
+                raise ValueError(f"{n} must have the shape of input_ids")
+    if err_bits is not None:
+        _dev(err_bits, "err_bits", torch.int32)
     check(
-        _lib.load().mr_pack_tokens(ptr(input_ids), ptr(attention_mask), ptr(token_type_ids), ptr(item_position_ids), B, L, pad_id,
-                                   ptr(cu_seqlens), ptr(tok_word), ptr(tok_pos), ptr(tok_tt), ptr(tok_ip), _stream(input_ids)),
-        "mr_pack_tokens",
+        _lib.load().mr_pack_tokens_checked(ptr(input_ids), ptr(attention_mask), ptr(token_type_ids), ptr(item_position_ids),
+                                           ptr(global_attention_mask if err_bits is not None else None), B, L, pad_id, vocab, n_type, n_ip,
+                                           ptr(cu_seqlens), ptr(tok_word), ptr(tok_pos), ptr(tok_tt), ptr(tok_ip), ptr(err_bits),
+                                           _stream(input_ids)),
+        "mr_pack_tokens_checked",
     )
     return tok_word, tok_pos, tok_tt, tok_ip
 

@@ -24,6 +24,32 @@ import torch.distributed as dist
 ALIGN = 64
 
 
+def init_from_env(verbose: bool = True) -> Tuple[int, int]:
+    """Entry-point helper of the CLIs: under ``python -m torch.distributed.run --nproc-per-node N <script>`` (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment) bind this process to its GPU and create the process group -- backend "nccl" (= RCCL
+    over xGMI), or MERGEREC_DIST_BACKEND=gloo to rehearse several ranks on fewer GPUs (collectives staged through the host).
+    Without those variables: a no-op, (0, 1).  Must run before any model is built (models take ``torch.cuda.current_device()``)."""
+    import os
+
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or is_dist():
+        return world()
+    local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    backend = os.environ.get("MERGEREC_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ws > ndev and int(os.environ.get("LOCAL_WORLD_SIZE", ws)) > ndev:
+        raise SystemExit(f"{ws} ranks need {ws} GPUs, {ndev} visible (set MERGEREC_DIST_BACKEND=gloo to share GPUs in a rehearsal)")
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    if verbose and dist.get_rank() == 0:
+        print(f"[dist] {ws} ranks, backend {backend}")
+    return world()
+
+
 def is_dist() -> bool:
     return dist.is_available() and dist.is_initialized()
 
@@ -140,6 +166,116 @@ def all_gather_vector(local: torch.Tensor, group=None) -> torch.Tensor:
         blocks.append((lo, lo + s))
         lo += s
     return all_gather_rows(local.reshape(-1, 1), blocks, group=group).reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------------ dataloader shards
+def deal_rows(weights: Optional[torch.Tensor], n_rows: int, world_size: int) -> List[torch.Tensor]:
+    """Row ids of every rank, each list ascending.  ``weights`` None: contiguous near-equal blocks (``row_blocks``).  Otherwise the
+    rows are sorted by weight (tokens, or a cheap proxy such as the number of items of a sequence) and dealt in snake order --
+    counts differ by at most one and the weight totals by a fraction of a per cent at Amazon-shaped length distributions."""
+    if weights is None:
+        return [torch.arange(lo, hi) for lo, hi in row_blocks(n_rows, world_size)]
+    if weights.numel() != n_rows:
+        raise ValueError("one weight per row expected")
+    order = torch.argsort(weights.to(torch.float64), descending=True, stable=True)
+    pos = torch.arange(n_rows)
+    rnd, col = pos // world_size, pos % world_size
+    owner = torch.where(rnd % 2 == 1, world_size - 1 - col, col)
+    return [torch.sort(order[owner == r]).values for r in range(world_size)]
+
+
+def _batch_rows(batch) -> int:
+    enc = getattr(batch, "items", None)
+    if enc is None:
+        enc = batch.sequence
+    return int(enc["input_ids"].shape[0])
+
+
+class ShardedLoader:
+    """This rank's share of a dataloader that yields BatchItem / BatchSequence, plus what is needed to put per-row results back
+    into the loader's row order on EVERY rank (``gather_rows``).  With one rank (or no process group) it is the loader itself.
+
+    Accepted loaders, cheapest split first:
+      * ``data.TokenizedBatches`` (pre-tokenised tensors): row-level split, exact token balance;
+      * ``torch.utils.data.DataLoader`` over a map-style dataset in sequential order: the same dataset / collator / batch size over
+        this rank's rows only, so each rank tokenises just its share; balance proxy = the length of a sample's item list;
+      * a list / tuple of batches, or any other iterable (materialised): contiguous blocks of whole batches.
+    ``balance`` False keeps contiguous blocks (the catalog: item lengths are near-uniform)."""
+
+    def __init__(self, loader, balance: bool = True, group=None):
+        self.group = group
+        self.rank, self.world = world()
+        self.loader = loader
+        self.index_lists: Optional[List[torch.Tensor]] = None
+        if self.world == 1:
+            self.local = loader
+            return
+        from .data import TokenizedBatches
+
+        W, r = self.world, self.rank
+        if isinstance(loader, TokenizedBatches) and loader.rows is None:
+            n = loader.hi - loader.lo
+            wts = loader.enc["attention_mask"][loader.lo:loader.hi].ne(0).sum(1) if balance else None
+            self.index_lists = [ix + loader.lo for ix in deal_rows(wts, n, W)]
+            self.local = TokenizedBatches(loader.enc, loader.bs, loader.labels, rows=self.index_lists[r])
+            self.index_lists = [ix - loader.lo for ix in self.index_lists]
+            return
+        try:
+            from torch.utils.data import DataLoader, SequentialSampler, Subset
+        except Exception:  # pragma: no cover
+            DataLoader = None
+        if DataLoader is not None and isinstance(loader, DataLoader) and isinstance(getattr(loader, "sampler", None), SequentialSampler) \
+                and hasattr(loader.dataset, "__getitem__") and loader.batch_size is not None:
+            ds = loader.dataset
+            n = len(ds)
+            wts = None
+            if balance and n:
+                probe = ds[0]
+                if isinstance(probe, (tuple, list)) and len(probe) == 2 and hasattr(probe[1], "__len__"):
+                    wts = torch.tensor([len(ds[i][1]) for i in range(n)])
+            self.index_lists = deal_rows(wts, n, W)
+            self.local = DataLoader(Subset(ds, self.index_lists[r].tolist()), batch_size=loader.batch_size, collate_fn=loader.collate_fn,
+                                    shuffle=False, num_workers=loader.num_workers, drop_last=False)
+            return
+        batches = loader if isinstance(loader, (list, tuple)) else list(loader)
+        sizes = [_batch_rows(b) for b in batches]
+        starts = [0]
+        for n in sizes:
+            starts.append(starts[-1] + n)
+        blocks = row_blocks(len(batches), W)
+        self.index_lists = [torch.arange(starts[lo], starts[hi]) for lo, hi in blocks]
+        lo, hi = blocks[r]
+        self.local = batches[lo:hi]
+
+    def __iter__(self):
+        return iter(self.local)
+
+    def __len__(self):
+        return len(self.local)
+
+    @property
+    def n_rows(self) -> Optional[int]:
+        return None if self.index_lists is None else sum(ix.numel() for ix in self.index_lists)
+
+    def gather_rows(self, local: torch.Tensor) -> torch.Tensor:
+        """(n_local, ...) per-row results in this rank's row order -> (n_rows, ...) in the loader's row order, on every rank.
+        ONE all-gather of max-count-padded blocks (RCCL over xGMI under the "nccl" backend)."""
+        if self.world == 1:
+            return local
+        counts = [ix.numel() for ix in self.index_lists]
+        if local.shape[0] != counts[self.rank]:
+            raise ValueError(f"rank {self.rank} produced {local.shape[0]} rows for a shard of {counts[self.rank]}")
+        mx = max(counts)
+        tail = local.shape[1:]
+        send = local.new_zeros((mx, *tail))
+        send[: local.shape[0]] = local
+        recv = local.new_empty((self.world * mx, *tail))
+        _all_gather_into(recv, send.contiguous(), group=self.group)
+        out = local.new_empty((sum(counts), *tail))
+        for r, ix in enumerate(self.index_lists):
+            if ix.numel():
+                out[ix.to(local.device)] = recv[r * mx : r * mx + ix.numel()]
+        return out
 
 
 # ------------------------------------------------------------------------------------------------ data-parallel alpha training

@@ -1,5 +1,5 @@
-"""Mirror of the reference's top-level utils.py (remove_duplicate_prefix :17-29, test_model :32-134,
-save_predictions :178-214) plus the minimal Trainer the test loop needs when lightning is absent."""
+"""Mirror of the reference's top-level utils.py (remove_duplicate_prefix :17-29, test_model :32-134 with the reference's argument
+list, save_predictions :178-214) plus the minimal Trainer the test loop needs when lightning is absent."""
 from __future__ import annotations
 
 import ast
@@ -57,6 +57,13 @@ class Trainer:
 
     @torch.no_grad()
     def test(self, module: RecModule, dataloader: Iterable, verbose: bool = False) -> List[Dict[str, float]]:
+        """One evaluation epoch.  With ``torch.distributed`` initialised on several ranks (one per GPU) every rank calls this with the
+        SAME dataloader: the catalog rows (callback) and the user sequences are dealt over the ranks (``parallel.ShardedLoader``,
+        token-balanced), each rank scores its users against the full item matrix, and the per-user results are gathered at the
+        epoch end -- every rank returns the single-process metrics."""
+        from .data import coalesce_batches
+        from .parallel import ShardedLoader
+
         module.trainer = self
         module.eval()
         if self.gemm_mode is not None and hasattr(module.model, "set_gemm_mode"):
@@ -65,22 +72,67 @@ class Trainer:
             if hasattr(cb, "on_test_epoch_start"):
                 cb.on_test_epoch_start(self, module)
         module.on_test_epoch_start()
-        from .data import coalesce_batches
-
-        stream = coalesce_batches(dataloader, self.coalesce_tokens) if self.coalesce_tokens else dataloader
+        shard = ShardedLoader(dataloader, balance=True)
+        module._shard = shard
+        stream = coalesce_batches(shard, self.coalesce_tokens) if self.coalesce_tokens else shard
         for i, batch in enumerate(stream):
             module.test_step(batch.to(module.device), i)
         metrics = module.on_test_epoch_end()
+        module._shard = None
         return [dict(metrics)]
 
 
-def test_model(module: RecModule, item_dataloaders: Sequence[Iterable], sequence_dataloaders: Sequence[Iterable],
-               data_names: Sequence[str], precision: str = "32-true", metrics_path: Optional[Path] = None,
-               predictions_path: Optional[Path] = None, item_embeddings_path: Optional[Path] = None,
-               user_embeddings_path: Optional[Path] = None):
-    """utils.py:32-134 from the point where the per-domain dataloaders exist (the datamodule / tokeniser
-    side is a 'next' row).  Returns (metric_dict, metrics, scores, labels) like the reference; ``scores``
-    entries are None unless predictions are being saved (the fused path does not materialise them)."""
+def _domain_loaders(model_type, data_path, model_tokenizer, batch_size, max_seq_len, max_attribute_len, max_items, num_workers,
+                    sequence_prompt, item_prompt, reverse_sequence, data_split, vocab):
+    """(name, item dataloader, sequence dataloader) of one ``data_paths`` entry: a dataset directory in the reference's JSON format
+    (utils.py:62-81: datamodule + tokenizer), or -- this build's additions -- a directory / file with pre-tokenised tensors
+    (``tokenized.pt``) or a ``synthetic:<Name>[:M[:U]]`` spec (mergerec_amd/data.py)."""
+    if data_split not in ("val", "test"):
+        raise ValueError(f"Unknown data split: {data_split}")
+    spec = str(data_path)
+    if not spec.startswith("synthetic:") and (Path(spec) / "train.json").exists():
+        if model_tokenizer is None:
+            raise ValueError("a tokenizer is required for dataset directories in the JSON format (pass tokenizer_name_or_path = a local "
+                             "tokenizer directory to the model; the box is offline)")
+        dm = get_data_module(model_type, batch_size, Path(spec), item_prompt, max_attribute_len, max_items, max_seq_len, model_tokenizer,
+                             None, num_workers, reverse_sequence, sequence_prompt)
+        dm.setup("fit")
+        return Path(spec).name, dm.item_dataloader(), (dm.val_dataloader() if data_split == "val" else dm.test_dataloader())
+    from .data import load_domain
+
+    kind = "recformer" if getattr(model_type, "name", str(model_type)).upper().startswith("RECFORMER") else "roberta"
+    dom = load_domain(spec, kind=kind, vocab=vocab)
+    return dom.name, dom.item_dataloader(batch_size), dom.sequence_dataloader(batch_size)
+
+
+def test_model(module: RecModule, model_type, data_paths: Sequence, model_tokenizer, batch_size: int, max_seq_len: int,
+               max_attribute_len: int, max_items: Optional[int], num_workers: int, sequence_prompt: Optional[str],
+               item_prompt: Optional[str], reverse_sequence: bool, precision: str, data_split: str,
+               metrics_path: Optional[Path] = None, predictions_path: Optional[Path] = None,
+               item_embeddings_path: Optional[Path] = None, user_embeddings_path: Optional[Path] = None) -> tuple:
+    """The reference's ``test_model`` (utils.py:32-134), argument for argument: dataset paths in, (metric_dict, metrics, scores,
+    labels) out; ``metric_dict`` keys ``test/dataset_{i}/{k}``.  ``scores`` entries are None unless ``predictions_path`` is given (the
+    fused scoring kernel does not materialise the (users, items) matrix otherwise).  Runs sharded over the ranks when launched under
+    ``torch.distributed.run`` (see ``Trainer.test``)."""
+    vocab = getattr(getattr(module.model, "spec", None), "vocab", 50265)
+    names, item_dls, seq_dls = [], [], []
+    for data_path in data_paths:
+        name, item_dl, seq_dl = _domain_loaders(model_type, data_path, model_tokenizer, batch_size, max_seq_len, max_attribute_len, max_items,
+                                                num_workers, sequence_prompt, item_prompt, reverse_sequence, data_split, vocab)
+        names.append(name)
+        item_dls.append(item_dl)
+        seq_dls.append(seq_dl)
+    return test_model_on_dataloaders(module, item_dls, seq_dls, names, precision=precision, metrics_path=metrics_path,
+                                     predictions_path=predictions_path, item_embeddings_path=item_embeddings_path,
+                                     user_embeddings_path=user_embeddings_path)
+
+
+def test_model_on_dataloaders(module: RecModule, item_dataloaders: Sequence[Iterable], sequence_dataloaders: Sequence[Iterable],
+                              data_names: Sequence[str], precision: str = "32-true", metrics_path: Optional[Path] = None,
+                              predictions_path: Optional[Path] = None, item_embeddings_path: Optional[Path] = None,
+                              user_embeddings_path: Optional[Path] = None):
+    """utils.py:83-134: the per-domain test loop of ``test_model`` from the point where the dataloaders exist (callers that already
+    hold dataloaders -- tests, synthetic domains -- enter here)."""
     cb = ItemEncodingCallback()
     trainer = Trainer(precision=precision, callbacks=[cb])
     module.keep_scores = predictions_path is not None
@@ -89,7 +141,7 @@ def test_model(module: RecModule, item_dataloaders: Sequence[Iterable], sequence
         cb.item_dataloader = item_dl
         module.item_embeddings = None  # utils.py:110: catalog re-encoded per domain
         metric = trainer.test(module, seq_dl, verbose=False)
-        scores.append(None if module.eval_scores is None else module.eval_scores.detach().cpu().clone())
+        scores.append(None if module.eval_scores is None else module.eval_scores.detach().cpu())
         labels.append(module.eval_labels.detach().cpu().clone())
         item_embs.append(module.item_embeddings.detach().cpu().clone())
         user_embs.append(module.eval_user_embeddings.detach().cpu().clone())
@@ -366,30 +418,14 @@ def get_data_module(model_type, batch_size, data_path, item_prompt, max_attribut
                          reverse_sequence=reverse_sequence)
 
 
-def test_model_from_paths(module: RecModule, model_type, data_paths: Sequence[Path], model_tokenizer, batch_size: int, max_seq_len: int,
-                          max_attribute_len: int, max_items: Optional[int], num_workers: int, sequence_prompt: Optional[str],
-                          item_prompt: Optional[str], reverse_sequence: bool, precision: str, data_split: str,
-                          metrics_path: Optional[Path] = None, predictions_path: Optional[Path] = None,
-                          item_embeddings_path: Optional[Path] = None, user_embeddings_path: Optional[Path] = None):
-    """The reference's ``test_model`` signature (utils.py:30-134): dataset directories in, metrics out."""
-    item_dls, seq_dls = [], []
-    for data_path in data_paths:
-        dm = get_data_module(model_type, batch_size, Path(data_path), item_prompt, max_attribute_len, max_items, max_seq_len, model_tokenizer,
-                             None, num_workers, reverse_sequence, sequence_prompt)
-        dm.setup("fit")
-        item_dls.append(dm.item_dataloader())
-        if data_split == "val":
-            seq_dls.append(dm.val_dataloader())
-        elif data_split == "test":
-            seq_dls.append(dm.test_dataloader())
-        else:
-            raise ValueError(f"Unknown data split: {data_split}")
-    return test_model(module, item_dls, seq_dls, [Path(p).name for p in data_paths], precision=precision, metrics_path=metrics_path,
-                      predictions_path=predictions_path, item_embeddings_path=item_embeddings_path, user_embeddings_path=user_embeddings_path)
-
-
 def save_predictions(data_names, item_embeddings, item_embeddings_path, labels, metrics, metrics_path, predictions_path,
                      scores, user_embeddings, user_embeddings_path):
+    """utils.py:178-214.  ``data_names``: dataset directory names (or Paths, whose ``.name`` is used).  One writer: rank 0."""
+    from .parallel import world
+
+    if world()[0] != 0:
+        return
+    data_names = [getattr(n, "name", n) if isinstance(n, Path) else n for n in data_names]
     if metrics_path is not None:  # utils.py:191-196: CSV indexed by dataset dir name
         cols = list(metrics[0].keys()) if metrics else []
         with open(metrics_path, "w", newline="") as f:

@@ -1,0 +1,78 @@
+"""Several ranks behind the drop-in surface, with the REAL kernels (BASELINE configs[3], configs[4]).
+
+Each test launches a fresh child ``python -m torch.distributed.run --nproc-per-node 2`` on the one GPU of the box with
+MERGEREC_DIST_BACKEND=gloo (collectives staged through the host: RCCL needs one GPU per rank) and compares what rank 0 saved with a
+single-process run of the same script: arena slices + all-gather, catalog shards + all-gather, token-balanced user shards and the
+gathered per-user results must reproduce the single-process outputs BIT FOR BIT (the encoder kernels are batch-composition
+invariant, the merge kernel is elementwise)."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, ranks, timeout=900):
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ranks > 1:
+        env["MERGEREC_DIST_BACKEND"] = "gloo"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_port())] + cmd
+    else:
+        cmd = [sys.executable] + cmd
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, f"{' '.join(map(str, cmd))}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    return r.stdout
+
+
+def test_two_ranks_reproduce_single_process_bit_for_bit(tmp_path):
+    worker = str(ROOT / "tests" / "tools" / "dist_worker.py")
+    _run([worker, str(tmp_path / "one.pt")], 1)
+    _run([worker, str(tmp_path / "two.pt")], 2)
+    one, two = torch.load(tmp_path / "one.pt"), torch.load(tmp_path / "two.pt")
+    assert one.pop("world") == 1 and two.pop("world") == 2
+    assert set(one) == set(two) and len(one) == 3
+    for key in one:
+        a, b = one[key], two[key]
+        assert a["placement"] == "replicated" and b["placement"] == "sliced", key  # the N > 1 default is the north-star split
+        for name in ("merged", "item_embeddings", "user_embeddings", "topk", "labels", "scores", "mm_forward_cls"):
+            assert a[name].shape == b[name].shape and torch.equal(a[name], b[name]), (key, name)
+        assert a["metrics"] == b["metrics"], key
+        assert a["metrics"]["test/NDCG@10"] >= 0.0
+        pa, pb = (torch.load(str(tmp_path / f) + ".pred_" + key.replace("/", "_")) for f in ("one.pt", "two.pt"))
+        assert torch.equal(pa["Toy"]["scores"], pb["Toy"]["scores"]) and torch.equal(pa["Toy"]["labels"], pb["Toy"]["labels"])
+
+
+def test_merge_test_cli_under_torch_distributed_run(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 merge_test.py ...` == `python merge_test.py ...` (metrics CSV, item and user
+    embeddings, predictions), for an 8-domain task-wise merge (BASELINE configs[3]'s shape on a small model)."""
+    def args(tag):
+        return ["merge_test.py", "--model_type", "BLAIR_BASE", "--model_kwargs", "init_seed", "7", "spec.hidden", "128", "spec.heads", "2",
+                "spec.layers", "2", "spec.intermediate", "256", "--finetune_checkpoint_paths",
+                *[f"synthetic:{i}" for i in range(1, 9)], "--merge_type", "task_vector", "--learn_type", "task_wise", "--weight_file", "average",
+                "--data_paths", "synthetic:Pantry:500:400", "synthetic:Toys:300:200", "--precision", "bf16-mixed",
+                "--metrics_path", str(tmp_path / f"{tag}.csv"), "--item_embeddings_path", str(tmp_path / f"{tag}_items.pt"),
+                "--user_embeddings_path", str(tmp_path / f"{tag}_users.pt"), "--predictions_path", str(tmp_path / f"{tag}_pred.pt")]
+
+    _run(args("one"), 1)
+    _run(args("two"), 2)
+    assert (tmp_path / "one.csv").read_text() == (tmp_path / "two.csv").read_text()
+    for name in ("items", "users"):
+        a, b = torch.load(tmp_path / f"one_{name}.pt"), torch.load(tmp_path / f"two_{name}.pt")
+        assert len(a) == len(b) == 2 and all(torch.equal(x, y) for x, y in zip(a, b)), name
+    pa, pb = torch.load(tmp_path / "one_pred.pt"), torch.load(tmp_path / "two_pred.pt")
+    assert pa.keys() == pb.keys() == {"Pantry", "Toys"}
+    for k in pa:
+        assert torch.equal(pa[k]["scores"], pb[k]["scores"]) and torch.equal(pa[k]["labels"], pb[k]["labels"])

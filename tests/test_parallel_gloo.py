@@ -137,3 +137,84 @@ def test_balanced_share_equalises_tokens():
     with pytest.raises(ValueError):
         balanced_share(pool[:-1], world, 0)
 
+
+
+def _sharded_loader_job(rank, world_size):
+    """Every loader form ShardedLoader accepts: the per-row 'result' (here: a row signature computed from the batch tensors)
+    gathered over the ranks must equal the one a single process computes, in the loader's row order."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from torch.utils.data import DataLoader, Dataset
+
+    from mergerec_amd.data import TokenizedBatches, coalesce_batches, load_domain
+    from mergerec_amd.model_batch import BatchItem, BatchSequence
+    from mergerec_amd.parallel import ShardedLoader
+
+    def signature(batches):  # per row: (sum of attended ids, label or -1) -- depends on the row only, not on its batch
+        rows = []
+        for b in batches:
+            enc = b.items if isinstance(b, BatchItem) else b.sequence
+            s = (enc["input_ids"] * enc["attention_mask"]).sum(1).double()
+            lab = b.labels.double() if isinstance(b, BatchSequence) else torch.full_like(s, -1.0)
+            rows.append(torch.stack([s, lab], dim=1))
+        return torch.cat(rows) if rows else torch.empty(0, 2, dtype=torch.float64)
+
+    dom = load_domain("synthetic:Toy:53:41", vocab=300)
+    out = {}
+    # (a) pre-tokenised tensors: row-level, token-balanced (users) / contiguous (items)
+    for name, loader, balance in (("tok_users", dom.sequence_dataloader(8), True), ("tok_items", dom.item_dataloader(8), False)):
+        sh = ShardedLoader(loader, balance=balance)
+        got = sh.gather_rows(signature(coalesce_batches(sh, 4096)))
+        out[name] = (bool(torch.equal(got, signature(loader))), [ix.numel() for ix in sh.index_lists],
+                     [int(dom.sequences["attention_mask"][ix].sum()) for ix in sh.index_lists] if balance else None)
+    # (b) a torch DataLoader over a map-style dataset whose samples are (index, item list): Subset route, item-count balance
+    class DS(Dataset):
+        def __init__(self):
+            g = torch.Generator().manual_seed(5)
+            self.seqs = [list(range(int(n))) for n in torch.randint(1, 30, (37,), generator=g)]
+        def __len__(self):
+            return len(self.seqs)
+        def __getitem__(self, i):
+            return i, self.seqs[i]
+    def collate(samples):
+        L = max(len(s) for _, s in samples)
+        ids = torch.tensor([[3 + x for x in s] + [1] * (L - len(s)) for _, s in samples])
+        mask = torch.tensor([[1] * len(s) + [0] * (L - len(s)) for _, s in samples])
+        return BatchSequence(sequence={"input_ids": ids, "attention_mask": mask}, labels=torch.tensor([i for i, _ in samples]))
+    dl = DataLoader(DS(), batch_size=5, collate_fn=collate)
+    sh = ShardedLoader(dl, balance=True)
+    got = sh.gather_rows(signature(sh))
+    out["dataloader"] = (bool(torch.equal(got, signature(dl))), [ix.numel() for ix in sh.index_lists], None)
+    # (c) a plain list of batches: whole-batch blocks
+    batches = list(dom.sequence_dataloader(7))
+    sh = ShardedLoader(batches, balance=True)
+    got = sh.gather_rows(signature(sh))
+    out["list"] = (bool(torch.equal(got, signature(batches))), [ix.numel() for ix in sh.index_lists], None)
+    # (d) a generator (materialised)
+    sh = ShardedLoader((b for b in dom.item_dataloader(6)), balance=False)
+    got = sh.gather_rows(signature(sh))
+    out["generator"] = (bool(torch.equal(got, signature(dom.item_dataloader(6)))), [ix.numel() for ix in sh.index_lists], None)
+    return out
+
+
+def test_sharded_loader_reassembles_rows_for_every_loader_form():
+    res = _run(_sharded_loader_job, 2)
+    assert res[0] == res[1]
+    for name, (ok, counts, tokens) in res[0].items():
+        assert ok, name
+        assert sum(counts) in (41, 53, 37) and abs(counts[0] - counts[1]) <= 7, (name, counts)
+    counts, tokens = res[0]["tok_users"][1], res[0]["tok_users"][2]
+    assert abs(counts[0] - counts[1]) <= 1 and max(tokens) <= 1.08 * min(tokens), (counts, tokens)  # snake dealing: near-equal token totals
+
+
+def test_deal_rows_partitions_and_single_rank_is_identity():
+    from mergerec_amd.data import load_domain
+    from mergerec_amd.parallel import ShardedLoader, deal_rows
+
+    w = torch.tensor([5, 1, 9, 3, 7, 2, 8])
+    shares = deal_rows(w, 7, 3)
+    assert sorted(torch.cat(shares).tolist()) == list(range(7)) and all(s.tolist() == sorted(s.tolist()) for s in shares)
+    assert [s.tolist() for s in deal_rows(None, 7, 3)] == [[0, 1, 2], [3, 4], [5, 6]]
+    loader = load_domain("synthetic:Toy:20:10", vocab=300).item_dataloader(4)
+    sh = ShardedLoader(loader)  # no process group: the loader itself
+    assert sh.local is loader and sh.gather_rows(torch.ones(3)).tolist() == [1, 1, 1]

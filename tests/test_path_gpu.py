@@ -1,6 +1,7 @@
 """GPU parity of the whole path behind the reference's own API surface (merger -> encoder -> scoring ->
 evaluator), against the golden vectors produced by the reference and against the CPU oracle."""
 from collections import OrderedDict
+from types import SimpleNamespace
 
 import pytest
 import torch
@@ -173,7 +174,7 @@ def test_end_to_end_merge_encode_score_evaluate(kind):
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
     from mergerec_amd.module import ModelType, RecModule
     from mergerec_amd.synthetic import make_domain
-    from mergerec_amd.utils import test_model
+    from mergerec_amd.utils import test_model_on_dataloaders as test_model
 
     rec = kind.startswith("RECFORMER")
     over = dict(hidden=128, heads=2, layers=2, intermediate=256, vocab=300, max_pos=200)
@@ -296,7 +297,7 @@ def test_precision_flag_selects_arithmetic():
     from mergerec_amd.module import RecModule
     from mergerec_amd.evaluator import Evaluator
     from mergerec_amd.data import load_domain
-    from mergerec_amd.utils import Trainer, precision_to_gemm_mode, test_model
+    from mergerec_amd.utils import Trainer, precision_to_gemm_mode, test_model_on_dataloaders as test_model
 
     assert precision_to_gemm_mode("32-true") is None and precision_to_gemm_mode("bf16-mixed") == "bf16x3"
     with pytest.raises(ValueError):
@@ -501,3 +502,114 @@ def test_large_configs_match_oracle(kind):
     res = L.check(kind, getattr(EncoderSpec, kind)(), verbose=False)
     assert res["f32"][0] <= 5e-6 and res["bf16x6"][0] <= 5e-6 and res["bf16x3"][0] <= 5e-5, res
     assert all(v[1] <= 1e-4 for v in res.values()), res  # the path's contract: cosine logits within 1e-4
+
+
+# ------------------------------------------------------------------ boundary: test_model called exactly as merge_test.py:91-110 calls it
+def test_test_model_called_like_the_reference(tmp_path):
+    """The reference's call site, argument for argument (keywords), on a dataset directory in its JSON format with a local tokenizer;
+    outputs in the reference's shapes: metric_dict keys test/dataset_{i}/..., CSV indexed by the directory name."""
+    import csv
+
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.module import ModelType, RecModule
+    from mergerec_amd.utils import test_model
+    from tests.conftest import GOLDEN
+
+    config = SimpleNamespace(
+        model_type="BLAIR_BASE", data_paths=[GOLDEN / "mini_dataset"], batch_size=8, max_seq_len=96, max_attribute_len=12, max_items=20,
+        num_workers=0, sequence_prompt=None, item_prompt=None, reverse_sequence=True, precision="32-true", test_data_split="test",
+        metrics_path=tmp_path / "m.csv", predictions_path=tmp_path / "p.pt", item_embeddings_path=tmp_path / "i.pt",
+        user_embeddings_path=tmp_path / "u.pt", metric_names=["NDCG", "RECALL"], ks=[1, 5, 10, 50], similarity="cosine")
+    model = ModelType[config.model_type].value(
+        model_name_or_path=None, tokenizer_name_or_path=str(GOLDEN / "mini_tokenizer"), lora_config=None, pooling_method="cls",
+        model_kwargs={"init_seed": 7, "spec_overrides": dict(hidden=128, heads=2, layers=2, intermediate=256), "device": DEV}, tokenizer_kwargs={})
+    module = RecModule(model=model, evaluator=Evaluator(metrics=config.metric_names, ks=config.ks), negative_sample=None, similarity=config.similarity)
+    _, metrics, scores, labels = test_model(
+        module=module,
+        model_type=ModelType[config.model_type],
+        data_paths=config.data_paths,
+        model_tokenizer=model.tokenizer,
+        batch_size=config.batch_size,
+        max_seq_len=config.max_seq_len,
+        max_attribute_len=config.max_attribute_len,
+        max_items=config.max_items,
+        num_workers=config.num_workers,
+        sequence_prompt=config.sequence_prompt,
+        item_prompt=config.item_prompt,
+        reverse_sequence=config.reverse_sequence,
+        precision=config.precision,
+        data_split=config.test_data_split,
+        metrics_path=config.metrics_path,
+        predictions_path=config.predictions_path,
+        item_embeddings_path=config.item_embeddings_path,
+        user_embeddings_path=config.user_embeddings_path,
+    )
+    assert len(metrics) == 1 and set(metrics[0]) >= {"test/NDCG@10", "test/Recall@50", "test/loss"}
+    n_users, n_items = labels[0].numel(), torch.load(config.item_embeddings_path)[0].shape[0]
+    assert scores[0].shape == (n_users, n_items)  # predictions_path given -> the (users, items) block is materialised like the reference's
+    rows = list(csv.DictReader(open(config.metrics_path)))
+    assert rows[0]["dataset"] == "mini_dataset" and float(rows[0]["test/NDCG@10"]) == metrics[0]["test/NDCG@10"]
+    pred = torch.load(config.predictions_path)["mini_dataset"]
+    assert torch.equal(pred["scores"], scores[0]) and torch.equal(pred["labels"], labels[0])
+    # the reference's top-k of those scores ranks the labels where the fused kernel did
+    top = torch.topk(scores[0], min(50, n_items), dim=1).indices
+    hit10 = (top[:, :10] == labels[0][:, None]).any(1).double().mean().item()
+    assert abs(hit10 - metrics[0]["test/Recall@10"]) < 1e-12
+    with pytest.raises(ValueError):
+        test_model(module, ModelType.BLAIR_BASE, config.data_paths, model.tokenizer, 8, 96, 12, 20, 0, None, None, True, "32-true", "train")
+
+
+def test_input_contract_violations_surface_at_check_inputs():
+    """ids / token types / item positions out of range, an unattended CLS and foreign global-attention patterns are caught inside the
+    packing kernel (no host sync per batch) and raised by check_inputs(); a bad id can never fault the gather (indices are clamped)."""
+    from mergerec_amd.engine import InputError
+    from mergerec_amd.module import ModelType
+
+    over = dict(hidden=128, heads=2, layers=1, intermediate=128, vocab=100, max_pos=64)
+    blair = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 1, "spec_overrides": over, "device": DEV})
+    ids = torch.randint(3, 100, (4, 20))
+    mask = torch.ones(4, 20, dtype=torch.int64)
+    mask[2, 7:] = 0
+    ok = {"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV)}
+    blair.encode_normalized(ok, normalize=True)
+    blair.check_inputs()  # clean
+    bad = dict(ok, input_ids=ids.clone().index_put_((torch.tensor([1]), torch.tensor([3])), torch.tensor(100)).to(DEV))
+    out = blair.encode_normalized(bad, normalize=True)  # runs (clamped gather), flagged
+    assert torch.isfinite(out).all()
+    with pytest.raises(InputError, match="input_ids"):
+        blair.check_inputs()
+    blair.check_inputs()  # the flag was cleared
+    nocls = dict(ok, attention_mask=mask.clone().index_put_((torch.tensor([0]), torch.tensor([0])), torch.tensor(0)).to(DEV))
+    blair.encode_normalized(nocls, normalize=True)
+    with pytest.raises(InputError, match="CLS"):
+        blair.check_inputs()
+    with pytest.raises(InputError):  # "now": checked at once
+        blair.runner.pack(bad, DEV, validate="now")
+    blair.runner.pack(bad, DEV, validate=False)
+    blair.check_inputs()  # unchecked packs leave no trace
+    with pytest.raises(ValueError, match="position table"):
+        blair.encode_normalized({"input_ids": torch.zeros(1, 80, dtype=torch.int64, device=DEV), "attention_mask": torch.ones(1, 80, dtype=torch.int64, device=DEV)}, True)
+    # stale host lengths (rows edited after .to()) are a length mismatch, not silent garbage
+    from mergerec_amd.model_batch import BatchItem
+
+    moved = BatchItem(items={"input_ids": ids, "attention_mask": mask}).to(DEV).items
+    moved["attention_mask"][3, 10:] = 0
+    blair.encode_normalized(moved, normalize=True)
+    with pytest.raises(InputError, match="lengths"):
+        blair.check_inputs()
+
+    rec = ModelType.RECFORMER_BASE.value(model_kwargs={"init_seed": 1, "spec_overrides": dict(over, max_pos=128), "device": DEV})
+    tt = torch.randint(0, 4, (4, 20))
+    ip = torch.randint(0, 51, (4, 20))
+    gm = torch.zeros(4, 20, dtype=torch.int64)
+    gm[:, 0] = 1
+    rb = {"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV), "token_type_ids": tt.to(DEV), "item_position_ids": ip.to(DEV),
+          "global_attention_mask": gm.to(DEV)}
+    rec.encode_normalized(rb, normalize=True)
+    rec.check_inputs()
+    for key, value, msg in (("token_type_ids", 4, "token_type"), ("item_position_ids", 51, "item_position"), ("global_attention_mask", 1, "global attention")):
+        t = {"token_type_ids": tt, "item_position_ids": ip, "global_attention_mask": gm}[key].clone()
+        t[1, 2] = value
+        rec.encode_normalized(dict(rb, **{key: t.to(DEV)}), normalize=True)
+        with pytest.raises(InputError, match=msg):
+            rec.check_inputs()

@@ -1,0 +1,100 @@
+"""north_star's accuracy clause at a real domain's scale: logits within 1e-4, ranked item indices equal (up to the reference's own
+near-ties) and NDCG@10 within 1e-3 of the REFERENCE pipeline, for every encoder arithmetic the build offers.
+
+Fixture: tests/golden/g12_realscale_blair_base.pt, produced in the build container by oracle/gen_golden_realscale.py from the
+reference itself -- its load_merging_module / get_state_dict (2-domain merge, alpha = 0.5: BASELINE configs[1]), transformers'
+RobertaModel at BLaIR-base true dimensions (12 x 768, 124.6 M parameters), user @ item.T and its Evaluator -- on a Pantry-sized
+synthetic domain (4,968 items, 2,048 users).  Inputs are regenerated from seeds here; the fixture holds outputs and the labels."""
+from collections import OrderedDict
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOGIT_TOL = 1e-4       # north_star
+NEAR_TIE = 2e-6        # two items whose REFERENCE scores are this close may swap places (fp32 summation order)
+NDCG_TOL = 1e-3        # north_star
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchSequence
+    from mergerec_amd.module import ModelType
+    from mergerec_amd.synthetic import make_domain
+
+    fx = load_golden("g12_realscale_blair_base.pt")
+    cfg = O.EncoderConfig()
+    pre0 = O.random_state_dict(O.roberta_param_shapes(cfg), seed=fx["seed_pre"], std=0.02)
+    pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])  # the order the reference's wrapper yielded (perturbations are drawn along it)
+    assert abs(float(sum(v.double().sum() for v in pre.values())) - fx["pre_checksum"]) < 1e-6 * abs(fx["pre_checksum"]) + 1e-9
+    fts = [O.perturbed_state_dict(pre, seed=s, std=fx["ft_std"]) for s in fx["seed_ft"]]
+    model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "device": DEV})
+    model.load_state_dict(pre)
+    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, pre, fts, set(), disable_softmax=True)
+    mm.load_weights_from_dict({"global_weights": {"all": [1.0]}, "global_biases": {"all": [0.0]}, "per_weights": {"all": [fx["alpha"]] * 2}})
+    sd = {k: v.detach().clone() for k, v in mm.get_state_dict().items()}
+    merged_sum = float(sum(v.double().sum() for v in sd.values()))
+    assert abs(merged_sum - fx["merged_checksum"]) < 1e-9 * max(1.0, abs(fx["merged_checksum"])) + 1e-6, (merged_sum, fx["merged_checksum"])
+    del mm, model, fts
+    torch.cuda.empty_cache()
+    dom = make_domain("Pantry", fx["n_items"], fx["n_users"], 32, cfg.vocab, fx["seed_domain"])
+    lab = fx["labels"]
+    seqs, at = [], 0
+    for b in dom.sequence_batches:  # the fixture's labels (the reference's rank-derived items) replace the generator's random ones
+        n = b.labels.numel()
+        seqs.append(BatchSequence(sequence=b.sequence, labels=lab[at:at + n].clone()))
+        at += n
+    ref_scores = fx["U"] @ fx["E"].T
+    return fx, sd, dom.item_batches, seqs, ref_scores
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "bf16x3"])
+def test_realscale_logits_ranks_and_ndcg_match_the_reference(setup, mode, tmp_path):
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.module import ModelType, RecModule
+    from mergerec_amd.utils import test_model_on_dataloaders
+
+    fx, sd, item_batches, seq_batches, ref_scores = setup
+    model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "device": DEV, "gemm_mode": mode})
+    model.load_state_dict(sd)  # merge_test.py:71-80
+    module = RecModule(model=model, evaluator=Evaluator(["NDCG", "RECALL"], fx["ks"]), similarity="cosine")
+    _, metrics, scores, labels = test_model_on_dataloaders(module, [item_batches], [seq_batches], ["Pantry"], predictions_path=tmp_path / "p.pt")
+    assert model._weights.mode == mode
+    E, U, got = module.item_embeddings.detach().cpu(), module.eval_user_embeddings, scores[0]
+    assert torch.equal(labels[0], fx["labels"])
+    # (1) embeddings and logits
+    assert float((E - fx["E"]).abs().max()) < LOGIT_TOL and float((U - fx["U"]).abs().max()) < LOGIT_TOL
+    logit_err = float((got - ref_scores).abs().max())
+    assert logit_err < LOGIT_TOL, logit_err
+    # (2) ranked item indices: identical to the reference's top-50 except where the reference's own scores are within NEAR_TIE
+    idx = module.eval_topk_indices
+    ref_idx = fx["ref_top50_idx"].long()
+    assert O.ranks_equal_up_to_ties(ref_scores, idx, ref_idx, atol=NEAR_TIE), "ranked indices differ beyond the reference's near-ties"
+    exact_rows = int((idx == ref_idx).all(1).sum())
+    # every position whose reference score is separated from both neighbours by more than twice the near-tie budget must hold
+    # exactly the reference's item (scores this close to 1.0 sit on a 6e-8 grid: most rows have SOME near-tie, few positions do)
+    top51 = torch.topk(ref_scores, 51, dim=1).values
+    gap = top51[:, :-1] - top51[:, 1:]                                    # gap[p] = s[p] - s[p + 1], p = 0..49
+    above = torch.cat([torch.full_like(gap[:, :1], float("inf")), gap[:, :-1]], dim=1)
+    clear = (gap > 2 * NEAR_TIE) & (above > 2 * NEAR_TIE)
+    assert bool((idx[clear] == ref_idx[clear]).all()), "a clearly separated rank position holds a different item"
+    # (3) label ranks and metrics
+    lab_score = ref_scores[torch.arange(len(labels[0])), labels[0]]
+    my_rank = (got > got[torch.arange(len(labels[0])), labels[0]][:, None]).sum(1)
+    moved = my_rank != fx["label_rank"].long()
+    if moved.any():  # a label may move only across items the reference scores within NEAR_TIE of it
+        for u in torch.nonzero(moved).flatten().tolist():
+            lo, hi = sorted((int(my_rank[u]), int(fx["label_rank"][u])))
+            between = torch.sort(ref_scores[u], descending=True).values[lo:hi + 1]
+            assert float((between - lab_score[u]).abs().max()) <= NEAR_TIE, (u, lo, hi)
+    for k, v in fx["metrics"].items():
+        assert abs(metrics[0][k] - v) <= NDCG_TOL, (k, metrics[0][k], v)
+    assert abs(metrics[0]["test/loss"] - fx["loss"]) < 1e-3
+    print(f"[{mode}] logit max err {logit_err:.2e}; rows with identical top-50: {exact_rows}/{len(idx)} ({int(clear.sum())} of {clear.numel()} positions clearly separated); "
+          f"labels moved {int(moved.sum())}; |dNDCG@10| {abs(metrics[0]['test/NDCG@10'] - fx['metrics']['test/NDCG@10']):.2e}")

@@ -16,7 +16,7 @@ from mergerec_amd.data import load_domain
 from mergerec_amd.evaluator import Evaluator
 from mergerec_amd.merger import LearnType, MergeType, load_merging_module
 from mergerec_amd.module import ModelType, RecModule
-from mergerec_amd.utils import test_model
+from mergerec_amd.utils import test_model_on_dataloaders as test_model
 from oracle import ref_cpu as O
 
 
