@@ -18,8 +18,10 @@ A "step" is one pass of the WHOLE hot path over one batch, per rank:
       (+ all-gather of the refreshed rows when N > 1) -- users_per_step / items_per_step = 2 matches the
       measured users:items ratio of the Amazon domains, so U/users_per_step steps re-encode one full catalog,
   (3) encode `users_per_step` user sequences (CLS pooled, L2-normalised),
-  (4) score them against the FULL catalog and take the canonical top-50 (+ CE terms, label ranks);
-after the K steps the evaluation epoch ends inside the timed region (metric gather + Recall / NDCG).
+  (4) score them against the FULL catalog and take the canonical top-50 (+ CE terms, label ranks).
+The timed region is one evaluation epoch over K steps in the product's own order (utils.Trainer.test): the K steps' catalog rows go
+through `ItemEncoderMixin.encode_items` first (the callback's code: token-coalesced passes, sharded over the ranks + all-gather),
+then the K user steps (merge + encode + score each), then the epoch end (metric gather + Recall / NDCG) -- all inside the timing.
 Nothing is cached across steps; inputs are resident in HBM before the timed region.
 value = users_per_step * N * K / max-over-ranks wall time (weak scaling: per-GPU work is fixed).
 """
@@ -83,7 +85,14 @@ class DeviceSampler(threading.Thread):
         cands = []
         if pci_bus_id:
             cands += glob.glob(f"/sys/bus/pci/devices/{pci_bus_id.lower()}/hwmon/hwmon*")
-        cands += sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        if not cands:  # a box may expose the hwmon files of every GPU of its host: without a PCI match take the card that is drawing power
+            allc = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+            if len(allc) == 1:
+                cands = allc
+            elif allc:
+                draw = [(self._read(os.path.join(c, "power1_input")) or self._read(os.path.join(c, "power1_average")) or 0.0, c) for c in allc]
+                cands = [max(draw)[1]]
+                self.note = "no PCI match: busiest card at start of the timed region"
         for c in cands:
             if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input")) or os.path.exists(os.path.join(c, "freq1_input")):
                 self.dir = c
@@ -144,6 +153,16 @@ def synth_state_dicts(model, n_dom, device, seed=1001):
 
 
 def main():
+    # rank 0 prints ONE JSON line on stdout: the product objects' progress prints ("Calculating task vectors...") go to stderr
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        _main(real_stdout)
+    finally:
+        sys.stdout = real_stdout
+
+
+def _main(real_stdout):
     args = parse()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world_env == 1:
@@ -198,15 +217,35 @@ def main():
 
     # the collator side: CPU batches in the reference's dataclasses; `.to(dev)` (what the Trainer does per batch) happens HERE, before
     # the timed region, so inputs are HBM-resident; the per-row lengths travel with the moved batch (model_batch.Encoding.host_lens)
-    user_batches, item_batches = [], []
-    tok_u = tok_i = 0
+    user_batches = []
+    tok_u = 0
     for s in range(n_total):
-        ul, il = my_share(blair_sequence_lengths, U_step), my_share(blair_item_lengths, I_step)
-        tok_u, tok_i = tok_u + int(ul.sum()), tok_i + int(il.sum())
+        ul = my_share(blair_sequence_lengths, U_step)
+        tok_u += int(ul.sum())
         labels = torch.randint(0, M, (U_step,), generator=g)
         user_batches.append(BatchSequence(sequence=_ids_from_lengths(ul, spec.vocab, g), labels=labels).to(dev))
-        item_batches.append(BatchItem(items=_ids_from_lengths(il, spec.vocab, g)).to(dev))
-    avg_user_tokens, avg_item_tokens = tok_u / (n_total * U_step), tok_i / (n_total * I_step)
+    # catalog rows: the SAME global list of item batches on every rank (shared seed).  As in the product, the collator's 128-item batches
+    # are coalesced ON THE HOST into token-sized encoder passes (data.coalesce_batches: utils.Trainer's 65,536-token budget) before they
+    # are moved; encode_items then deals the passes over the ranks (parallel.ShardedLoader: contiguous blocks = this rank's steps).
+    from mergerec_amd.data import coalesce_batches
+
+    g_items = torch.Generator().manual_seed(777)
+    per_pass = max(1, 65536 // (I_step * 40))  # collator batches per pass: fixed count, so every rank builds the same list
+
+    def item_passes(n_steps):
+        out = []
+        for r in range(world):
+            blk = []
+            for s in range(n_steps):
+                il = blair_item_lengths(I_step, g_items)
+                blk.append((BatchItem(items=_ids_from_lengths(il, spec.vocab, g_items)), int(il.sum())))
+            for c0 in range(0, n_steps, per_pass):
+                out.extend(b.to(dev) for b in coalesce_batches([b for b, _ in blk[c0:c0 + per_pass]], 1 << 30))
+        return out, sum(t for _, t in blk) if n_steps else 0
+
+    items_warm, _ = item_passes(args.warmup)
+    items_timed, tok_i = item_passes(args.steps)
+    avg_user_tokens, avg_item_tokens = tok_u / (n_total * U_step), tok_i / max(args.steps * I_step, 1)
 
     # full catalog encoded once with the merged model (setup): E (M, d), row == item id
     merged_model.load_weights()
@@ -220,26 +259,29 @@ def main():
     model.check_inputs()
     torch.cuda.synchronize()
 
-    item_blocks = [(r * I_step, (r + 1) * I_step) for r in range(world)]
+    from mergerec_amd.module.callbacks import ItemEncoderMixin
+
+    module.trainer = type("T", (), {"coalesce_tokens": 0})()  # the passes were coalesced on the host above (HBM-resident inputs)
     state = {"cursor": 0}
 
     @torch.no_grad()
     def step(i):
         # (1) the merge, as TaskVectorMergingModuleBase.forward does it on every call (_base.py:78-81): into the arena the model reads
         merged_model.load_weights(force=True)
-        # (2) catalog rows: RecModule.forward(BatchItem) -> normalised embeddings; refresh those rows before scoring
-        e_new = module.forward(item_batches[i])
-        e_all = parallel.all_gather_rows(e_new, item_blocks) if world > 1 else e_new
-        c = state["cursor"]
-        n = e_all.shape[0]
-        if c + n > M:
-            c = 0
-        module.item_embeddings.data[c : c + n] = e_all
-        state["cursor"] = c + n
         # (3) + (4) RecModule.test_step: encode users, full-catalog scoring, canonical top-50, CE terms
         module.test_step(user_batches[i], i)
 
-    def epoch(lo, hi):
+    def epoch(lo, hi, passes):
+        # (2) the catalog rows of these steps: the callback's encode (callbacks.py:18-38) -- coalesced passes, rank shards, all-gather
+        if not passes:
+            return None
+        merged_model.load_weights(force=True)
+        e_all = ItemEncoderMixin.encode_items(passes, module)
+        c, n = state["cursor"], e_all.shape[0]
+        if c + n > M:
+            c = 0
+        module.item_embeddings.data[c : c + n] = e_all  # refresh those rows before scoring
+        state["cursor"] = c + n
         module.on_test_epoch_start()
         for i in range(lo, hi):
             step(i)
@@ -247,13 +289,12 @@ def main():
             parallel.all_gather_vector(torch.cat(module._ranks))
         return module.on_test_epoch_end()
 
-    epoch(0, args.warmup)
+    epoch(0, args.warmup, items_warm)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     sampler = None
     if rank == 0:
-        bus = getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)
         bus_id = None
         try:
             p = torch.cuda.get_device_properties(dev)
@@ -266,7 +307,7 @@ def main():
     ops.PROF.records.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    metrics = epoch(args.warmup, n_total)
+    metrics = epoch(args.warmup, n_total, items_timed)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -354,7 +395,7 @@ def main():
             roofline=roofline, cpu_baseline=cpu_baseline, kernels=kernels, parity=parity,
             epoch_metrics_sample={k: round(v, 6) for k, v in list(metrics.items())[:3]},
         )
-        print(json.dumps(out))
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
