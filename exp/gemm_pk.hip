@@ -41,6 +41,9 @@ __global__ void split_pk_kernel(const float* __restrict__ x, int R, int K, int64
         uint2 h, l;
         h.x = pack2(v.x, v.y); h.y = pack2(v.z, v.w);
         l.x = pack2(v.x - lo_f(h.x), v.y - hi_f(h.x)); l.y = pack2(v.z - lo_f(h.y), v.w - hi_f(h.y));
+#ifdef PK_LOMASK  // diagnostic: data-dependent MFMA power -- drop the low mantissa bits of the lo piece (changes numerics)
+        l.x &= PK_LOMASK; l.y &= PK_LOMASK;
+#endif
         const int64_t dst = ((int64_t)(k >> 4) * R_pad + r) * 16 + ((((k >> 3) & 1) ^ (int)((r >> 3) & 1)) * 8) + (k & 7);
         *reinterpret_cast<uint2*>(hi + dst) = h;
         *reinterpret_cast<uint2*>(lo + dst) = l;

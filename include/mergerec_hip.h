@@ -56,6 +56,14 @@ const char* mr_last_hip_error(void);
  * replaces: rec_retrieval/merger/algorithms/task_vector.py:8-10 (get_task_vectors, one row). */
 int mr_task_vector_f32(const float* theta, const float* base, int64_t n, float* tv, mr_stream_t stream);
 
+/* Fixed-weight merges as ONE streaming pass, a running sum in model order with every operation rounded on its own (no FMA):
+ *   base != NULL ("task_vector"): out = (...((base + w_0 (m_0 - base)) + w_1 (m_1 - base)) ...)
+ *   base == NULL ("linear")     : out = (...((0 + w_0 m_0) + w_1 m_1) ...)
+ * models: (N, P) with row stride `stride` (fine-tuned PARAMETERS, not task vectors); weights: N floats on the device.
+ * replaces: rec_retrieval/merger/merger.py:46-93 with algorithms/task_vector.py:13-34 and algorithms/linear.py:8-27. */
+int mr_merge_running_f32(const float* base, const float* models, int64_t stride, const float* weights, int N, int64_t P,
+                         float* out, mr_stream_t stream);
+
 /* out[p] = base[p] + sum_{i<N} round(alpha[s(p)*N + i] * tv[i*tv_stride + p]),  p in [p_begin, p_begin+p_count)
  * with the sum taken sequentially i = 0..N-1 from the first product and NO fused multiply-add, i.e.
  * bit-for-bit torch's `base + (alpha[:, None] * T).sum(0)` on CPU.
@@ -205,7 +213,8 @@ int mr_split_bf16x3_f32(const float* x, int64_t n, uint16_t* hi, uint16_t* mid, 
 
 /* Split every weight matrix listed in `table` (device int64, 3 per matrix: arena offset, N, K; K % 16 == 0, offset % 8
  * == 0) from the fp32 arena into the three bf16 piece arenas in the k-blocked layout mr_gemm_nt_bf16x6_f32 reads.
- * unit_prefix (device int64, n_mat + 1) holds the exclusive prefix sums of N*K/4; total_units = unit_prefix[n_mat]. */
+ * unit_prefix (device int64, n_mat + 1) holds the exclusive prefix sums of N*K/4; total_units = unit_prefix[n_mat].
+ * lo may be NULL: only the hi / mid pieces are written (all the "products = 3" GEMMs read). */
 int mr_split_weights_kblock_f32(const float* arena, const int64_t* table, const int64_t* unit_prefix, int n_mat,
                                 int64_t total_units, uint16_t* hi, uint16_t* mid, uint16_t* lo, mr_stream_t stream);
 

@@ -84,6 +84,7 @@ def main(argv=None):
         sample_method=_pop(argv, "--sample_method", "random"),
         weights_dir=_pop(argv, "--weights_dir", "weights"),
         skip_test=_pop(argv, "--skip_test", "false").lower() in ("1", "true", "yes"),
+        result_path=_pop(argv, "--result_path", None),  # every rank saves its result dict to <result_path>.rank<r>.pt
     )
     config = mt.parse(argv)
     from mergerec_amd.datamodule import DistillSequenceDataModule, DistillSequenceDataModuleForRecformer, load_tokenizer
@@ -199,6 +200,8 @@ def main(argv=None):
         if rank == 0:
             print(f"Test metrics after training: {metric_dict}")
         result["test_metrics"] = metric_dict
+    if opt["result_path"]:
+        torch.save(result, f"{opt['result_path']}.rank{rank}.pt")
     if world > 1:
         import torch.distributed as dist
 

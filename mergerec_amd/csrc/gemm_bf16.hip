@@ -70,29 +70,43 @@ __global__ __launch_bounds__(kThreads) void split_bf16x3_kernel(const float* __r
     }
 }
 
+// split 8 fp32 (two float4) into pieces of 8 bf16 (one 16-byte chunk each)
+__device__ __forceinline__ void split8(const float4 x0, const float4 x1, uint4& h, uint4& m, uint4& l) {
+    uint2 h0, m0, l0, h1, m1, l1;
+    split4(x0, h0, m0, l0);
+    split4(x1, h1, m1, l1);
+    h = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    m = make_uint4(m0.x, m0.y, m1.x, m1.y);
+    l = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
 // table[3*i .. 3*i+2] = (arena offset, N, K) of weight matrix i; unit_prefix[i] = number of 4-element units before it.
-// Each thread converts 4 consecutive k of one row and writes them at the k-blocked position of the three piece arenas.
+// One thread = one 16-byte OUTPUT chunk (8 consecutive k of one row): chunk c of a matrix is (k-block, row, half) with the half
+// fastest, so a wave writes 1 KB of contiguous k-blocked output per piece and reads 32 rows x 64 B (the other half of each 128-B
+// line is read by the wave handling the next k-block: an L2 hit).  `lo` may be NULL (bf16x3 keeps two pieces).
 __global__ __launch_bounds__(kThreads) void split_weights_kblock_kernel(const float* __restrict__ arena,
                                                                        const int64_t* __restrict__ table,
                                                                        const int64_t* __restrict__ unit_prefix, int n_mat,
                                                                        uint16_t* __restrict__ hi, uint16_t* __restrict__ mid,
                                                                        uint16_t* __restrict__ lo) {
-    const int64_t total = unit_prefix[n_mat];
-    for (int64_t u = (int64_t)blockIdx.x * kThreads + threadIdx.x; u < total; u += (int64_t)gridDim.x * kThreads) {
-        int a = 0, b = n_mat - 1;  // largest i with unit_prefix[i] <= u
+    const int64_t total = unit_prefix[n_mat] >> 1;  // 8-element chunks
+    for (int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x; c < total; c += (int64_t)gridDim.x * kThreads) {
+        int a = 0, b = n_mat - 1;  // largest i with unit_prefix[i] / 2 <= c
         while (a < b) {
-            const int c = (a + b + 1) >> 1;
-            if (unit_prefix[c] <= u) a = c; else b = c - 1;
+            const int mdl = (a + b + 1) >> 1;
+            if ((unit_prefix[mdl] >> 1) <= c) a = mdl; else b = mdl - 1;
         }
         const int64_t off = table[3 * a], N = table[3 * a + 1], K = table[3 * a + 2];
-        const int64_t e = (u - unit_prefix[a]) * 4;  // row-major element index inside the matrix
-        const int64_t n = e / K, k = e - n * K;
-        uint2 h, m, l;
-        split4(*reinterpret_cast<const float4*>(arena + off + e), h, m, l);
-        const int64_t dst = off + ((k >> 4) * N + n) * 16 + (k & 15);
-        *reinterpret_cast<uint2*>(hi + dst) = h;
-        *reinterpret_cast<uint2*>(mid + dst) = m;
-        *reinterpret_cast<uint2*>(lo + dst) = l;
+        const int64_t cm = c - (unit_prefix[a] >> 1);   // chunk inside the matrix: (kb * N + n) * 2 + half
+        const int half = (int)(cm & 1);
+        const int64_t rowk = cm >> 1, kb = rowk / N, n = rowk - kb * N;
+        const float* src = arena + off + n * K + kb * 16 + half * 8;
+        uint4 h, m, l;
+        split8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4), h, m, l);
+        const int64_t dst = off + cm * 8;
+        *reinterpret_cast<uint4*>(hi + dst) = h;
+        *reinterpret_cast<uint4*>(mid + dst) = m;
+        if (lo) *reinterpret_cast<uint4*>(lo + dst) = l;
     }
 }
 
@@ -457,12 +471,12 @@ extern "C" int mr_split_bf16x3_f32(const float* x, int64_t n, uint16_t* hi, uint
 extern "C" int mr_split_weights_kblock_f32(const float* arena, const int64_t* table, const int64_t* unit_prefix, int n_mat,
                                           int64_t total_units, uint16_t* hi, uint16_t* mid, uint16_t* lo,
                                           mr_stream_t stream) {
-    if (!arena || !table || !unit_prefix || !hi || !mid || !lo || n_mat < 0 || total_units < 0) return MR_EINVAL;
+    if (!arena || !table || !unit_prefix || !hi || !mid || n_mat < 0 || total_units < 0) return MR_EINVAL;
     if (!mr::aligned16(arena) || (reinterpret_cast<uintptr_t>(hi) & 15) || (reinterpret_cast<uintptr_t>(mid) & 15) ||
-        (reinterpret_cast<uintptr_t>(lo) & 15))
+        (lo && (reinterpret_cast<uintptr_t>(lo) & 15)))
         return MR_EALIGN;
     if (n_mat == 0 || total_units == 0) return MR_OK;
-    int64_t blocks = (total_units + kThreads - 1) / kThreads;
+    int64_t blocks = (total_units / 2 + kThreads - 1) / kThreads;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(split_weights_kblock_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, arena, table,
                        unit_prefix, n_mat, hi, mid, lo);
@@ -486,11 +500,11 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
                                      const float* b1, const float* b2, int nseg, int M, int seg_n, int K, int act,
                                      const float* R, int64_t ldr, float* C, int64_t ldc, int products, mr_stream_t stream) {
     if (products != 6 && products != 3) return MR_EUNSUPPORTED;
-    if (!A || !w_hi || !w_mid || !w_lo || !C || nseg < 1 || nseg > 3 || M < 0 || seg_n < 1 || K < 1) return MR_EINVAL;
+    if (!A || !w_hi || !w_mid || (products == 6 && !w_lo) || !C || nseg < 1 || nseg > 3 || M < 0 || seg_n < 1 || K < 1) return MR_EINVAL;
     if (K % BK) return MR_EUNSUPPORTED;
     if (nseg > 1 && (seg_n % 128)) return MR_EUNSUPPORTED;
     if (act != MR_ACT_NONE && act != MR_ACT_GELU_ERF) return MR_EUNSUPPORTED;
-    if ((lda & 3) || !mr::aligned16(A) || !mr::aligned16(w_hi) || !mr::aligned16(w_mid) || !mr::aligned16(w_lo) ||
+    if ((lda & 3) || !mr::aligned16(A) || !mr::aligned16(w_hi) || !mr::aligned16(w_mid) || (w_lo && !mr::aligned16(w_lo)) ||
         (off0 & 7) || (nseg > 1 && (off1 & 7)) || (nseg > 2 && (off2 & 7)))
         return MR_EALIGN;
     if (ldc < 1 || ldc > (1 << 21) || (R && (ldr < 1 || ldr > (1 << 21)))) return MR_EUNSUPPORTED;  // 32-bit tile-local offsets in the epilogue

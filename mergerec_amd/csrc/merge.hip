@@ -218,6 +218,37 @@ __global__ __launch_bounds__(MR_WAVE) void merge_bwd_stage2(const float* __restr
     if (threadIdx.x == 0) dalpha[s * N + i] = (float)acc;
 }
 
+// ModelMerger.merge("task_vector" | "linear") (merger.py:46-93): a running sum in model order, every operation rounded on its own:
+//   task_vector: acc = base;  acc = acc + w_i * (theta_i - base)      (algorithms/task_vector.py:30-32)
+//   linear     : acc = 0;     acc = acc + w_i * theta_i               (algorithms/linear.py:23-25)
+// (the learnable-alpha module sums the products first and adds base last: 1-ulp differences)
+template <bool TASK_VECTOR>
+__global__ __launch_bounds__(kThreads) void merge_running_kernel(const float* __restrict__ base, const float* __restrict__ models,
+                                                                int64_t stride, const float* __restrict__ w, int N, int64_t nvec,
+                                                                float* __restrict__ out) {
+    for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kThreads) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (TASK_VECTOR) b = ld4(base + v * 4);
+        float4 acc = b;
+        for (int i = 0; i < N; ++i) {
+            const float4 m = ld4_nt(models + (int64_t)i * stride + v * 4);
+            const float wi = w[i];
+            if (TASK_VECTOR) {
+                acc.x = __fadd_rn(acc.x, __fmul_rn(wi, __fsub_rn(m.x, b.x)));
+                acc.y = __fadd_rn(acc.y, __fmul_rn(wi, __fsub_rn(m.y, b.y)));
+                acc.z = __fadd_rn(acc.z, __fmul_rn(wi, __fsub_rn(m.z, b.z)));
+                acc.w = __fadd_rn(acc.w, __fmul_rn(wi, __fsub_rn(m.w, b.w)));
+            } else {
+                acc.x = __fadd_rn(acc.x, __fmul_rn(wi, m.x));
+                acc.y = __fadd_rn(acc.y, __fmul_rn(wi, m.y));
+                acc.z = __fadd_rn(acc.z, __fmul_rn(wi, m.z));
+                acc.w = __fadd_rn(acc.w, __fmul_rn(wi, m.w));
+            }
+        }
+        *reinterpret_cast<float4*>(out + v * 4) = acc;
+    }
+}
+
 int64_t host_chunk_upper_bound(int S, int64_t P) { return (P + kBwdChunk - 1) / kBwdChunk + S; }
 
 }  // namespace
@@ -230,6 +261,21 @@ extern "C" int mr_task_vector_f32(const float* theta, const float* base, int64_t
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(task_vector_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, theta, base, n, tv);
+    return mr::check_launch();
+}
+
+extern "C" int mr_merge_running_f32(const float* base, const float* models, int64_t stride, const float* weights, int N, int64_t P,
+                                    float* out, mr_stream_t stream) {
+    if (!models || !weights || !out || N < 1 || P < 0) return MR_EINVAL;
+    if ((P & 3) || (stride & 3)) return MR_EALIGN;
+    if (!mr::aligned16(models) || !mr::aligned16(out) || (base && !mr::aligned16(base))) return MR_EALIGN;
+    if (P == 0) return MR_OK;
+    int64_t blocks = (P / 4 + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (base)
+        hipLaunchKernelGGL((merge_running_kernel<true>), dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, base, models, stride, weights, N, P / 4, out);
+    else
+        hipLaunchKernelGGL((merge_running_kernel<false>), dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, base, models, stride, weights, N, P / 4, out);
     return mr::check_launch();
 }
 

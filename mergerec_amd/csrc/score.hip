@@ -4,8 +4,9 @@
 // One 256-thread workgroup per score row.  Exact radix select on order-preserving 32-bit keys
 // (4 passes x 8 bits, histograms in LDS) finds the k-th largest key; a collection pass takes
 // everything above it plus the lowest-index ties, and one wavefront bitonic-sorts the <= 64 survivors
-// by (score desc, index asc).  The row (<= ~120 KB) is re-read from L2 on every pass; the kernel's
-// HBM traffic is one read of the score block.
+// by (score desc, index asc).  Rows of up to kMaxCachedCols scores are copied into LDS once (one 16-byte-per-lane sweep of the
+// score block: the kernel's only global read) and every later pass -- four histogram passes, the collection, the log-sum-exp --
+// runs out of LDS; longer rows are re-read from L2 on every pass.
 #include "common.h"
 #include <math.h>
 
@@ -20,6 +21,9 @@ __device__ __forceinline__ unsigned ord_key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+constexpr int kMaxCachedCols = 38 * 1024;  // 152 KB of the CU's 160 KB LDS (the rest: histogram, candidates)
+
+template <bool CACHED>
 __global__ __launch_bounds__(kThreads) void topk_rows_kernel(const float* __restrict__ scores, int64_t ld, int ncols,
                                                             int k, float* __restrict__ top_val,
                                                             int64_t* __restrict__ top_idx,
@@ -32,8 +36,17 @@ __global__ __launch_bounds__(kThreads) void topk_rows_kernel(const float* __rest
     __shared__ unsigned long long cand[64];
     __shared__ float red[kThreads / MR_WAVE];
 
+    extern __shared__ __attribute__((aligned(16))) float row_cache[];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* __restrict__ s = scores + (int64_t)row * ld;
+    const float* __restrict__ g = scores + (int64_t)row * ld;
+    if (CACHED) {  // ld % 4 == 0 and a 16-byte aligned block are checked by the host for this variant
+        const int nv = ncols >> 2;
+        for (int v = tid; v < nv; v += kThreads) reinterpret_cast<float4*>(row_cache)[v] = reinterpret_cast<const float4*>(g)[v];
+        for (int i = (nv << 2) + tid; i < ncols; i += kThreads) row_cache[i] = g[i];
+        __syncthreads();
+    }
+    // `s[i]` below: LDS when cached (the address-space-3 array), global otherwise
+#define s (CACHED ? row_cache : g)
 
     if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)k; s_ngt = 0u; }
     if (tid < 64) cand[tid] = 0ull;
@@ -160,6 +173,7 @@ __global__ __launch_bounds__(kThreads) void topk_rows_kernel(const float* __rest
             }
         }
     }
+#undef s
 }
 
 }  // namespace
@@ -171,8 +185,20 @@ extern "C" int mr_topk_rows_f32(const float* scores, int64_t ld, int nrows, int 
     if (k > 64 || k > ncols) return MR_EUNSUPPORTED;
     if (ld < ncols) return MR_EINVAL;
     if (nrows == 0) return MR_OK;
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(nrows), dim3(kThreads), 0, (hipStream_t)stream, scores, ld, ncols, k, top_val,
-                       top_idx, labels, inv_temp, row_lse, row_lab, label_rank);
+    const bool cached = ncols <= kMaxCachedCols && (ld & 3) == 0 && mr::aligned16(scores);
+    if (cached) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kMaxCachedCols * (int)sizeof(float));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(topk_rows_kernel<true>, dim3(nrows), dim3(kThreads), (size_t)((ncols + 3) & ~3) * sizeof(float), (hipStream_t)stream,
+                           scores, ld, ncols, k, top_val, top_idx, labels, inv_temp, row_lse, row_lab, label_rank);
+    } else {
+        hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(nrows), dim3(kThreads), 0, (hipStream_t)stream, scores, ld, ncols, k, top_val,
+                           top_idx, labels, inv_temp, row_lse, row_lab, label_rank);
+    }
     return mr::check_launch();
 }
 

@@ -216,7 +216,7 @@ class WeightSet:
                 ent = [(self.layout.offsets[k], shp[0], shp[1]) for k, shp in self.layout.shapes.items()
                        if len(shp) == 2 and "embeddings" not in k and shp[1] % 16 == 0]
                 self._table = ops.KBlockTable(ent, self.flat.device)
-            self.pieces = ops.split_weights_kblock(self.flat, self._table, self.pieces)
+            self.pieces = ops.split_weights_kblock(self.flat, self._table, self.pieces, n_pieces=3 if self.mode == "bf16x6" else 2)
         return self
 
     @staticmethod

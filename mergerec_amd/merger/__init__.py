@@ -1,4 +1,5 @@
 from .enums import LearnType, LossType, MergeType
+from .merger import ModelMerger
 from .weight_learning import (
     TaskVectorMergingModuleBase,
     TaskVectorMergingModuleLayerWise,
@@ -7,6 +8,6 @@ from .weight_learning import (
 )
 
 __all__ = [
-    "MergeType", "LearnType", "LossType", "load_merging_module", "TaskVectorMergingModuleBase",
+    "MergeType", "LearnType", "LossType", "ModelMerger", "load_merging_module", "TaskVectorMergingModuleBase",
     "TaskVectorMergingModuleTaskWise", "TaskVectorMergingModuleLayerWise",
 ]

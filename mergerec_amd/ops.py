@@ -121,6 +121,23 @@ def merge_nway(
     return out
 
 
+def merge_running(base: Optional[torch.Tensor], models: torch.Tensor, weights: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ModelMerger.merge's running sums: base given -> "task_vector" (base + w_0 (m_0 - base) + ...), base None -> "linear"."""
+    _dev(models, "models", torch.float32), _dev(weights, "weights", torch.float32)
+    if models.dim() != 2 or weights.numel() != models.shape[0]:
+        raise ValueError("models must be (N, P) with one weight per row")
+    N, P = models.shape
+    if base is not None:
+        _dev(base, "base", torch.float32)
+        if base.numel() != P:
+            raise ValueError("base / models size mismatch")
+    out = torch.empty(P, dtype=torch.float32, device=models.device) if out is None else _dev(out, "out", torch.float32)
+    ev = PROF.begin(models.device)
+    check(_lib.load().mr_merge_running_f32(ptr(base), ptr(models), models.stride(0), ptr(weights), N, P, ptr(out), _stream(models)), "mr_merge_running_f32")
+    PROF.end(ev, models.device, "merge_running", nbytes=(N + (2 if base is not None else 1)) * P * 4)
+    return out
+
+
 def merge_bwd_alpha(tv: torch.Tensor, g: torch.Tensor, seg_off: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(tv, "tv", torch.float32), _dev(g, "g", torch.float32)
     N, P = tv.shape
@@ -312,15 +329,16 @@ class KBlockTable:
         self.bytes = sum(n * k for _, n, k in ent) * 10.0  # 4 B read + 3 x 2 B written per element
 
 
-def split_weights_kblock(flat: torch.Tensor, table: KBlockTable, pieces=None):
-    """fp32 arena -> three bf16 piece arenas (same length) holding the listed matrices in k-blocked form."""
+def split_weights_kblock(flat: torch.Tensor, table: KBlockTable, pieces=None, n_pieces: int = 3):
+    """fp32 arena -> bf16 piece arenas (same length) holding the listed matrices in k-blocked form.  n_pieces = 2: only (hi, mid)
+    are produced -- all that the three-product GEMMs read -- and the returned tuple's third entry is None."""
     _dev(flat, "flat", torch.float32)
-    if pieces is None:
-        pieces = tuple(torch.zeros(flat.numel(), dtype=torch.bfloat16, device=flat.device) for _ in range(3))
+    if pieces is None or sum(p is not None for p in pieces) != n_pieces:
+        pieces = tuple(torch.zeros(flat.numel(), dtype=torch.bfloat16, device=flat.device) if i < n_pieces else None for i in range(3))
     ev = PROF.begin(flat.device)
     check(_lib.load().mr_split_weights_kblock_f32(ptr(flat), ptr(table.table), ptr(table.prefix), table.n_mat, table.total_units,
                                                   ptr(pieces[0]), ptr(pieces[1]), ptr(pieces[2]), _stream(flat)), "mr_split_weights_kblock_f32")
-    PROF.end(ev, flat.device, "split_weights", nbytes=table.bytes)
+    PROF.end(ev, flat.device, "split_weights", nbytes=table.bytes * (4 + 2 * n_pieces) / 10.0)
     return pieces
 
 
@@ -403,7 +421,10 @@ def gather_rows(x: torch.Tensor, row_idx: torch.Tensor, out=None) -> torch.Tenso
 
 # ------------------------------------------------------------------------------------------ scoring
 def topk_rows(scores: torch.Tensor, k: int, labels: Optional[torch.Tensor] = None, inv_temp: float = 1.0):
-    _dev(scores, "scores", torch.float32)
+    """``scores``: (R, C) fp32 with unit column stride (rows may be padded: a leading dimension that is a multiple of 4 on a 16-byte
+    aligned block lets the kernel keep each row in LDS)."""
+    if not (isinstance(scores, torch.Tensor) and scores.is_cuda and scores.dtype == torch.float32 and scores.dim() == 2 and scores.stride(1) == 1):
+        raise ValueError("scores must be a (R, C) fp32 GPU matrix with unit column stride (the HIP path has no CPU fallback)")
     R, C = scores.shape
     dev = scores.device
     val = torch.empty(R, k, dtype=torch.float32, device=dev)
@@ -438,9 +459,11 @@ def score_topk(U: torch.Tensor, E: torch.Tensor, k: int, labels: Optional[torch.
     if PROF.enabled:
         # profiling: the same two launches the fused entry point makes, timed separately (scoring GEMM on the fp32 matrix cores,
         # then the row select) -- identical results
-        sc = gemm_nt(U, [E], prof_name="score_gemm")
+        ldm = (M + 3) // 4 * 4  # the fused entry point's workspace layout
+        sc = torch.empty(nU, ldm, dtype=torch.float32, device=dev)[:, :M]
+        gemm_nt(U, [E], out=sc, prof_name="score_gemm")
         val, idx, lse, lab, rank = topk_rows(sc, k, labels, inv_temp)
-        return val, idx, lse, lab, rank, (sc if return_scores else None)
+        return val, idx, lse, lab, rank, (sc.contiguous() if return_scores else None)
     scores = ws = None
     nbytes = 0
     if return_scores:

@@ -96,6 +96,21 @@ def merge_task_wise(base: torch.Tensor, tv: torch.Tensor, alpha: torch.Tensor) -
     return base + (alpha.unsqueeze(1) * tv).sum(dim=0)
 
 
+def merge_running(base: Optional[torch.Tensor], models: Sequence[torch.Tensor], weights: Sequence[float]) -> torch.Tensor:
+    """ModelMerger.merge("task_vector") (merger/algorithms/task_vector.py:13-34: ``merged = base.clone(); merged += w_i * (m_i - base)``)
+    and ("linear") (algorithms/linear.py:8-27: ``merged = zeros; merged += w_i * m_i``) -- running sums in model order."""
+    assert len(models) == len(weights), "Number of models and weights should match."
+    if base is None:
+        merged = torch.zeros_like(models[0])
+        for w, m in zip(weights, models):
+            merged += w * m
+        return merged
+    merged = base.clone()
+    for w, m in zip(weights, models):
+        merged += w * (m - base)
+    return merged
+
+
 def group_parameters_by_layer(shape_dict) -> "OrderedDict[str, List[Tuple[str, int, int]]]":
     """layer_wise.py:13-33 -- group id = ``name.split('.')[3]`` when ``'encoder.layer.'`` is in the
     name, else ``'others'``; groups keep first-seen order."""

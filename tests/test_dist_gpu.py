@@ -76,3 +76,43 @@ def test_merge_test_cli_under_torch_distributed_run(tmp_path):
     assert pa.keys() == pb.keys() == {"Pantry", "Toys"}
     for k in pa:
         assert torch.equal(pa[k]["scores"], pb[k]["scores"]) and torch.equal(pa[k]["labels"], pb[k]["labels"])
+
+
+def test_merge_train_two_ranks_keep_identical_alpha(tmp_path):
+    """BASELINE configs[4]'s loop (collaborative-merging optimisation, pseudo-user batches data-parallel over the ranks) on a small
+    model: both ranks must end every step with the SAME alpha (one all-reduce of d loss / d alpha per step), the alpha must have moved,
+    and the test after training -- itself sharded over the two ranks -- must report what a single-process merge_test.py reports for
+    that alpha file."""
+    from tests.conftest import GOLDEN
+
+    data, tok = str(GOLDEN / "mini_dataset"), str(GOLDEN / "mini_tokenizer")
+    small = ["--model_type", "blair_base", "--model_kwargs", "init_seed", "7", "spec.hidden", "128", "spec.heads", "2", "spec.layers", "2",
+             "spec.intermediate", "256", "--tokenizer_path", tok, "--max_seq_len", "96", "--max_attribute_len", "12", "--max_items", "20",
+             "--batch_size", "8", "--finetune_checkpoint_paths", "synthetic:1", "synthetic:2", "--merge_type", "task_vector",
+             "--learn_type", "layer_wise"]
+    out = _run(["merge_train.py", *small, "--data_paths", data, data, "--item_embeddings_paths", "auto", "--sequence_embeddings_paths", "auto",
+                "--train_data_split", "item", "--test_data_split", "test", "--loss_type", "SINGLE_PSEUDO_LABEL_KD", "--coefficient", "1000",
+                "--learning_rate", "0.01", "--max_steps", "6", "--weights_dir", str(tmp_path / "w"), "--result_path", str(tmp_path / "res"),
+                "--metrics_path", str(tmp_path / "train_test.csv")], 2)
+    r0, r1 = (torch.load(f"{tmp_path}/res.rank{r}.pt", weights_only=False) for r in (0, 1))
+    assert r0["world_size"] == r1["world_size"] == 2 and len(r0["history"]) == len(r1["history"]) == 6
+    assert r0["weights"] == r1["weights"], "alpha diverged between the ranks"
+    per = r0["weights"]["per_weights"]
+    assert set(per) == {"0", "1", "others"} and any(abs(a - 0.2) > 1e-4 for v in per.values() for a in v)
+    assert r0["history"] != r1["history"]  # the ranks really trained on different shards
+    assert r0["test_metrics"] == r1["test_metrics"] and "Test metrics after training" in out
+    # the alpha file the run logged, evaluated by a single process: same merged model, same metrics as the sharded test after training
+    wfile = r0["weights_file"]
+    assert wfile and Path(wfile).exists()
+    last = len(Path(wfile).read_text().strip().splitlines()) - 1
+    _run(["merge_test.py", *small, "--data_paths", data, data, "--weight_file", wfile, "--weight_file_line", str(last),
+          "--metrics_path", str(tmp_path / "single.csv")], 1)
+    import csv
+
+    a = list(csv.DictReader(open(tmp_path / "train_test.csv")))
+    b = list(csv.DictReader(open(tmp_path / "single.csv")))
+    logged = eval(Path(wfile).read_text().strip().splitlines()[last], {"__builtins__": {}})["weights"]  # noqa: S307 - our own file
+    if logged == r0["weights"]:  # the last logged step is the final alpha (log_every_steps divides max_steps): metrics must agree exactly
+        assert a == b
+    else:
+        assert [r["dataset"] for r in a] == [r["dataset"] for r in b]

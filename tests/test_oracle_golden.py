@@ -84,6 +84,19 @@ def test_merge_matches_reference_bitwise():
         assert torch.allclose(cls, case["cls"], atol=2e-5, rtol=1e-5), (cls - case["cls"]).abs().max()
 
 
+def test_model_merger_fixed_weight_merges_match_reference_bitwise():
+    """ModelMerger.merge("task_vector" | "linear") of the reference (merger.py:46-93): running sums in model order"""
+    g2 = load_golden("g2_merger.pt")
+    pre = g2["pretrain"]
+    base, _ = O.flatten_model(pre)
+    models = [O.flatten_model(OrderedDict((k, ft[k]) for k in pre))[0] for ft in g2["finetunes"]]
+    assert torch.equal(O.merge_running(base, models, [0.5, 0.25, 0.7]), g2["model_merger_task_vector"])
+    assert torch.equal(O.merge_running(None, models, [0.2, 0.3, 0.5]), g2["model_merger_linear"])
+    # the learnable-alpha module sums the products first and adds the base last: same value, different rounding (SURVEY appendix A.4)
+    tw = O.merge_task_wise(base, O.get_task_vectors(base, models), torch.tensor([0.5, 0.25, 0.7]))
+    assert not torch.equal(tw, g2["model_merger_task_vector"]) and torch.allclose(tw, g2["model_merger_task_vector"], atol=1e-6)
+
+
 def test_flatten_promotes_int_buffer():
     g2 = load_golden("g2_merger.pt")
     sd = OrderedDict([("model.embeddings.position_ids", torch.arange(10).view(1, 10))] + list(g2["pretrain"].items()))

@@ -151,6 +151,39 @@ def test_load_merging_module_matches_reference_golden():
         assert torch.allclose(cls.cpu(), case["cls"], atol=1e-4, rtol=1e-5), (cls.cpu() - case["cls"]).abs().max()
 
 
+def test_model_merger_fixed_weight_merges_bit_exact():
+    """ModelMerger(models, base).merge("task_vector" | "linear", weights) == the reference's own ModelMerger output (golden g2), bit for bit;
+    argument checks as merger.py:46-93"""
+    from mergerec_amd.merger import ModelMerger
+
+    g2 = load_golden("g2_merger.pt")
+    pre = g2["pretrain"]
+    fts = [OrderedDict((k, ft[k]) for k in pre) for ft in g2["finetunes"]]
+    mg = ModelMerger(models=fts, base_model=pre, align_key_order=False, device=DEV)
+    flat = lambda sd: torch.cat([sd[k].reshape(-1) for k in pre]).cpu()
+    tv = mg.merge("task_vector", [0.5, 0.25, 0.7])
+    assert list(tv.keys()) == list(pre.keys()) and all(tv[k].shape == pre[k].shape for k in pre)
+    assert torch.equal(flat(tv), g2["model_merger_task_vector"])
+    assert torch.equal(flat(mg.merge("linear", [0.2, 0.3, 0.5])), g2["model_merger_linear"])
+    # a single float is broadcast; sorted key order when asked to align; shuffled dicts are aligned, not rejected
+    shuffled = [OrderedDict(reversed(list(ft.items()))) for ft in fts]
+    mg2 = ModelMerger(models=shuffled, base_model=pre, align_key_order=True, device=DEV)
+    assert list(mg2.shape_dict.keys()) == sorted(pre.keys())
+    got = mg2.merge("task_vector", 0.25)
+    want = O.merge_running(O.flatten_model(pre)[0], [O.flatten_model(ft)[0] for ft in fts], [0.25] * 3)
+    assert torch.equal(flat(got), want)
+    with pytest.raises(AssertionError, match="not aligned"):
+        ModelMerger(models=shuffled, base_model=pre, align_key_order=False, device=DEV)
+    with pytest.raises(ValueError, match="float or a list of floats"):
+        mg.merge("linear", [1, 2, 3])
+    with pytest.raises(ValueError, match="not supported"):
+        mg.merge("slerp", 0.5)
+    with pytest.raises(ValueError, match="requires a base model"):
+        ModelMerger(models=fts, device=DEV).merge("task_vector", 0.5)
+    head = ModelMerger(models=fts, device=DEV)  # no base: all models are merged (the reference keeps the first as the head of the list)
+    assert torch.equal(flat(head.merge("linear", [0.2, 0.3, 0.5])), g2["model_merger_linear"])
+
+
 def test_merging_module_errors_mirror_reference():
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
 
