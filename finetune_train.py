@@ -105,8 +105,15 @@ def main(argv=None):
 
     import random
 
-    random.seed(config.seed)  # L.seed_everything: python, numpy, torch
+    import numpy as np
+
+    # L.seed_everything (python, numpy, torch).  With several ranks the data-side streams (the collators' random prefix cuts and
+    # sampled negatives) are offset by the rank so the shards are not augmented identically; the shard assignment itself uses its own
+    # shared seed (parallel.shard_indices), and the model initialisation below is seeded identically everywhere.
+    random.seed(config.seed + rank)
+    np.random.seed(config.seed + rank)
     torch.manual_seed(config.seed)
+    print("note: the training graph has no dropout (the reference trains under HF's hidden / attention dropout 0.1); see DESIGN.md section 7")
     if not config.tokenizer_path:
         raise SystemExit("--tokenizer_path <local tokenizer directory> is required (the box is offline)")
     negative_sample = NegativeSampleConfig(k=config.negative_k, in_batch=config.negative_in_batch)

@@ -96,6 +96,9 @@ def main(argv=None):
     from mergerec_amd.utils import DistillTrainer, remove_duplicate_prefix, test_model
 
     torch.manual_seed(config.seed)
+    if rank == 0:
+        print("note: the training graph has no dropout (the reference optimises alpha under HF's hidden / attention dropout 0.1, "
+              "Lightning's train() mode); see DESIGN.md section 7")
     recformer = config.model_type.startswith("RECFORMER")
     if not config.tokenizer_path:
         raise SystemExit("--tokenizer_path <local tokenizer directory> is required (the box is offline)")

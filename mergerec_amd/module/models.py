@@ -66,6 +66,14 @@ class BaseEncoderModel(nn.Module):
         self.tokenizer = self._load_tokenizer(tokenizer_name_or_path, tokenizer_kwargs or {})
         ckpt_path = model_kwargs.pop("ckpt_path", None)  # Recformer (interface.py:38-41)
         init_seed = model_kwargs.pop("init_seed", None)
+        # HF config overrides the reference forwards to from_pretrained: dropout rates do not change inference; the training graph
+        # (merge_train / finetune_train) has no dropout at all -- say so instead of dropping the keys silently
+        for key in ("hidden_dropout_prob", "attention_probs_dropout_prob", "classifier_dropout"):
+            rate = model_kwargs.pop(key, None)
+            if rate:
+                print(f"note: model_kwargs {key}={rate} has no effect here: evaluation never applies dropout and the training graph is built without it")
+        if model_kwargs:
+            print(f"note: model_kwargs {sorted(model_kwargs)} are not used by the HIP encoder")
         src = ckpt_path or model_name_or_path
         if src is not None and os.path.isfile(str(src)):
             sd = torch.load(str(src), map_location="cpu")

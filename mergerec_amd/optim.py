@@ -42,8 +42,10 @@ class ArenaAdamW:
         # one segment per run of adjacent tensors with the same decay (arena offsets are multiples of 64 floats)
         starts, wds = [], []
         for name in layout.shapes:
-            # buffers the arena carries (Recformer's embeddings.position_ids) are not parameters: never decayed
-            wd = 0.0 if (any(nd in name for nd in no_decay) or name.endswith("position_ids")) else self.weight_decay
+            # buffers the arena carries (Recformer's embeddings.position_ids) are not parameters: never decayed.  Neither is the RoBERTa
+            # pooler: CLS pooling never reads it, so its .grad stays None in the reference and torch's AdamW skips it (decay included)
+            frozen = name.endswith("position_ids") or ".pooler." in name
+            wd = 0.0 if (frozen or any(nd in name for nd in no_decay)) else self.weight_decay
             if not wds or wds[-1] != wd:
                 starts.append(layout.offsets[name])
                 wds.append(wd)

@@ -288,14 +288,23 @@ def allreduce_mean_grads(params, group=None) -> None:
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
+    ws = dist.get_world_size(group)
+    staged = dist.get_backend(group) == "gloo" and grads[0].is_cuda
+
+    def reduce_(t):
+        if staged:
+            host = t.cpu()
+            dist.all_reduce(host, group=group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, group=group)
+        t /= ws
+
+    if len(grads) == 1 and grads[0].is_contiguous():  # the fine-tuning arena: one contiguous gradient, reduced in place
+        reduce_(grads[0].view(-1))
+        return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    if dist.get_backend(group) == "gloo" and flat.is_cuda:
-        host = flat.cpu()
-        dist.all_reduce(host, group=group)
-        flat = host.to(flat.device)
-    else:
-        dist.all_reduce(flat, group=group)
-    flat /= dist.get_world_size(group)
+    reduce_(flat)
     off = 0
     for g in grads:
         g.copy_(flat[off:off + g.numel()].view_as(g))

@@ -209,9 +209,9 @@ class DistillTrainer:
                 allreduce_mean_grads(trainable)  # data parallel: the only exchange of the step (no-op on one rank)
                 opt.step()
                 self.global_step += 1
-                self.history.append(float(loss.detach()))
+                self.history.append(loss.detach())  # stays on the device: no host sync per step unless this step is logged
                 if self.verbose and self.global_step % self.log_every_n_steps == 0:
-                    print(f"step {self.global_step}: train/loss {self.history[-1]:.6f}")
+                    print(f"step {self.global_step}: train/loss {float(self.history[-1]):.6f}")
                 self._hook("on_train_batch_end", module, loss, batch, batch_idx)
                 if self.max_steps is not None and self.max_steps >= 0 and self.global_step >= self.max_steps:
                     done = True
@@ -235,6 +235,7 @@ class DistillTrainer:
             if self.max_epochs is not None and self.current_epoch >= self.max_epochs:
                 done = True
         self._hook("teardown", module, "fit")
+        self.history = [float(x) for x in self.history]
         return self.history
 
 
