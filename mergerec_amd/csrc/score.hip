@@ -56,10 +56,23 @@ __global__ __launch_bounds__(kThreads) void topk_rows_kernel(const float* __rest
         hist[tid] = 0u;
         __syncthreads();
         const unsigned prefix = s_prefix;
+        // run-length pre-aggregation per thread: cosine scores share sign, exponent and the top mantissa bits, so in the first passes
+        // (nearly) every element falls into ONE bucket -- one LDS atomic per run instead of one per element keeps that from serialising
+        unsigned run_b = 0xffffffffu, run_n = 0u;
         for (int i = tid; i < ncols; i += kThreads) {
             const unsigned key = ord_key(s[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
+            if ((key & mask) == prefix) {
+                const unsigned bk = (key >> shift) & 0xffu;
+                if (bk == run_b) {
+                    ++run_n;
+                } else {
+                    if (run_n) atomicAdd(&hist[run_b], run_n);
+                    run_b = bk;
+                    run_n = 1u;
+                }
+            }
         }
+        if (run_n) atomicAdd(&hist[run_b], run_n);
         __syncthreads();
         if (tid == 0) {
             unsigned rem = s_remaining, c = 0u;
