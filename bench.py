@@ -153,13 +153,17 @@ def synth_state_dicts(model, n_dom, device, seed=1001):
 
 
 def main():
-    # rank 0 prints ONE JSON line on stdout: the product objects' progress prints ("Calculating task vectors...") go to stderr
-    real_stdout = sys.stdout
-    sys.stdout = sys.stderr
+    # rank 0 prints ONE JSON line on stdout: everything else that writes to file descriptor 1 while the bench runs -- the product
+    # objects' progress prints ("Calculating task vectors..."), gloo's connection banner from C++ -- is sent to stderr instead
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    real_stdout = os.fdopen(saved_fd, "w")
     try:
         _main(real_stdout)
     finally:
-        sys.stdout = real_stdout
+        sys.stdout.flush()
+        real_stdout.flush()
 
 
 def _main(real_stdout):

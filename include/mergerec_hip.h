@@ -253,6 +253,7 @@ int mr_attn_global_row_f32(const float* qg, const float* kvg, const int32_t* cu_
                            float* ctx, int compact, mr_stream_t stream);
 
 /* out[b,:] = x[cu_seqlens[b], :]  (CLS pooling), then if normalize: out / max(||out||_2, 1e-12).
+ * cu_seqlens == NULL: out[b,:] = x[b,:] (rows already one per sequence: the CLS-only last layer).
  * replaces: module/models/encoder/_base.py:44-45 (pool 'cls') + module/recommender/module.py:74-77. */
 int mr_cls_pool_normalize_f32(const float* x, int64_t ldx, const int32_t* cu_seqlens, int B, int d, int normalize,
                               float* out, mr_stream_t stream);

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void cls_pool_kernel(const float* __restr
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (b >= B) return;
-    const float* r = xin + (int64_t)cu[b] * ldx;
+    const float* r = xin + (int64_t)(cu ? cu[b] : b) * ldx;  // cu == NULL: row b (the rows are already one per sequence)
     float4 x[NV];
     float s = 0.f;
 #pragma unroll
@@ -319,7 +319,7 @@ extern "C" int mr_layernorm_f32(const float* x, int64_t ldx, const float* gamma,
 
 extern "C" int mr_cls_pool_normalize_f32(const float* x, int64_t ldx, const int32_t* cu_seqlens, int B, int d,
                                          int normalize, float* out, mr_stream_t stream) {
-    if (!x || !cu_seqlens || !out || B < 0 || d <= 0) return MR_EINVAL;
+    if (!x || !out || B < 0 || d <= 0) return MR_EINVAL;
     if ((d & 3) || d > 2048) return MR_EUNSUPPORTED;
     if ((ldx & 3) || !mr::aligned16(x) || !mr::aligned16(out)) return MR_EALIGN;
     if (B == 0) return MR_OK;

@@ -412,8 +412,7 @@ class EncoderRunner:
             out = ops.cls_pool_normalize(x, pb.cu_seqlens, pb.B, normalize)
             return (out, hidden) if return_hidden else out
         # x already holds one row per sequence
-        ident = torch.arange(pb.B + 1, dtype=torch.int32, device=x.device)
-        return ops.cls_pool_normalize(x, ident, pb.B, normalize)
+        return ops.cls_pool_normalize(x, None, pb.B, normalize)
 
     def encode(self, w: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], device, normalize: bool, lens=None, validate: bool = True):
         return self.forward_packed(w, self.pack(batch, device, lens=lens, validate=validate), normalize)

@@ -7,8 +7,9 @@ teacher rows ``S_ds[sequence_id]`` gathered on the device, and ONE fused loss la
 losses and d loss / d logits; the batch loss is the mean over all samples, as in module.py:72.
 
 The whole chain is on the device: loss value, d loss / d logits, d loss / d representations here; representations -> merged
-parameters through ``engine_train.RobertaTrainGraph`` (BLaIR / RoBERTa; Recformer's windowed attention backward is not built) and
-merged parameters -> alpha through ``mr_merge_bwd_alpha_f32``."""
+parameters through ``engine_train.EncoderTrainGraph`` (BLaIR / RoBERTa and Recformer / Longformer) and merged parameters -> alpha
+through ``mr_merge_bwd_alpha_f32``.  (Row normalisation of the teacher embeddings and the index gathers of the per-sample bookkeeping are
+plain torch ops: a few (rows, d) tensors per step.)"""
 from __future__ import annotations
 
 from typing import List, Literal, Optional, Sequence

@@ -85,8 +85,7 @@ class RecModule(_Base):
             return self.model.encode_normalized(batch, normalize=self.similarity == "cosine")
         out = self.model.forward(batch)  # e.g. a TaskVectorMergingModule (re-merges, then encodes)
         if self.similarity == "cosine":
-            ident = torch.arange(out.shape[0] + 1, dtype=torch.int32, device=out.device)
-            out = ops.cls_pool_normalize(out.contiguous(), ident, out.shape[0], True)
+            out = ops.cls_pool_normalize(out.contiguous(), None, out.shape[0], True)
         return out
 
     def _forward_all_negative(self, batch, labels: torch.Tensor):
