@@ -7,7 +7,9 @@ g12 real-scale domain are compared with an all-float64 run.
   bf16x3   : x = hi + lo (bf16 pieces), hi*hi + hi*lo + lo*hi                       (the library's three-product arithmetic)
   f16i8    : x = fp16(x) + xl;  fp16*fp16  +  int8(x)*int8(wl) + int8(xl)*int8(w)   per-row scales over the whole K, xl / wl scale = 2^-11 of it
   f16i8c256: the same with scales per (row, 256-wide K chunk)
-Usage: python tests/tools/split_scheme_study.py [n_users] [n_items]"""
+  f16mx8   : the same split with the cross-term operands in MX-fp8: e4m3 elements, one power-of-two scale per (row, 32 k) block
+             (what v_mfma_scale_f32_32x32x64_f8f6f4 applies in hardware, so ONE f32 accumulator serves all three products)
+Usage: python tests/tools/split_scheme_study.py [n_users] [n_items] [modes...]"""
 import sys
 from collections import OrderedDict
 from pathlib import Path
@@ -34,6 +36,18 @@ def _i8(t, scale):
     return torch.clamp(torch.round(t / scale), -127, 127)
 
 
+def _mx8(t):
+    """MX-fp8 round trip: blocks of 32 along the last dim share a power-of-two scale chosen so the block maximum lands in e4m3's top
+    binade (<= 448); elements are rounded to e4m3 (torch.float8_e4m3fn, round-to-nearest-even, saturating)."""
+    shp = t.shape
+    b = t.reshape(*shp[:-1], shp[-1] // 32, 32)
+    amax = b.abs().amax(-1, keepdim=True).clamp_min(1e-38)
+    e = torch.floor(torch.log2(amax)) - 8.0          # e4m3 max 448 = 1.75 * 2^8: block max maps into [2^8, 2^9)
+    scale = torch.exp2(e)
+    q = (b / scale).clamp(-448, 448).to(torch.float8_e4m3fn).to(torch.float32)
+    return (q * scale).reshape(shp)
+
+
 def make_linear(mode):
     def linear(x, w, b=None):
         shp = x.shape
@@ -45,6 +59,10 @@ def make_linear(mode):
             xh, xl = _bf16_split(x2)
             wh, wl = _bf16_split(w2)
             y = xh @ wh.T + xh @ wl.T + xl @ wh.T
+        elif mode == "f16mx8":
+            xh = x2.to(torch.float16).float(); xl = x2 - xh
+            wh = w2.to(torch.float16).float(); wl = w2 - wh
+            y = xh.double() @ wh.double().T + _mx8(x2).double() @ _mx8(wl).double().T + _mx8(xl).double() @ _mx8(w2).double().T
         else:
             chunk = 256 if mode.endswith("c256") else x2.shape[1]
             xh = x2.to(torch.float16).float(); xl = x2 - xh
@@ -80,7 +98,8 @@ def main():
     ub = [b.sequence for b in dom.sequence_batches[: (n_users + 31) // 32]]
     ib = [b.items for b in dom.item_batches[: (n_items + 31) // 32]]
     res = {}
-    for mode in ("f64", "bf16x3", "f16i8", "f16i8c256"):
+    modes = sys.argv[3:] or ["bf16x3", "f16i8", "f16i8c256", "f16mx8"]
+    for mode in ["f64"] + modes:
         O.F.linear = make_linear(mode)
         try:
             with torch.no_grad():
