@@ -116,3 +116,10 @@ def test_merge_train_two_ranks_keep_identical_alpha(tmp_path):
         assert a == b
     else:
         assert [r["dataset"] for r in a] == [r["dataset"] for r in b]
+
+
+def test_rccl_initialises_and_accepts_the_products_collectives():
+    """backend "nccl" (= RCCL) with one rank on the one GPU: process-group creation as parallel.init_from_env does it, and every collective
+    call shape / dtype of the product path (tests/tools/nccl_single_rank.py)."""
+    out = _run([str(ROOT / "tests" / "tools" / "nccl_single_rank.py"), str(_port())], 1, timeout=300)
+    assert out.strip().endswith("OK")
