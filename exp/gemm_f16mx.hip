@@ -108,6 +108,8 @@ __device__ __forceinline__ float amax16(const float4 v0, const float4 v1, const 
 // W (N, K) fp32 row-major -> per (k-block of 32, tile of 256 rows): wh [4 planes][256][16 B] fp16, wm [4 planes][256][16 B] (plane 2 h + 0: wl8 of
 // k 16 h .. 16 h + 15 = block 0, which meets the activations' x8; plane 2 h + 1: w8 of the same k = block 1, which meets their xl8),
 // wsc [2][256] bytes (half h: scale of block h).  One thread per (k-block, row, half): 16 elements.  N % 256 == 0.
+// ACTS: the same images for an ACTIVATION matrix (rows = tokens): block 0 = x8 (scale s), block 1 = xl8 (scale s 2^-11).
+template <bool ACTS>
 __global__ __launch_bounds__(256) void split_weights_mx_kernel(const float* __restrict__ W, int N, int K, uint8_t* __restrict__ wh, uint8_t* __restrict__ wm,
                                                               uint8_t* __restrict__ wsc) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -130,9 +132,9 @@ __global__ __launch_bounds__(256) void split_weights_mx_kernel(const float* __re
     *reinterpret_cast<uint4*>(th + (h) * 4096) = h0;       // unit 2 h     -> plane h
     *reinterpret_cast<uint4*>(th + (2 + h) * 4096) = h1;   // unit 2 h + 1 -> plane 2 + h
     uint8_t* tm = wm + tile * WTILE + r * 16;
-    *reinterpret_cast<uint4*>(tm + (2 * h) * 4096) = ql;     // block 0: residual image
-    *reinterpret_cast<uint4*>(tm + (2 * h + 1) * 4096) = q;  // block 1: 8-bit image of w
-    wsc[tile * 512 + h * 256 + r] = (uint8_t)(h == 0 ? bl : bs);
+    *reinterpret_cast<uint4*>(tm + (2 * h) * 4096) = ACTS ? q : ql;      // block 0: weights: residual image; activations: 8-bit image
+    *reinterpret_cast<uint4*>(tm + (2 * h + 1) * 4096) = ACTS ? ql : q;  // block 1: weights: 8-bit image; activations: residual image
+    wsc[tile * 512 + h * 256 + r] = (uint8_t)((h == 0) == ACTS ? bs : bl);
 }
 
 __device__ unsigned long long g_clk[4096 * 4];
@@ -141,13 +143,19 @@ __device__ unsigned long long g_ph[1024 * 8 * 6];
 template <int ACT, bool HAS_R>
 __global__ __launch_bounds__(NTHR, 1) void gemm_f16mx_kernel(const float* __restrict__ A, int64_t lda, const uint8_t* __restrict__ wh, const uint8_t* __restrict__ wm,
                                                             const uint8_t* __restrict__ wsc, const float* __restrict__ bias, int M, int N, int K,
-                                                            const float* __restrict__ R, int64_t ldr, float* __restrict__ C, int64_t ldc, int tiles_n, int nwg) {
+                                                            const float* __restrict__ R, int64_t ldr, float* __restrict__ C, int64_t ldc, int tiles_n, int nwg,
+                                                            const uint8_t* __restrict__ ah, const uint8_t* __restrict__ am, const uint8_t* __restrict__ asc, int tiles_m, int group_n) {
 #ifdef MX_CLOCK
     const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int pid = xcd_remap(blockIdx.x, nwg);
-    const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
+    // column-group-major tile order: all row tiles of the first group_n column tiles, then the next group -- the group's weight images
+    // (group_n x 0.75 MB at K = 768) stay in the XCD's L2 while the activation panels stream past once per group
+    const int per_group = tiles_m * group_n;
+    const int ng = pid / per_group, rem_ = pid - ng * per_group;
+    const int gw = (tiles_n - ng * group_n) < group_n ? (tiles_n - ng * group_n) : group_n;
+    const int tm = rem_ / gw, tn = ng * group_n + (rem_ - tm * gw);
     const int m0 = tm * TM, n0 = tn * TN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,6 +209,27 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_f16mx_kernel(const float* __rest
         MX_GLDS(pm_ + dg0, b_ + OFF_BM + dl0, 16);                                           \
         MX_GLDS(pm_ + dg1, b_ + OFF_BM + dl1, 16);                                           \
         MX_GLDS(cbase + (int64_t)(kt_) * sblk + dgs, b_ + OFF_BS + dls, 4);                   \
+    } while (0)
+#endif
+    // -DMX_APRESPLIT: the activations arrive as images too (their producers would write them) and take the same DMA path; no staging registers,
+    // no split, no LDS stores
+    const int64_t ablk = (int64_t)tiles_m * WTILE, asblk = (int64_t)tiles_m * 512;
+    const uint8_t* ahbase = ah + (int64_t)tm * WTILE;
+    const uint8_t* ambase = am + (int64_t)tm * WTILE;
+    const uint8_t* acbase = asc + (int64_t)tm * 512;
+#ifdef MX_ABL_NODMA
+#define MX_DMA_A(buf_, kt_) do { } while (0)
+#else
+#define MX_DMA_A(buf_, kt_)                                                                  \
+    do {                                                                                     \
+        unsigned char* b_ = (buf_);                                                          \
+        const uint8_t* ph_ = ahbase + (int64_t)(kt_) * ablk;                                  \
+        const uint8_t* pm_ = ambase + (int64_t)(kt_) * ablk;                                  \
+        MX_GLDS(ph_ + dg0, b_ + OFF_AH + dl0, 16);                                           \
+        MX_GLDS(ph_ + dg1, b_ + OFF_AH + dl1, 16);                                           \
+        MX_GLDS(pm_ + dg0, b_ + OFF_AM + dl0, 16);                                           \
+        MX_GLDS(pm_ + dg1, b_ + OFF_AM + dl1, 16);                                           \
+        MX_GLDS(acbase + (int64_t)(kt_) * asblk + dgs, b_ + OFF_AS + dls, 4);                 \
     } while (0)
 #endif
 #ifdef MX_ABL_NOALOAD
@@ -392,7 +421,32 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_f16mx_kernel(const float* __rest
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
-#ifndef MX_PINGPONG
+#ifdef MX_APRESPLIT
+    (void)role;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // (the prologue above filled buf0's activation images through the split path: overwrite them consistently)
+    MX_DMA_A(buf0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        const int k2 = kt + 2 < nk ? kt + 2 : 0;
+        MX_DMA_A(buf1, kt + 1);
+        MX_DMA_B(buf1, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        MX_COMPUTE(buf0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        MX_DMA_A(buf0, k2);
+        MX_DMA_B(buf0, k2);
+        __builtin_amdgcn_sched_barrier(0);
+        MX_COMPUTE(buf1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#elif !defined(MX_PINGPONG)
     (void)role;
     for (int kt = 0; kt < nk; kt += 2) {   // past-the-end prefetches re-read stage 0 and are never consumed
         const int k2 = kt + 2 < nk ? kt + 2 : 0, k3 = kt + 3 < nk ? kt + 3 : 0;
@@ -517,7 +571,18 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dR, hR.data(), hR.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemset(dC, 0xff, (size_t)M * N * 4));
-        hipLaunchKernelGGL(split_weights_mx_kernel, dim3((unsigned)(((int64_t)(K / 32) * N * 2 + 255) / 256)), dim3(256), 0, 0, dW, N, K, wh, wm, wsc);
+        hipLaunchKernelGGL(split_weights_mx_kernel<false>, dim3((unsigned)(((int64_t)(K / 32) * N * 2 + 255) / 256)), dim3(256), 0, 0, dW, N, K, wh, wm, wsc);
+        uint8_t *ah = nullptr, *am = nullptr, *asc = nullptr;
+#ifdef MX_APRESPLIT
+        if (M % 256) { printf("MX_APRESPLIT needs M %% 256 == 0\n"); return 1; }
+        CK(hipMalloc(&ah, hA.size() * 2)); CK(hipMalloc(&am, hA.size() * 2)); CK(hipMalloc(&asc, (size_t)(K / 32) * M * 2));
+        hipEvent_t q0, q1; CK(hipEventCreate(&q0)); CK(hipEventCreate(&q1));
+        CK(hipEventRecord(q0, 0));
+        hipLaunchKernelGGL(split_weights_mx_kernel<true>, dim3((unsigned)(((int64_t)(K / 32) * M * 2 + 255) / 256)), dim3(256), 0, 0, dA, M, K, ah, am, asc);
+        CK(hipEventRecord(q1, 0)); CK(hipEventSynchronize(q1));
+        float qms; CK(hipEventElapsedTime(&qms, q0, q1));
+        printf("      (activation images by a separate pass: %.3f ms)\n", qms);
+#endif
         CK(hipGetLastError());
         {
             int64_t tab[3] = {0, N, K}, pref[2] = {0, (int64_t)N * K / 4};
@@ -531,13 +596,15 @@ int main(int argc, char** argv) {
         }
         if ((K / BK) % 2 || N % TN) { printf("shape not supported\n"); return 1; }
         const int tiles_m = (M + TM - 1) / TM, tiles_n = N / TN, nwg = tiles_m * tiles_n;
+        const int group_arg = argc > 4 ? atoi(argv[4]) : 0;
+        const int group_n = group_arg > 0 && group_arg < tiles_n ? group_arg : tiles_n;
         auto launch = [&] {
             if (sh.act == 1)
-                hipLaunchKernelGGL((gemm_f16mx_kernel<1, false>), dim3(nwg), dim3(NTHR), LDS_BYTES, 0, dA, (int64_t)K, wh, wm, wsc, db, M, N, K, nullptr, 0, dC, (int64_t)N, tiles_n, nwg);
+                hipLaunchKernelGGL((gemm_f16mx_kernel<1, false>), dim3(nwg), dim3(NTHR), LDS_BYTES, 0, dA, (int64_t)K, wh, wm, wsc, db, M, N, K, nullptr, 0, dC, (int64_t)N, tiles_n, nwg, ah, am, asc, tiles_m, group_n);
             else if (sh.res)
-                hipLaunchKernelGGL((gemm_f16mx_kernel<0, true>), dim3(nwg), dim3(NTHR), LDS_BYTES, 0, dA, (int64_t)K, wh, wm, wsc, db, M, N, K, dR, (int64_t)N, dC, (int64_t)N, tiles_n, nwg);
+                hipLaunchKernelGGL((gemm_f16mx_kernel<0, true>), dim3(nwg), dim3(NTHR), LDS_BYTES, 0, dA, (int64_t)K, wh, wm, wsc, db, M, N, K, dR, (int64_t)N, dC, (int64_t)N, tiles_n, nwg, ah, am, asc, tiles_m, group_n);
             else
-                hipLaunchKernelGGL((gemm_f16mx_kernel<0, false>), dim3(nwg), dim3(NTHR), LDS_BYTES, 0, dA, (int64_t)K, wh, wm, wsc, db, M, N, K, nullptr, 0, dC, (int64_t)N, tiles_n, nwg);
+                hipLaunchKernelGGL((gemm_f16mx_kernel<0, false>), dim3(nwg), dim3(NTHR), LDS_BYTES, 0, dA, (int64_t)K, wh, wm, wsc, db, M, N, K, nullptr, 0, dC, (int64_t)N, tiles_n, nwg, ah, am, asc, tiles_m, group_n);
         };
         auto launch_lib = [&](int products, float* out) {
             int rc = mr_gemm_nt_bf16x6_f32(dA, K, lwh, lwm, lwl, 0, 0, 0, db, nullptr, nullptr, 1, M, N, K, sh.act, sh.res ? dR : nullptr, N, out, N, products, 0);
@@ -587,7 +654,7 @@ int main(int argc, char** argv) {
         }
         std::sort(ts.begin(), ts.end()); std::sort(tl.begin(), tl.end());
         const double fl = 2.0 * M * N * K;
-        printf("f16mx %-5s M=%d N=%d K=%d: %.3f ms %.1f TFLOP/s alg (best %.1f) | library bf16x3 %.3f ms %.1f TFLOP/s | speedup %.2fx\n", sh.name, M, N, K,
+        printf("f16mx %-5s (group_n %d) M=%d N=%d K=%d: %.3f ms %.1f TFLOP/s alg (best %.1f) | library bf16x3 %.3f ms %.1f TFLOP/s | speedup %.2fx\n", sh.name, group_n, M, N, K,
                ts[ts.size() / 2], fl / ts[ts.size() / 2] / 1e9, fl / ts[0] / 1e9, tl[tl.size() / 2], fl / tl[tl.size() / 2] / 1e9, tl[tl.size() / 2] / ts[ts.size() / 2]);
         printf("      vs library bf16x6: max abs diff %.3g, rel rms %.3g (bf16x3: %.3g, %.3g); elements off by > 1e-2: %zu; vs fp64 on sampled rows: max abs %.3g (bf16x3 %.3g)\n",
                worst, sqrt(sq / sref), worst3, sqrt(sq3 / sref), nbad, w64, w64_3);
