@@ -280,9 +280,18 @@ int mr_topk_rows_f32(const float* scores, int64_t ld, int nrows, int ncols, int 
                      mr_stream_t stream);
 
 /* Full-catalog scoring + top-k in one call: scores = U E^T (U: (nU, d), E: (M, d), both row-major),
- * then mr_topk_rows_f32 semantics.  If scores_out == NULL the (nU, M) block lives in `ws`.
+ * then mr_topk_rows_f32 semantics.  scores_out != NULL: the (nU, M) block is written there (predictions were asked for).
+ * scores_out == NULL, two routes with the same indices, values, label ranks and label logits (the log-sum-exp agrees to rounding):
+ *   fused   -- the block is never materialised: every workgroup scores 32 users against one 768-item part of the catalog into LDS and
+ *              selects the part's top-k there; a second launch merges the parts' candidate lists (k <= 64, d % 32 == 0, M <= 393,216);
+ *   staged  -- the scoring GEMM into `ws`, then mr_topk_rows_f32.
+ * mr_score_fused_mode(2) (default, or MR_SCORE_FUSED): fused when the block would exceed 128 MB, i.e. could not stay in the Infinity Cache
+ * between its writes and its reads; 1: always fused; 0: never.  Returns the previous mode; a negative argument only queries.
+ * `ws`: mr_score_topk_ws_bytes_ex bytes for the call's shape under the current mode (mr_score_topk_ws_bytes: an upper bound over d, k, modes).
  * replaces: module/recommender/module.py:133-139 + evaluator/evaluator.py:43. */
 size_t mr_score_topk_ws_bytes(int64_t nU, int64_t M);
+size_t mr_score_topk_ws_bytes_ex(int64_t nU, int64_t M, int d, int k);
+int mr_score_fused_mode(int mode);
 int mr_score_topk_f32(const float* U, const float* E, int64_t nU, int64_t M, int d, int k, float* top_val,
                       int64_t* top_idx, float* scores_out, const int64_t* labels, float inv_temp, float* row_lse,
                       float* row_lab, int32_t* label_rank, void* ws, size_t ws_bytes, mr_stream_t stream);

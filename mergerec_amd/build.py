@@ -16,9 +16,10 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "lib" / "obj"
 LIB = HERE / "lib" / "libmergerec_hip.so"
-SOURCES = ["capi.hip", "merge.hip", "embed.hip", "gemm.hip", "gemm_bf16.hip", "attn.hip", "attn_bf16.hip", "score.hip", "select.hip", "distill.hip", "backward.hip", "attn_bwd.hip", "optim.hip"]
+SOURCES = ["capi.hip", "merge.hip", "embed.hip", "gemm.hip", "gemm_bf16.hip", "attn.hip", "attn_bf16.hip", "score.hip", "score_fused.hip", "select.hip", "distill.hip", "backward.hip", "attn_bwd.hip", "optim.hip"]
 # merge.hip must not contract a*b+c into an FMA: the reference rounds the products separately.
-EXTRA = {"merge.hip": ["-ffp-contract=off"], "gemm_bf16.hip": os.environ.get("MR_GEMM_DEFS", "").split()}
+EXTRA = {"merge.hip": ["-ffp-contract=off"], "gemm_bf16.hip": os.environ.get("MR_GEMM_DEFS", "").split(),
+         "score_fused.hip": os.environ.get("MR_SCORE_DEFS", "").split()}
 
 
 def hipcc() -> str:

@@ -9,6 +9,7 @@
 // runs out of LDS; longer rows are re-read from L2 on every pass.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -215,10 +216,50 @@ extern "C" int mr_topk_rows_f32(const float* scores, int64_t ld, int nrows, int 
     return mr::check_launch();
 }
 
-extern "C" size_t mr_score_topk_ws_bytes(int64_t nU, int64_t M) {
-    if (nU < 0 || M < 0) return 0;
+namespace mr {  // score_fused.hip
+bool score_fused_supported(int64_t nU, int64_t M, int d, int k);
+size_t score_fused_ws_bytes(int64_t nU, int64_t M, int k);
+int score_fused_launch(const float* U, const float* E, int64_t nU, int64_t M, int d, int k, float* top_val, int64_t* top_idx, const int64_t* labels,
+                       float inv_temp, float* row_lse, float* row_lab, int32_t* label_rank, void* ws, hipStream_t st);
+}  // namespace mr
+
+// Route of mr_score_topk_f32(scores_out = NULL).  2 = auto (default): the fused kernels when the (users x M) block would exceed
+// kFusedAutoBytes -- it could not stay in the 256 MB Infinity Cache between the scoring GEMM's writes and the select's reads, i.e. it would
+// cost HBM traffic; below that the two-kernel route is faster (its block never leaves the caches: 0.23 vs 0.31 ms at 256 x 22,855).
+// 0 = never, 1 = always.  Initial value from MR_SCORE_FUSED; mr_score_fused_mode() changes it at run time (tests, A/B runs).
+constexpr int64_t kFusedAutoBytes = (int64_t)128 << 20;
+static int g_fused_mode = [] { const char* e = getenv("MR_SCORE_FUSED"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
+
+extern "C" int mr_score_fused_mode(int mode) {
+    const int old = g_fused_mode;
+    if (mode >= 0 && mode <= 2) g_fused_mode = mode;
+    return old;
+}
+
+static bool score_use_fused(int64_t nU, int64_t M, int d, int k) {
+    if (g_fused_mode == 0 || nU <= 0 || M <= 0 || !mr::score_fused_supported(nU, M, d, k)) return false;
+    return g_fused_mode == 1 || nU * M * (int64_t)sizeof(float) > kFusedAutoBytes;
+}
+
+static size_t score_unfused_ws(int64_t nU, int64_t M) {
     const int64_t ldm = (M + 3) & ~(int64_t)3;
     return (size_t)nU * (size_t)ldm * sizeof(float) + 256;
+}
+
+// workspace of mr_score_topk_f32(scores_out = NULL) for exactly this call shape: the candidate lists of the fused path when it applies
+// (mr_score_fused_mode; k <= 64, d % 32 == 0, at most 512 parts of 768 items), else the (nU, M) block of the two-kernel path
+extern "C" size_t mr_score_topk_ws_bytes_ex(int64_t nU, int64_t M, int d, int k) {
+    if (nU < 0 || M < 0) return 0;
+    if (!score_use_fused(nU, M, d, k)) return score_unfused_ws(nU, M);
+    return mr::score_fused_ws_bytes(nU, M, k);
+}
+
+// shape-agnostic upper bound (either path, any d, k <= 64)
+extern "C" size_t mr_score_topk_ws_bytes(int64_t nU, int64_t M) {
+    if (nU < 0 || M < 0) return 0;
+    const size_t a = score_unfused_ws(nU, M);
+    const size_t b = (nU > 0 && M > 0 && mr::score_fused_supported(nU, M, 32, 1)) ? mr::score_fused_ws_bytes(nU, M, 64) : 0;
+    return a > b ? a : b;
 }
 
 extern "C" int mr_score_topk_f32(const float* U, const float* E, int64_t nU, int64_t M, int d, int k, float* top_val,
@@ -227,11 +268,19 @@ extern "C" int mr_score_topk_f32(const float* U, const float* E, int64_t nU, int
                                  mr_stream_t stream) {
     if (!U || !E || nU < 0 || M < 1 || d < 1) return MR_EINVAL;
     if (nU > 0x7fffffff || M > 0x7fffffff) return MR_EUNSUPPORTED;
+    if (!scores_out && score_use_fused(nU, M, d, k)) {
+        // nobody asked for the (users x M) block: selection inside the scoring kernel (score_fused.hip), candidates only in the workspace
+        if (!top_val || !top_idx) return MR_EINVAL;
+        if (!ws) return MR_EINVAL;
+        if (ws_bytes < mr::score_fused_ws_bytes(nU, M, k)) return MR_EWS;
+        if ((d & 3) || !mr::aligned16(U) || !mr::aligned16(E)) return MR_EALIGN;
+        return mr::score_fused_launch(U, E, nU, M, d, k, top_val, top_idx, labels, inv_temp, row_lse, row_lab, label_rank, ws, (hipStream_t)stream);
+    }
     float* sc = scores_out;
     int64_t ldm = M;
     if (!sc) {
         if (!ws) return MR_EINVAL;
-        if (ws_bytes < mr_score_topk_ws_bytes(nU, M)) return MR_EWS;
+        if (ws_bytes < score_unfused_ws(nU, M)) return MR_EWS;
         sc = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
         ldm = (M + 3) & ~(int64_t)3;
     }

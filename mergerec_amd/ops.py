@@ -442,8 +442,11 @@ def topk_rows(scores: torch.Tensor, k: int, labels: Optional[torch.Tensor] = Non
 
 
 def score_topk(U: torch.Tensor, E: torch.Tensor, k: int, labels: Optional[torch.Tensor] = None, inv_temp: float = 1.0,
-               return_scores: bool = False):
-    """scores = U @ E.T -> canonical top-k (+ lse / label logit / label rank when labels are given)."""
+               return_scores: bool = False, fused: Optional[bool] = None):
+    """scores = U @ E.T -> canonical top-k (+ lse / label logit / label rank when labels are given).  Without ``return_scores`` the
+    library picks the route (include/mergerec_hip.h, mr_score_fused_mode): selection inside the scoring kernel (csrc/score_fused.hip: the
+    (users x M) block is never written, only per-part candidates reach memory) when the block would not stay cache-resident, the scoring
+    GEMM into a workspace + row select otherwise.  ``fused`` True / False forces a route for this call."""
     _dev(U, "U", torch.float32), _dev(E, "E", torch.float32)
     nU, d = U.shape
     M = E.shape[0]
@@ -456,24 +459,30 @@ def score_topk(U: torch.Tensor, E: torch.Tensor, k: int, labels: Optional[torch.
         lse = torch.empty(nU, dtype=torch.float32, device=dev)
         lab = torch.empty(nU, dtype=torch.float32, device=dev)
         rank = torch.empty(nU, dtype=torch.int32, device=dev)
-    if PROF.enabled:
-        # profiling: the same two launches the fused entry point makes, timed separately (scoring GEMM on the fp32 matrix cores,
-        # then the row select) -- identical results
-        ldm = (M + 3) // 4 * 4  # the fused entry point's workspace layout
+    staged = return_scores or fused is False or (fused is None and lib.mr_score_topk_ws_bytes_ex(nU, M, d, k) >= 4 * nU * M)
+    if PROF.enabled and staged:
+        # profiling the staged route: its two launches timed separately (scoring GEMM on the fp32 matrix cores, then the row select) --
+        # identical results
+        ldm = (M + 3) // 4 * 4  # the entry point's workspace layout
         sc = torch.empty(nU, ldm, dtype=torch.float32, device=dev)[:, :M]
         gemm_nt(U, [E], out=sc, prof_name="score_gemm")
         val, idx, lse, lab, rank = topk_rows(sc, k, labels, inv_temp)
         return val, idx, lse, lab, rank, (sc.contiguous() if return_scores else None)
     scores = ws = None
     nbytes = 0
-    if return_scores:
-        scores = torch.empty(nU, M, dtype=torch.float32, device=dev)
-    else:
-        nbytes = lib.mr_score_topk_ws_bytes(nU, M)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    ev = PROF.begin(dev)
-    check(lib.mr_score_topk_f32(ptr(U), ptr(E), nU, M, d, k, ptr(val), ptr(idx), ptr(scores), ptr(labels), inv_temp, ptr(lse), ptr(lab), ptr(rank), ptr(ws), nbytes, _stream(U)), "mr_score_topk_f32")
-    PROF.end(ev, dev, "score_topk", flops=2.0 * nU * M * d, nbytes=4.0 * (nU + M) * d + nU * k * 12)
+    prev = lib.mr_score_fused_mode(-1 if fused is None else int(bool(fused)))
+    try:
+        if return_scores:
+            scores = torch.empty(nU, M, dtype=torch.float32, device=dev)
+        else:
+            nbytes = lib.mr_score_topk_ws_bytes_ex(nU, M, d, k)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ev = PROF.begin(dev)
+        check(lib.mr_score_topk_f32(ptr(U), ptr(E), nU, M, d, k, ptr(val), ptr(idx), ptr(scores), ptr(labels), inv_temp, ptr(lse), ptr(lab), ptr(rank), ptr(ws), nbytes, _stream(U)), "mr_score_topk_f32")
+        PROF.end(ev, dev, "score_topk", flops=2.0 * nU * M * d, nbytes=4.0 * (nU + M) * d + nU * k * 12)
+    finally:
+        if fused is not None:
+            lib.mr_score_fused_mode(prev)
     return val, idx, lse, lab, rank, scores
 
 

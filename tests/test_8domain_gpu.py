@@ -1,0 +1,110 @@
+"""north_star: "NDCG@10 within 1e-3 of reference across all 8 Amazon domains" -- BASELINE configs[3]'s model (ONE 8-domain task-vector merge
+of BLaIR-base at true dimensions) evaluated on every domain's full catalog (4,968 ... 27,932 items, 114,075 in all), 256 users per domain.
+
+Fixture: tests/golden/g13_8domain_blair_base.pt, produced in the build container by oracle/gen_golden_8domain.py from the reference itself
+(its load_merging_module / get_state_dict, transformers' RobertaModel, user @ item.T, its Evaluator; CPU, fp32).  Inputs are regenerated from
+seeds here.  Checked per domain, in the product's default arithmetic (bf16x3) through the drop-in evaluation loop: user embeddings, sampled
+item rows and their logits within 1e-4; the ranked top-50 equal to the reference's up to its own near-ties (2e-6); label ranks equal up to
+near-ties; every Recall / NDCG value within 1e-3; the loss within 1e-3."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOGIT_TOL = 1e-4       # north_star
+NEAR_TIE = 2e-6        # two items whose REFERENCE scores are this close may swap places (fp32 summation order)
+NDCG_TOL = 1e-3        # north_star
+
+
+@pytest.fixture(scope="module")
+def merged():
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.module import ModelType
+
+    fx = load_golden("g13_8domain_blair_base.pt")
+    cfg = O.EncoderConfig()
+    pre0 = O.random_state_dict(O.roberta_param_shapes(cfg), seed=fx["seed_pre"], std=0.02)
+    pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])  # the order the reference's wrapper yielded (perturbations are drawn along it)
+    assert abs(float(sum(v.double().sum() for v in pre.values())) - fx["pre_checksum"]) < 1e-6 * abs(fx["pre_checksum"]) + 1e-9
+    fts = [O.perturbed_state_dict(pre, seed=s, std=fx["ft_std"]) for s in fx["seed_ft"]]
+    model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "device": DEV})
+    model.load_state_dict(pre)
+    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, pre, fts, set(), disable_softmax=True)  # merge_test.py:35-71
+    mm.load_weights_from_dict({"global_weights": {"all": [1.0]}, "global_biases": {"all": [0.0]}, "per_weights": {"all": list(fx["alphas"])}})
+    sd = {k: v.detach().clone() for k, v in mm.get_state_dict().items()}
+    merged_sum = float(sum(v.double().sum() for v in sd.values()))
+    assert abs(merged_sum - fx["merged_checksum"]) < 1e-9 * max(1.0, abs(fx["merged_checksum"])) + 1e-5, (merged_sum, fx["merged_checksum"])
+    del mm, model, fts
+    torch.cuda.empty_cache()
+    model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "device": DEV})  # product default arithmetic
+    model.load_state_dict(sd)
+    return fx, cfg, model
+
+
+def test_all_eight_domains_match_the_reference(merged, tmp_path):
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.model_batch import BatchSequence
+    from mergerec_amd.module import RecModule
+    from mergerec_amd.synthetic import CATALOG_SIZES, make_domain
+    from mergerec_amd.utils import test_model_on_dataloaders
+
+    fx, cfg, model = merged
+    assert list(fx["domains"]) == list(CATALOG_SIZES), "the fixture covers every domain"
+    module = RecModule(model=model, evaluator=Evaluator(["NDCG", "RECALL"], fx["ks"]), similarity="cosine")
+    worst = dict(logit=0.0, ndcg10=0.0, any_metric=0.0)
+    n_users = fx["n_users"]
+    ar = torch.arange(n_users)
+    for name, d in fx["domains"].items():
+        dom = make_domain(name, d["n_items"], n_users, 32, cfg.vocab, d["seed"])
+        seqs, at = [], 0
+        for b in dom.sequence_batches:  # the fixture's labels (the reference's rank-derived items) replace the generator's random ones
+            n = b.labels.numel()
+            seqs.append(BatchSequence(sequence=b.sequence, labels=d["labels"][at:at + n].clone()))
+            at += n
+        _, metrics, scores, labels = test_model_on_dataloaders(module, [dom.item_batches], [seqs], [name], precision="bf16-mixed",
+                                                               predictions_path=tmp_path / f"{name}.pt")
+        assert model._weights.mode == "bf16x3"
+        got, E, U = scores[0], module.item_embeddings.detach().cpu(), module.eval_user_embeddings.detach().cpu()
+        assert got.shape == (n_users, d["n_items"]) and torch.equal(labels[0], d["labels"])
+        # (1) embeddings, catalog checksum, logits on the sampled columns
+        rows = d["E_rows"].long()
+        assert float((U - d["U"]).abs().max()) < LOGIT_TOL and float((E[rows] - d["E_sample"]).abs().max()) < LOGIT_TOL
+        assert abs(float(E.double().sum()) - d["E_checksum"]) < 1e-4 * d["n_items"]
+        logit_err = float((got[:, rows] - d["U"] @ d["E_sample"].T).abs().max())
+        assert logit_err < LOGIT_TOL, (name, logit_err)
+        # (2) ranked indices: the reference's top-50, except where the reference's own scores are within NEAR_TIE of each other
+        idx = module.eval_topk_indices.cpu()
+        ref_idx, ref_val = d["ref_top52_idx"].long(), d["ref_top52_val"]
+        diff = idx != ref_idx[:, :50]
+        for u, p in torch.nonzero(diff).tolist():
+            hit = torch.nonzero(ref_idx[u] == idx[u, p]).flatten()
+            assert hit.numel() == 1, (name, u, p, "an item outside the reference's top-52 entered the top-50")
+            assert abs(float(ref_val[u, int(hit)] - ref_val[u, p])) <= NEAR_TIE, (name, u, p)
+        gap = ref_val[:, :50] - ref_val[:, 1:51]
+        above = torch.cat([torch.full_like(gap[:, :1], float("inf")), gap[:, :-1]], dim=1)
+        clear = (gap > 2 * NEAR_TIE) & (above > 2 * NEAR_TIE)
+        assert bool((idx[clear] == ref_idx[:, :50][clear]).all()), (name, "a clearly separated rank position holds a different item")
+        # (3) label ranks: a label may move only across items the reference scores within NEAR_TIE of it
+        my_rank = (got > got[ar, labels[0]][:, None]).sum(1)
+        ref_rank = d["label_rank"].long()
+        for u in torch.nonzero(my_rank != ref_rank).flatten().tolist():
+            shift = int(my_rank[u] - ref_rank[u])
+            assert abs(shift) <= 3, (name, u, shift)
+            lo, hi = sorted((3, 3 + shift))
+            between = d["label_window"][u, lo:hi + 1]
+            assert float((between - d["label_score"][u]).abs().max()) <= NEAR_TIE, (name, u, shift)
+        # (4) metrics and loss
+        for k, v in d["metrics"].items():
+            worst["any_metric"] = max(worst["any_metric"], abs(metrics[0][k] - v))
+            assert abs(metrics[0][k] - v) <= NDCG_TOL, (name, k, metrics[0][k], v)
+        assert abs(metrics[0]["test/loss"] - d["loss"]) < 1e-3, (name, metrics[0]["test/loss"], d["loss"])
+        dn = abs(metrics[0]["test/NDCG@10"] - d["metrics"]["test/NDCG@10"])
+        worst["logit"], worst["ndcg10"] = max(worst["logit"], logit_err), max(worst["ndcg10"], dn)
+        print(f"[{name}] M={d['n_items']} logit max err {logit_err:.2e}; top-50 positions differing (all near-ties) {int(diff.sum())}; "
+              f"labels moved {int((my_rank != ref_rank).sum())}; NDCG@10 {metrics[0]['test/NDCG@10']:.4f} (reference {d['metrics']['test/NDCG@10']:.4f}, |d| {dn:.1e})")
+    print(f"[8 domains] worst logit err {worst['logit']:.2e}, worst |dNDCG@10| {worst['ndcg10']:.1e}, worst |d metric| {worst['any_metric']:.1e}")

@@ -40,7 +40,13 @@ def test_argument_validation_without_gpu():
     assert lib.mr_gemm_nt_bias_act_f32(None, 0, None, None, None, None, None, None, 1, 4, 4, 16, 0, None, 0, None, 0, None) == -1
     assert lib.mr_topk_rows_f32(None, 0, 1, 10, 5, None, None, None, 1.0, None, None, None, None) == -1
     assert lib.mr_merge_bwd_alpha_ws_bytes(8, 13, 1 << 20) > 0
-    assert lib.mr_score_topk_ws_bytes(32, 1001) >= 32 * 1004 * 4
+    assert lib.mr_score_topk_ws_bytes(32, 1001) >= 32 * 1004 * 4          # upper bound over both routes
+    assert lib.mr_score_fused_mode(1) == 2                                   # default: auto
+    assert 32 * 2 * 50 * 12 <= lib.mr_score_topk_ws_bytes_ex(32, 1001, 768, 50) < 32 * 1004 * 4   # fused route: candidates of two 768-item parts
+    assert lib.mr_score_topk_ws_bytes_ex(32, 1001, 48, 50) >= 32 * 1004 * 4  # d % 32 != 0: the staged route's score block
+    assert lib.mr_score_fused_mode(2) == 1
+    assert lib.mr_score_topk_ws_bytes_ex(32, 1001, 768, 50) >= 32 * 1004 * 4  # auto: a 128 KB block stays in the caches -> staged route
+    assert lib.mr_score_topk_ws_bytes_ex(4096, 22855, 768, 50) < 4096 * 22855  # auto: a 374 MB block would not -> fused route
 
 
 def test_ops_refuse_cpu_tensors():

@@ -346,6 +346,72 @@ def test_score_topk_full_catalog(ops, nU, M):
     assert abs(loss - O.ce_loss(ref, labels, 0.05)) < 1e-3
 
 
+def _assert_fused_equals_unfused(ops, U, E, k, labels, inv_temp=20.0):
+    """score_topk without the score block (selection inside the scoring kernel, csrc/score_fused.hip) against the scoring GEMM + topk_rows
+    pair: indices, values, label ranks and label logits bit for bit; the log-sum-exp to rounding (different summation order)."""
+    Ud, Ed, Ld = U.to(DEV), E.to(DEV), labels.to(DEV)
+    fv, fi, flse, flab, frank, none = ops.score_topk(Ud, Ed, k, Ld, inv_temp, fused=True)
+    uv, ui, ulse, ulab, urank, scores = ops.score_topk(Ud, Ed, k, Ld, inv_temp, return_scores=True)
+    assert none is None and scores is not None
+    assert torch.equal(fi, ui), "fused ranked indices differ"
+    assert torch.equal(fv.view(torch.int32), uv.view(torch.int32)), "fused top values differ (bit pattern, so NaN and -0.0 count)"
+    assert torch.equal(frank, urank)
+    assert torch.equal(flab.view(torch.int32), ulab.view(torch.int32))
+    both_nan = torch.isnan(flse) & torch.isnan(ulse)
+    assert torch.equal(torch.isnan(flse), torch.isnan(ulse))
+    assert torch.allclose(flse[~both_nan], ulse[~both_nan], atol=2e-5, rtol=1e-6)
+    return scores.cpu(), fi.cpu()
+
+
+@pytest.mark.parametrize("nU,M,d,k", [(70, 4968, 768, 50), (256, 22855, 768, 50), (33, 768, 64, 50), (5, 769, 64, 64), (31, 50, 32, 50),
+                                      (40, 1537, 48, 1)])
+def test_score_topk_fused_matches_unfused(ops, nU, M, d, k):
+    g = _g(nU * 7 + M)
+    U = O.maybe_normalize(torch.randn(nU, d, generator=g))
+    E = O.maybe_normalize(torch.randn(M, d, generator=g))
+    if M > 1000:
+        E[M // 2] = E[3]                      # an exact tie across two parts of the catalog
+        E[5] = E[4]                           # and inside one part
+    labels = torch.randint(0, M, (nU,), generator=g)
+    labels[0] = M + 5                         # out of range: label logit NaN, rank -1
+    scores, idx = _assert_fused_equals_unfused(ops, U, E, k, labels)
+    _, wi = CO.topk_rows(scores, k)
+    assert torch.equal(idx, wi)
+
+
+def test_score_topk_auto_route_by_block_size(ops):
+    """mode auto (the default): a (users x M) block beyond 128 MB could not stay in the Infinity Cache -> the fused kernels (workspace =
+    candidate lists); a small block -> scoring GEMM + row select.  Same answers either way."""
+    lib = ops._lib.load()
+    assert lib.mr_score_fused_mode(-1) == 2
+    g = _g(5)
+    d, k = 64, 50
+    for nU, M, want_fused in ((1500, 22855, True), (64, 4968, False)):
+        assert (lib.mr_score_topk_ws_bytes_ex(nU, M, d, k) < 4 * nU * M) == want_fused
+        U, E = torch.randn(nU, d, generator=g).to(DEV), torch.randn(M, d, generator=g).to(DEV)
+        labels = torch.randint(0, M, (nU,), generator=g).to(DEV)
+        av, ai, alse, alab, arank, _ = ops.score_topk(U, E, k, labels, 1.0)
+        sv, si, slse, slab, srank, _ = ops.score_topk(U, E, k, labels, 1.0, return_scores=True)
+        assert torch.equal(ai, si) and torch.equal(av, sv) and torch.equal(arank, srank) and torch.equal(alab, slab)
+        assert torch.allclose(alse, slse, atol=2e-5, rtol=1e-6)
+
+
+def test_score_topk_fused_ties_nan_and_signed_zero(ops):
+    g = _g(99)
+    nU, M, d, k = 40, 3000, 32, 50
+    U = torch.randn(nU, d, generator=g)
+    E = torch.randn(M, d, generator=g)
+    E[100:400] = E[7]                          # 301 identical items: ties straddling the k-th value, by ascending index
+    E[2000:2100] = E[7]                        # ... continuing in another part
+    U[1] = 0.0                                 # every score +0.0 or -0.0 (E has both signs): one key, order by index
+    U[2, 3] = float("nan")                     # every score NaN
+    E[1234, 0] = float("nan")                  # one NaN column for everyone: ranks first
+    U[3] = 1e30; E[50] = 1e30                  # +inf scores
+    labels = torch.randint(0, M, (nU,), generator=g)
+    labels[4] = 1234
+    _assert_fused_equals_unfused(ops, U, E, k, labels, inv_temp=1.0)
+
+
 @pytest.mark.parametrize("tool,env", [("gemm_fuzz.py", {"FZ_N": "25", "FZ_SEED": "3"}), ("attn_fuzz.py", {"FZ_N": "12", "FZ_SEED": "3"})])
 def test_randomised_differential_fuzz(tool, env):
     """tools/gemm_fuzz.py / tools/attn_fuzz.py: random shapes, strides, epilogues, ragged lengths and windows against float64 torch"""
