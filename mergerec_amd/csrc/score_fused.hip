@@ -1,7 +1,7 @@
 // K5 fused: full-catalog scoring with the top-k selection inside the scoring kernel -- the (users x M) score block is never written.
 //
 //   score_part_topk_kernel   one workgroup = 32 users x one PART of the catalog (768 consecutive items).  The part's scores are produced
-//                            256 columns at a time by the exact-fp32 MFMA product of gemm.hip (v_mfma_f32_32x32x2_f32: every score is the
+//                            256 columns at a time (8 waves x 32) by the exact-fp32 MFMA product of gemm.hip (v_mfma_f32_32x32x2_f32: every score is the
 //                            ascending-k fp32 FMA chain, bit for bit what mr_gemm_nt_bias_act_f32 writes) into a 32 x 768 strip in LDS;
 //                            then each wave radix-selects its rows' top-k out of LDS (as topk_rows_kernel: 4 passes x 8 bits on
 //                            order-preserving keys, ties at the threshold by ascending index, one bitonic sort of the <= 64 survivors)
@@ -18,7 +18,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;            // part kernel: 8 waves = two per SIMD (one workgroup per CU: 153 KB of LDS), each 32 columns of a chunk
+constexpr int kWaves = kThreads / 64;
 constexpr int SBM = 32, SBN = 256, SBK = 16;   // d % (2 SBK) == 0: the k loop is unrolled by two
 constexpr int SSTR = 20;                 // floats per staged row: 8 even-k | 8 odd-k | 4 pad (gemm.hip)
 constexpr int PART = 768;                // catalog columns per workgroup (strip row length)
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(kThreads, 1) void score_part_topk_kernel(const floa
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* stage = lds;                                   // 2 x STAGE_F
     float* strip = lds + 2 * STAGE_F;                     // SBM x PART
-    unsigned* hist_all = reinterpret_cast<unsigned*>(strip + SBM * PART);                       // 4 x 256
-    unsigned long long* slots_all = reinterpret_cast<unsigned long long*>(hist_all + 4 * 256);  // 4 x 64
+    unsigned* hist_all = reinterpret_cast<unsigned*>(strip + SBM * PART);                            // kWaves x 256
+    unsigned long long* slots_all = reinterpret_cast<unsigned long long*>(hist_all + kWaves * 256);  // kWaves x 64
 
     const int part = blockIdx.x, m0 = blockIdx.y * SBM;
     const int c_begin = part * PART;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kThreads, 1) void score_part_topk_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
 
-    // staging maps (gemm.hip): A rows by threads 0..127, B rows tid >> 2 + 64 q
+    // staging maps (gemm.hip): A rows by threads 0..127, B rows tid >> 2 + 128 q
     const int sr = tid >> 2, kq = tid & 3;
     int ar = m0 + (sr & 31);
     ar = ar < nU ? ar : nU - 1;
@@ -155,34 +156,30 @@ __global__ __launch_bounds__(kThreads, 1) void score_part_topk_kernel(const floa
     const int wa = (sr & 31) * SSTR + 2 * kq;
     const bool stage_a = tid < 128;  // wave-uniform
     const int ra = lr * SSTR + lh * 8;
-    const int rb = (SBM + wave * 64 + lr) * SSTR + lh * 8;
+    const int rb = (SBM + wave * 32 + lr) * SSTR + lh * 8;
     const int nk = d / SBK;
 
     for (int c0 = 0; c0 < ncols; c0 += SBN) {
-        const float* gb[4];
-        int wb[4];
+        const float* gb[2];
+        int wb[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int br = c_begin + c0 + sr + 64 * q;
+        for (int q = 0; q < 2; ++q) {
+            int br = c_begin + c0 + sr + 128 * q;
             br = br < M ? br : M - 1;
             gb[q] = E + (int64_t)br * d + kq * 4;
-            wb[q] = (SBM + sr + 64 * q) * SSTR + 2 * kq;
+            wb[q] = (SBM + sr + 128 * q) * SSTR + 2 * kq;
         }
-        f32x16 acc[2];
+        f32x16 acc;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         // two named staging sets: a k-tile's global loads are issued two tiles before they are stored to LDS (one workgroup per CU and one
         // wave per SIMD: nothing else covers the load latency), as the prefetch-distance-2 loop of gemm_bf16.hip
-        float4 xa, xb0, xb1, xb2, xb3, ya, yb0, yb1, yb2, yb3;
+        float4 xa, xb0, xb1, ya, yb0, yb1;
 #define SF_GLOAD(S, k0_)                                                      \
     do {                                                                      \
         if (stage_a) S##a = *reinterpret_cast<const float4*>(ga + (k0_));     \
         S##b0 = *reinterpret_cast<const float4*>(gb[0] + (k0_));              \
         S##b1 = *reinterpret_cast<const float4*>(gb[1] + (k0_));              \
-        S##b2 = *reinterpret_cast<const float4*>(gb[2] + (k0_));              \
-        S##b3 = *reinterpret_cast<const float4*>(gb[3] + (k0_));              \
     } while (0)
 #define SF_ST(buf_, off_, v_)                                                            \
     do {                                                                                 \
@@ -194,26 +191,17 @@ __global__ __launch_bounds__(kThreads, 1) void score_part_topk_kernel(const floa
         if (stage_a) SF_ST(buf_, wa, S##a);     \
         SF_ST(buf_, wb[0], S##b0);              \
         SF_ST(buf_, wb[1], S##b1);              \
-        SF_ST(buf_, wb[2], S##b2);              \
-        SF_ST(buf_, wb[3], S##b3);              \
     } while (0)
 #define SF_COMPUTE(buf_)                                                                                                   \
     do {                                                                                                                   \
         const float* b_ = (buf_);                                                                                          \
         const float4 a0 = *reinterpret_cast<const float4*>(b_ + ra), a1 = *reinterpret_cast<const float4*>(b_ + ra + 4);   \
-        float4 bf[2][2];                                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                    \
-            bf[j][0] = *reinterpret_cast<const float4*>(b_ + rb + j * 32 * SSTR);                                          \
-            bf[j][1] = *reinterpret_cast<const float4*>(b_ + rb + j * 32 * SSTR + 4);                                      \
-        }                                                                                                                  \
+        const float4 b0 = *reinterpret_cast<const float4*>(b_ + rb), b1 = *reinterpret_cast<const float4*>(b_ + rb + 4);   \
         _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                                    \
-            const float4 fa = (s >> 2) ? a1 : a0;                                                                          \
+            const float4 fa = (s >> 2) ? a1 : a0, fb = (s >> 2) ? b1 : b0;                                                 \
             const float av = (s & 3) == 0 ? fa.x : ((s & 3) == 1 ? fa.y : ((s & 3) == 2 ? fa.z : fa.w));                   \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
-                const float4 fb = bf[j][s >> 2];                                                                           \
-                const float bv = (s & 3) == 0 ? fb.x : ((s & 3) == 1 ? fb.y : ((s & 3) == 2 ? fb.z : fb.w));               \
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);                                    \
-            }                                                                                                              \
+            const float bv = (s & 3) == 0 ? fb.x : ((s & 3) == 1 ? fb.y : ((s & 3) == 2 ? fb.z : fb.w));                   \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);                                              \
         }                                                                                                                  \
     } while (0)
         float* buf0 = stage;
@@ -247,21 +235,20 @@ __global__ __launch_bounds__(kThreads, 1) void score_part_topk_kernel(const floa
 #undef SF_ST
 #undef SF_LSTORE
         // accumulators -> strip (C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
+        {
+            const int col = c0 + wave * 32 + lr;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = c0 + wave * 64 + j * 32 + lr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * PART + col] = acc[j][r];
+            for (int r = 0; r < 16; ++r) strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * PART + col] = acc[r];
         }
         // (the next chunk's first staging store follows a barrier that every wave reaches only after these stores were issued; the
         // selection below waits at its own barrier)
     }
     __syncthreads();
 
-    // ---- per-row selection: wave w takes rows w, w + 4, ...
+    // ---- per-row selection: wave w takes rows w, w + 8, ...
     volatile unsigned* hist = hist_all + wave * 256;
     volatile unsigned long long* slots = slots_all + wave * 64;
-    for (int r = wave; r < SBM; r += 4) {
+    for (int r = wave; r < SBM; r += kWaves) {
         const int row = m0 + r;
         if (row >= nU) break;  // wave-uniform
         const float* s = strip + r * PART;
@@ -367,7 +354,7 @@ int score_fused_launch(const float* U, const float* E, int64_t nU, int64_t M, in
     float* cand_val = reinterpret_cast<float*>(w + (size_t)nU * P * k * 8);
     float* pmax = cand_val + (size_t)nU * P * k;
     float* psum = pmax + (size_t)nU * P;
-    const size_t shm = (size_t)(2 * STAGE_F + SBM * PART) * sizeof(float) + 4 * 256 * 4 + 4 * 64 * 8;
+    const size_t shm = (size_t)(2 * STAGE_F + SBM * PART) * sizeof(float) + kWaves * 256 * 4 + kWaves * 64 * 8;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&score_part_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

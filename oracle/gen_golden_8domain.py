@@ -4,12 +4,12 @@
 TEST INFRASTRUCTURE.  north_star's clause "NDCG@10 within 1e-3 of reference across all 8 Amazon domains", for BASELINE configs[3]'s model:
 ONE 8-domain task-vector merge of BLaIR-base at true dimensions (the reference's ``load_merging_module(TASK_VECTOR, TASK_WISE)`` +
 ``load_weights_from_dict`` + ``get_state_dict()``, merge_test.py:35-71, fixed per-domain alpha), evaluated the way merge_test.py evaluates
-it -- on EVERY domain's full catalog (mergerec_amd.synthetic.CATALOG_SIZES: 4,968 ... 27,932 items, 114,075 in all) with 256 test users
+it -- on EVERY domain's full catalog (mergerec_amd.synthetic.CATALOG_SIZES: 4,968 ... 27,932 items, 114,075 in all) with 1,024 test users
 per domain: transformers' RobertaModel (the arithmetic the reference delegates to, models/_base.py:56, encoder/_base.py:37-45), CLS pooled,
 ``F.normalize`` (module.py:74-77), ``user @ item.T`` (module.py:137), ``cross_entropy(scores / 0.05)`` (module.py:356), the reference's
 ``Evaluator`` (evaluator.py:31-49, metrics.py:38-88) as imported -- all on the CPU in fp32.
 
-Inputs are regenerated from seeds by the test; per domain the fixture stores the users' embeddings U (256, 768), every 16th row of the item
+Inputs are regenerated from seeds by the test; per domain the fixture stores the first 256 users' embeddings U (256, 768), every 64th row of the item
 matrix E (for the logit check), the labels (the item the REFERENCE ranks at a log-uniform position in [1, 200]: NDCG@10 near 0.3 and
 sensitive to rank changes around every cutoff), the reference's top-50 (indices and scores), the scores of ranks 51 and 52 (near-tie
 bookkeeping at the cutoff), per-user label ranks with the reference scores three ranks either side of the label, the metric dict and the loss.
@@ -25,7 +25,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "oracle"))
 
-N_USERS, E_STRIDE = 256, 16
+N_USERS, U_KEEP, E_STRIDE = 1024, 256, 64
 SEED_PRE, SEED_FT = 2000, tuple(range(2001, 2009))
 ALPHAS = (0.30, 0.10, 0.20, 0.15, 0.05, 0.25, 0.10, 0.20)
 SEED_DOMAIN0 = 31000
@@ -108,13 +108,13 @@ def main():
         win = label_rank.long()[:, None] + torch.arange(-3, 4)[None, :]                    # sorted positions rank - 3 .. rank + 3
         label_window = torch.where((win >= 0) & (win < M), srt.gather(1, win.clamp(0, M - 1)), torch.full(win.shape, float("nan")))
         rows = torch.arange(0, M, E_STRIDE)
-        domains[name] = dict(n_items=M, seed=seed, U=U.clone(), E_rows=rows.to(torch.int32), E_sample=E[rows].clone(),
+        domains[name] = dict(n_items=M, seed=seed, U=U[:U_KEEP].clone(), E_rows=rows.to(torch.int32), E_sample=E[rows].clone(),
                              E_checksum=float(E.double().sum()), labels=labels, ref_top52_idx=top.indices[:, :52].to(torch.int32).clone(),
                              ref_top52_val=top.values[:, :52].clone(), label_rank=label_rank, label_score=lab_score.clone(), label_window=label_window,
                              metrics={k: float(v) for k, v in metrics.items()}, loss=loss)
         print(f"{name}: M={M} NDCG@10={metrics['test/NDCG@10']:.4f} loss={loss:.4f}  {time.time() - t0:.0f}s", flush=True)
 
-    out = dict(n_users=N_USERS, e_stride=E_STRIDE, seed_pre=SEED_PRE, seed_ft=list(SEED_FT), alphas=list(ALPHAS), ft_std=1e-3, ks=ks,
+    out = dict(n_users=N_USERS, u_keep=U_KEEP, e_stride=E_STRIDE, seed_pre=SEED_PRE, seed_ft=list(SEED_FT), alphas=list(ALPHAS), ft_std=1e-3, ks=ks,
                key_order=list(pre.keys()), pre_checksum=float(sum(v.double().sum() for v in pre.values())),
                merged_checksum=float(sum(v.double().sum() for v in merged.values())), domains=domains,
                versions=dict(torch=str(torch.__version__), transformers=str(__import__("transformers").__version__)))

@@ -1,5 +1,5 @@
 """north_star: "NDCG@10 within 1e-3 of reference across all 8 Amazon domains" -- BASELINE configs[3]'s model (ONE 8-domain task-vector merge
-of BLaIR-base at true dimensions) evaluated on every domain's full catalog (4,968 ... 27,932 items, 114,075 in all), 256 users per domain.
+of BLaIR-base at true dimensions) evaluated on every domain's full catalog (4,968 ... 27,932 items, 114,075 in all), 1,024 users per domain.
 
 Fixture: tests/golden/g13_8domain_blair_base.pt, produced in the build container by oracle/gen_golden_8domain.py from the reference itself
 (its load_merging_module / get_state_dict, transformers' RobertaModel, user @ item.T, its Evaluator; CPU, fp32).  Inputs are regenerated from
@@ -72,10 +72,10 @@ def test_all_eight_domains_match_the_reference(merged, tmp_path):
         got, E, U = scores[0], module.item_embeddings.detach().cpu(), module.eval_user_embeddings.detach().cpu()
         assert got.shape == (n_users, d["n_items"]) and torch.equal(labels[0], d["labels"])
         # (1) embeddings, catalog checksum, logits on the sampled columns
-        rows = d["E_rows"].long()
-        assert float((U - d["U"]).abs().max()) < LOGIT_TOL and float((E[rows] - d["E_sample"]).abs().max()) < LOGIT_TOL
+        rows, nu = d["E_rows"].long(), d["U"].shape[0]   # the fixture keeps the first users' embeddings and sampled catalog rows
+        assert float((U[:nu] - d["U"]).abs().max()) < LOGIT_TOL and float((E[rows] - d["E_sample"]).abs().max()) < LOGIT_TOL
         assert abs(float(E.double().sum()) - d["E_checksum"]) < 1e-4 * d["n_items"]
-        logit_err = float((got[:, rows] - d["U"] @ d["E_sample"].T).abs().max())
+        logit_err = float((got[:nu][:, rows] - d["U"] @ d["E_sample"].T).abs().max())
         assert logit_err < LOGIT_TOL, (name, logit_err)
         # (2) ranked indices: the reference's top-50, except where the reference's own scores are within NEAR_TIE of each other
         idx = module.eval_topk_indices.cpu()
@@ -98,9 +98,11 @@ def test_all_eight_domains_match_the_reference(merged, tmp_path):
             lo, hi = sorted((3, 3 + shift))
             between = d["label_window"][u, lo:hi + 1]
             assert float((between - d["label_score"][u]).abs().max()) <= NEAR_TIE, (name, u, shift)
-        # (4) metrics and loss
+        # (4) metrics and loss: within 1e-3 of the reference, and EXACTLY the reference's values after the near-tie label moves verified above
+        must = O.metrics_after_rank_moves(d["metrics"], ref_rank, my_rank, fx["ks"])
         for k, v in d["metrics"].items():
             worst["any_metric"] = max(worst["any_metric"], abs(metrics[0][k] - v))
+            assert abs(metrics[0][k] - must[k]) < 5e-6, (name, k, metrics[0][k], must[k])
             assert abs(metrics[0][k] - v) <= NDCG_TOL, (name, k, metrics[0][k], v)
         assert abs(metrics[0]["test/loss"] - d["loss"]) < 1e-3, (name, metrics[0]["test/loss"], d["loss"])
         dn = abs(metrics[0]["test/NDCG@10"] - d["metrics"]["test/NDCG@10"])

@@ -1,0 +1,102 @@
+"""north_star's accuracy clause for the second model family at true dimensions: BASELINE configs[2] -- a 3-domain task-vector merge of
+Recformer-base (Longformer-base geometry, 148 M parameters; windowed + global attention, token-type and item-position embeddings) --
+evaluated on a Pantry-sized domain (4,968 items, 1,024 users with sequences up to 1,024 tokens).
+
+Fixture: tests/golden/g14_realscale_recformer_base.pt, produced in the build container by oracle/gen_golden_recformer_realscale.py from the
+reference itself (its load_merging_module / get_state_dict, its RecformerModel driving transformers' LongformerEncoder, user @ item.T, its
+Evaluator; CPU, fp32).  Inputs are regenerated from seeds here.  Checked through the drop-in evaluation loop: embeddings and sampled logits
+within 1e-4, the ranked top-50 equal up to the reference's own near-ties (2e-6), label ranks equal up to near-ties, every metric within 1e-3."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOGIT_TOL = 1e-4       # north_star
+NEAR_TIE = 2e-6        # two items whose REFERENCE scores are this close may swap places (fp32 summation order)
+NDCG_TOL = 1e-3        # north_star
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchSequence
+    from mergerec_amd.module import ModelType
+    from mergerec_amd.synthetic import make_domain
+
+    fx = load_golden("g14_realscale_recformer_base.pt")
+    cfg = O.EncoderConfig(max_pos=4098, token_type_size=4, max_item_embeddings=51, one_sided_window=32)
+    pre0 = O.random_state_dict(O.recformer_param_shapes(cfg), seed=fx["seed_pre"], std=0.02)
+    pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])  # the reference model's key order (perturbations are drawn along it)
+    fsum = lambda sd: float(sum(v.double().sum() for v in sd.values() if v.is_floating_point()))
+    assert abs(fsum(pre) - fx["pre_checksum"]) < 1e-6 * abs(fx["pre_checksum"]) + 1e-9
+    fts = [O.perturbed_state_dict(pre, seed=s, std=fx["ft_std"]) for s in fx["seed_ft"]]
+    model = ModelType.RECFORMER_BASE.value(model_kwargs={"init_seed": 0, "device": DEV})
+    model.load_state_dict(pre)
+    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, pre, fts, set(), disable_softmax=True)  # merge_test.py:35-71
+    mm.load_weights_from_dict({"global_weights": {"all": [1.0]}, "global_biases": {"all": [0.0]}, "per_weights": {"all": list(fx["alphas"])}})
+    sd = {k: v.detach().clone() for k, v in mm.get_state_dict().items()}
+    assert abs(fsum(sd) - fx["merged_checksum"]) < 1e-9 * max(1.0, abs(fx["merged_checksum"])) + 1e-5, (fsum(sd), fx["merged_checksum"])
+    del mm, model, fts
+    torch.cuda.empty_cache()
+    dom = make_domain("Pantry", fx["n_items"], fx["n_users"], 32, cfg.vocab, fx["seed_domain"], kind="recformer", max_seq_len=fx["max_seq_len"])
+    seqs, at = [], 0
+    for b in dom.sequence_batches:  # the fixture's labels (the reference's rank-derived items) replace the generator's random ones
+        n = b.labels.numel()
+        seqs.append(BatchSequence(sequence=b.sequence, labels=fx["labels"][at:at + n].clone()))
+        at += n
+    assert int(torch.cat([b.sequence["attention_mask"].sum(1) for b in seqs]).max()) == fx["longest_sequence"]
+    return fx, sd, dom.item_batches, seqs
+
+
+@pytest.mark.parametrize("mode,precision", [("bf16x3", "bf16-mixed"), ("f32", "32-true")])
+def test_recformer_base_logits_ranks_and_ndcg_match_the_reference(setup, mode, precision, tmp_path):
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.module import ModelType, RecModule
+    from mergerec_amd.utils import test_model_on_dataloaders
+
+    fx, sd, item_batches, seq_batches = setup
+    model = ModelType.RECFORMER_BASE.value(model_kwargs={"init_seed": 0, "device": DEV, "gemm_mode": mode})
+    model.load_state_dict(sd)  # merge_test.py:71-80
+    module = RecModule(model=model, evaluator=Evaluator(["NDCG", "RECALL"], fx["ks"]), similarity="cosine")
+    _, metrics, scores, labels = test_model_on_dataloaders(module, [item_batches], [seq_batches], ["Pantry"], precision=precision,
+                                                           predictions_path=tmp_path / "p.pt")
+    assert model._weights.mode == mode
+    n_users, M = fx["n_users"], fx["n_items"]
+    got, E, U = scores[0], module.item_embeddings.detach().cpu(), module.eval_user_embeddings.detach().cpu()
+    assert got.shape == (n_users, M) and torch.equal(labels[0], fx["labels"])
+    rows, nu = fx["E_rows"].long(), fx["U"].shape[0]   # the fixture keeps the first users' embeddings and sampled catalog rows
+    assert float((U[:nu] - fx["U"]).abs().max()) < LOGIT_TOL and float((E[rows] - fx["E_sample"]).abs().max()) < LOGIT_TOL
+    assert abs(float(E.double().sum()) - fx["E_checksum"]) < 1e-4 * M
+    logit_err = float((got[:nu][:, rows] - fx["U"] @ fx["E_sample"].T).abs().max())
+    assert logit_err < LOGIT_TOL, logit_err
+    idx = module.eval_topk_indices.cpu()
+    ref_idx, ref_val = fx["ref_top52_idx"].long(), fx["ref_top52_val"]
+    diff = idx != ref_idx[:, :50]
+    for u, p in torch.nonzero(diff).tolist():
+        hit = torch.nonzero(ref_idx[u] == idx[u, p]).flatten()
+        assert hit.numel() == 1, (u, p, "an item outside the reference's top-52 entered the top-50")
+        assert abs(float(ref_val[u, int(hit)] - ref_val[u, p])) <= NEAR_TIE, (u, p)
+    gap = ref_val[:, :50] - ref_val[:, 1:51]
+    above = torch.cat([torch.full_like(gap[:, :1], float("inf")), gap[:, :-1]], dim=1)
+    clear = (gap > 2 * NEAR_TIE) & (above > 2 * NEAR_TIE)
+    assert bool((idx[clear] == ref_idx[:, :50][clear]).all()), "a clearly separated rank position holds a different item"
+    ar = torch.arange(n_users)
+    my_rank = (got > got[ar, labels[0]][:, None]).sum(1)
+    ref_rank = fx["label_rank"].long()
+    for u in torch.nonzero(my_rank != ref_rank).flatten().tolist():
+        shift = int(my_rank[u] - ref_rank[u])
+        assert abs(shift) <= 3, (u, shift)
+        lo, hi = sorted((3, 3 + shift))
+        assert float((fx["label_window"][u, lo:hi + 1] - fx["label_score"][u]).abs().max()) <= NEAR_TIE, (u, shift)
+    must = O.metrics_after_rank_moves(fx["metrics"], ref_rank, my_rank, fx["ks"])  # the reference's values after the verified near-tie moves
+    for k, v in fx["metrics"].items():
+        assert abs(metrics[0][k] - must[k]) < 5e-6, (k, metrics[0][k], must[k])
+        assert abs(metrics[0][k] - v) <= NDCG_TOL, (k, metrics[0][k], v)
+    assert abs(metrics[0]["test/loss"] - fx["loss"]) < 1e-3
+    print(f"[recformer-base {mode}] logit max err {logit_err:.2e}; top-50 positions differing (all near-ties) {int(diff.sum())}; labels moved "
+          f"{int((my_rank != ref_rank).sum())}; NDCG@10 {metrics[0]['test/NDCG@10']:.4f} (reference {fx['metrics']['test/NDCG@10']:.4f})")
