@@ -282,8 +282,9 @@ int mr_topk_rows_f32(const float* scores, int64_t ld, int nrows, int ncols, int 
 /* Full-catalog scoring + top-k in one call: scores = U E^T (U: (nU, d), E: (M, d), both row-major),
  * then mr_topk_rows_f32 semantics.  scores_out != NULL: the (nU, M) block is written there (predictions were asked for).
  * scores_out == NULL, two routes with the same indices, values, label ranks and label logits (the log-sum-exp agrees to rounding):
- *   fused   -- the block is never materialised: every workgroup scores 32 users against one 768-item part of the catalog into LDS and
- *              selects the part's top-k there; a second launch merges the parts' candidate lists (k <= 64, d % 32 == 0, M <= 393,216);
+ *   fused   -- the block is never materialised: every workgroup scores 32 users against one part of the catalog (256 / 512 / 768 items,
+ *              chosen so that the launch fills the chip) into LDS and selects the part's top-k there; a second launch merges the parts'
+ *              candidate lists (k <= 64, d % 32 == 0, at most 512 parts);
  *   staged  -- the scoring GEMM into `ws`, then mr_topk_rows_f32.
  * mr_score_fused_mode(2) (default, or MR_SCORE_FUSED): fused when the block would exceed 128 MB, i.e. could not stay in the Infinity Cache
  * between its writes and its reads; 1: always fused; 0: never.  Returns the previous mode; a negative argument only queries.

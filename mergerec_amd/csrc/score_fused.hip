@@ -24,7 +24,7 @@ constexpr int SBM = 32, SBN = 256, SBK = 16;   // d % (2 SBK) == 0: the k loop i
 constexpr int SSTR = 20;                 // floats per staged row: 8 even-k | 8 odd-k | 4 pad (gemm.hip)
 constexpr int PART = 768;                // catalog columns per workgroup (strip row length)
 constexpr int STAGE_F = (SBM + SBN) * SSTR;
-constexpr int kMaxParts = 512;           // merge kernel: the candidates of one user (parts x k x 4 B) must fit LDS; larger catalogs (M > 393,216) take the two-kernel path
+constexpr int kMaxParts = 512;           // merge kernel: the candidates of one user (parts x k x 4 B) must fit LDS; larger catalogs take the two-kernel path
 
 __device__ __forceinline__ unsigned ord_key(float f) {
     unsigned u = __float_as_uint(f);
@@ -133,7 +133,7 @@ __device__ __forceinline__ unsigned long long wave_topk(const float* __restrict_
 }
 
 __global__ __launch_bounds__(kThreads, 1) void score_part_topk_kernel(const float* __restrict__ U, const float* __restrict__ E, int nU, int M, int d, int k,
-                                                                     int P, unsigned long long* __restrict__ cand, float* __restrict__ cand_val,
+                                                                     int P, int part_cols, unsigned long long* __restrict__ cand, float* __restrict__ cand_val,
                                                                      float* __restrict__ pmax, float* __restrict__ psum,
                                                                      const int64_t* __restrict__ labels, float inv_temp, float* __restrict__ row_lab) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(kThreads, 1) void score_part_topk_kernel(const floa
     unsigned long long* slots_all = reinterpret_cast<unsigned long long*>(hist_all + kWaves * 256);  // kWaves x 64
 
     const int part = blockIdx.x, m0 = blockIdx.y * SBM;
-    const int c_begin = part * PART;
-    const int ncols = (M - c_begin) < PART ? (M - c_begin) : PART;   // >= 1 by construction of P
+    const int c_begin = part * part_cols;  // part_cols: 256 / 512 / 768 (<= PART, the strip's row length), chosen per launch to fill the chip
+    const int ncols = (M - c_begin) < part_cols ? (M - c_begin) : part_cols;   // >= 1 by construction of P
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
 
@@ -335,20 +335,28 @@ __global__ __launch_bounds__(64) void score_merge_kernel(const unsigned long lon
 
 namespace mr {
 
-int score_parts(int64_t M) { return (int)((M + PART - 1) / PART); }
+// columns per workgroup: the widest part (fewest candidates, best reuse of the staged user rows) that still gives the chip ~one workgroup
+// per CU; small catalogs / few users take narrower parts
+int score_part_cols(int64_t nU, int64_t M) {
+    const int64_t strips = (nU + SBM - 1) / SBM;
+    for (int pc = PART; pc > SBN; pc -= SBN)
+        if (((M + pc - 1) / pc) * strips >= 224) return pc;
+    return SBN;
+}
+int score_parts(int64_t nU, int64_t M) { const int pc = score_part_cols(nU, M); return (int)((M + pc - 1) / pc); }
 
 bool score_fused_supported(int64_t nU, int64_t M, int d, int k) {
-    return k >= 1 && k <= 64 && k <= M && d % (2 * SBK) == 0 && score_parts(M) <= kMaxParts && nU > 0 && (nU + SBM - 1) / SBM <= 65535;
+    return k >= 1 && k <= 64 && k <= M && d % (2 * SBK) == 0 && score_parts(nU, M) <= kMaxParts && nU > 0 && (nU + SBM - 1) / SBM <= 65535;
 }
 
 size_t score_fused_ws_bytes(int64_t nU, int64_t M, int k) {
-    const size_t P = (size_t)score_parts(M);
+    const size_t P = (size_t)score_parts(nU, M);
     return (size_t)nU * P * (size_t)k * 12 + (size_t)nU * P * 8 + 512;
 }
 
 int score_fused_launch(const float* U, const float* E, int64_t nU, int64_t M, int d, int k, float* top_val, int64_t* top_idx, const int64_t* labels,
                        float inv_temp, float* row_lse, float* row_lab, int32_t* label_rank, void* ws, hipStream_t st) {
-    const int P = score_parts(M);
+    const int pc = score_part_cols(nU, M), P = score_parts(nU, M);
     unsigned char* w = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(w);
     float* cand_val = reinterpret_cast<float*>(w + (size_t)nU * P * k * 8);
@@ -360,9 +368,9 @@ int score_fused_launch(const float* U, const float* E, int64_t nU, int64_t M, in
         hipFuncSetAttribute(reinterpret_cast<const void*>(&score_part_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_done = true;
     }
-    hipLaunchKernelGGL(score_part_topk_kernel, dim3(P, (unsigned)((nU + SBM - 1) / SBM)), dim3(kThreads), shm, st, U, E, (int)nU, (int)M, d, k, P, cand,
+    hipLaunchKernelGGL(score_part_topk_kernel, dim3(P, (unsigned)((nU + SBM - 1) / SBM)), dim3(kThreads), shm, st, U, E, (int)nU, (int)M, d, k, P, pc, cand,
                        cand_val, pmax, psum, labels, inv_temp, row_lab);
-    const int last = (int)(M - (int64_t)(P - 1) * PART);
+    const int last = (int)(M - (int64_t)(P - 1) * pc);
     const int n_valid = (P - 1) * k + (k < last ? k : last);
     const size_t shm_m = (size_t)((n_valid + 3) & ~3) * sizeof(float) + 256 * 4 + 64 * 8;
     static size_t attr_m = 0;
