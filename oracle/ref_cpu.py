@@ -457,19 +457,26 @@ def ranks_equal_up_to_ties(scores: torch.Tensor, idx_a: torch.Tensor, idx_b: tor
     return bool(ok.all())
 
 
-def metrics_after_rank_moves(ref_metrics, ref_rank: torch.Tensor, new_rank: torch.Tensor, ks, prefix: str = "test/"):
+def metrics_after_rank_moves(ref_metrics, ref_rank: torch.Tensor, new_rank: torch.Tensor, ks, prefix: str = "test/", tie_users=None):
     """Checker helper: the reference's Recall@k / NDCG@k (evaluator/metrics.py:38-88: per user 1 / log2(rank + 2) resp. 1 if the label's
     0-based rank is < k, averaged) after the labels of some users moved from ``ref_rank`` to ``new_rank`` -- what the metrics MUST be
-    when the only differences to the reference are label moves (each verified separately to cross reference near-ties only)."""
+    when the only differences to the reference are label moves (each verified separately to cross reference near-ties only).
+    Returns (values, slack): ``tie_users`` (bool mask) marks users whose label ties EXACTLY with a neighbour in the reference's scores --
+    torch.topk orders such ties arbitrarily, so the reference's own position of those labels is known only to +-1; slack[key] bounds
+    what that can change."""
     n = ref_rank.numel()
-    out = dict(ref_metrics)
+    out, slack = dict(ref_metrics), {}
     r0, r1 = ref_rank.double(), new_rank.double()
+    t = torch.zeros(n, dtype=torch.bool) if tie_users is None else tie_users.bool()
     for k in ks:
-        g = lambda r: torch.where(r < k, 1.0 / torch.log2(r + 2.0), torch.zeros_like(r))
-        h = lambda r: (r < k).double()
+        g = lambda r: torch.where((r >= 0) & (r < k), 1.0 / torch.log2(r.clamp(min=0) + 2.0), torch.zeros_like(r))
+        h = lambda r: ((r >= 0) & (r < k)).double()
         out[f"{prefix}NDCG@{k}"] = ref_metrics[f"{prefix}NDCG@{k}"] + float((g(r1) - g(r0)).sum()) / n
         out[f"{prefix}Recall@{k}"] = ref_metrics[f"{prefix}Recall@{k}"] + float((h(r1) - h(r0)).sum()) / n
-    return out
+        for name, f in (("NDCG", g), ("Recall", h)):
+            step = torch.maximum((f(r0) - f(r0 + 1)).abs(), (f(r0) - f(r0 - 1)).abs())
+            slack[f"{prefix}{name}@{k}"] = float(step[t].sum()) / n
+    return out, slack
 
 
 # --------------------------------------------------------------------------------------------
