@@ -66,6 +66,7 @@ def parse(argv=None):
     ap.add_argument("--finetune_checkpoint_paths", nargs="+", required=True)
     ap.add_argument("--train_data_split", default="item")
     ap.add_argument("--test_data_split", choices=["val", "test"], default="test")
+    ap.add_argument("--data_split", choices=["val", "test"], default=None)  # deprecated alias (configs/base.py:80-100)
     ap.add_argument("--merge_type", required=True)
     ap.add_argument("--learn_type", required=True)
     ap.add_argument("--ties_density", type=float, default=0.2)
@@ -77,9 +78,22 @@ def parse(argv=None):
     ap.add_argument("--item_embeddings_path", default=None)
     ap.add_argument("--user_embeddings_path", default=None)
     cfg, unknown = ap.parse_known_args(argv)
+    skip = False
     for u in unknown:
         if u.startswith("--lora"):
             print(f"note: {u} ignored (LoRA wrappers are outside the merged-inference path)")
+            skip = True      # its value, if any, follows
+        elif u.startswith("--"):
+            ap.error(f"unrecognized argument {u}")
+        elif not skip:
+            ap.error(f"unrecognized argument {u}")
+    if cfg.data_split is not None:  # configs/base.py:91-101: the alias never overrides test_data_split
+        import warnings
+
+        if cfg.test_data_split != cfg.data_split:
+            warnings.warn("data_split is set but does not match test_data_split. Using test_data_split for merging.", UserWarning)
+        else:
+            warnings.warn("data_split is deprecated and will be removed in future versions. Use test_data_split instead.", DeprecationWarning)
     cfg.model_type = cfg.model_type.upper()
     cfg.merge_type, cfg.learn_type = cfg.merge_type.upper(), cfg.learn_type.upper()
     cfg.metric_names = [m.upper() for m in cfg.metric_names]

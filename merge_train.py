@@ -85,7 +85,10 @@ def main(argv=None):
         weights_dir=_pop(argv, "--weights_dir", "weights"),
         skip_test=_pop(argv, "--skip_test", "false").lower() in ("1", "true", "yes"),
         result_path=_pop(argv, "--result_path", None),  # every rank saves its result dict to <result_path>.rank<r>.pt
+        loss_fn_kwargs=mt._kv(_pop(argv, "--loss_fn_kwargs", [], many=True)),  # configs/distill.py:14,32
     )
+    for unused in ("--patience", "--gradient_accumulation_steps"):  # declared by DistillConfig, read by nothing in merge_train.py
+        _pop(argv, unused)
     config = mt.parse(argv)
     from mergerec_amd.datamodule import DistillSequenceDataModule, DistillSequenceDataModuleForRecformer, load_tokenizer
     from mergerec_amd.evaluator import Evaluator
@@ -152,7 +155,7 @@ def main(argv=None):
         finetune_state_dicts=[{k: v for k, v in sd.items() if k != "item_embeddings"} for sd in finetune_state_dicts], ignore_keys=set(),
         ties_density=config.ties_density, disable_softmax=not config.use_softmax, initial_per_weight=opt["initial_per_weight"],
         placement="replicated")  # d loss / d alpha contracts the whole gradient with every task vector: data parallel, nothing sliced
-    kwargs = {"coefficient": opt["coefficient"]} if opt["loss_type"].endswith("_KD") else {}
+    kwargs = ({"coefficient": opt["coefficient"]} if opt["loss_type"].endswith("_KD") else {}) | opt["loss_fn_kwargs"]
     module = DistillSequenceModule(
         merged_model=merged_model, score_embeddings=score_embeddings,
         loss_fn=distill_loss_factory(LossType[opt["loss_type"]], temperature=opt["temperature"], **kwargs), learning_rate=opt["learning_rate"],
