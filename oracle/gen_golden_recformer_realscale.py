@@ -29,6 +29,12 @@ N_ITEMS, N_USERS, U_KEEP, E_STRIDE, SEED_DOMAIN = 4968, 1024, 256, 8, 41000
 SEED_PRE, SEED_FT = 3000, (3001, 3002, 3003)
 ALPHAS = (0.42, 0.31, 0.27)
 MAX_SEQ_LEN = 1024
+# `python oracle/gen_golden_recformer_realscale.py large`: Recformer-LARGE (24 x 1,024, 16 heads, 435 M parameters: BASELINE configs[4]'s
+# model) on a smaller sample (2,048 items, 512 users) -> tests/golden/g15_realscale_recformer_large.pt
+LARGE = len(sys.argv) > 1 and sys.argv[1] == "large"
+if LARGE:
+    N_ITEMS, N_USERS, SEED_DOMAIN = 2048, 512, 42000
+    SEED_PRE, SEED_FT = 4000, (4001, 4002, 4003)
 
 
 def main():
@@ -48,7 +54,8 @@ def main():
     from transformers import LongformerConfig
 
     rm = GG.load_by_path("_ref_recformer_models", GG.REF / "rec_retrieval/module/models/encoder/recformer/models.py")
-    cfg = O.EncoderConfig(max_pos=4098, token_type_size=4, max_item_embeddings=51, one_sided_window=32)
+    cfg = O.EncoderConfig(max_pos=4098, token_type_size=4, max_item_embeddings=51, one_sided_window=32,
+                          **(dict(hidden=1024, heads=16, layers=24, intermediate=4096) if LARGE else {}))
     t0 = time.time()
     hc = LongformerConfig(attention_window=[2 * cfg.one_sided_window] * cfg.layers, vocab_size=cfg.vocab, hidden_size=cfg.hidden,
                           num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, intermediate_size=cfg.intermediate,
@@ -127,7 +134,8 @@ def main():
                label_score=lab_score.clone(), label_window=label_window, metrics={k: float(v) for k, v in metrics.items()}, loss=loss,
                longest_sequence=int(seq_lens.max()),
                versions=dict(torch=str(torch.__version__), transformers=str(__import__("transformers").__version__)))
-    path = ROOT / "tests" / "golden" / "g14_realscale_recformer_base.pt"
+    out["encoder"] = dict(hidden=cfg.hidden, heads=cfg.heads, layers=cfg.layers, intermediate=cfg.intermediate)
+    path = ROOT / "tests" / "golden" / ("g15_realscale_recformer_large.pt" if LARGE else "g14_realscale_recformer_base.pt")
     torch.save(out, path)
     print("saved", path, path.stat().st_size, metrics, "loss", loss, "longest sequence", int(seq_lens.max()), f"{time.time() - t0:.0f}s")
 
