@@ -1,6 +1,8 @@
 """north_star's accuracy clause for the second model family at true dimensions: BASELINE configs[2] -- a 3-domain task-vector merge of
 Recformer-base (Longformer-base geometry, 148 M parameters; windowed + global attention, token-type and item-position embeddings) --
-evaluated on a Pantry-sized domain (4,968 items, 1,024 users with sequences up to 1,024 tokens).
+evaluated on a Pantry-sized domain (4,968 items, 1,024 users with sequences up to 1,024 tokens); and the same for Recformer-LARGE
+(24 x 1,024, 435 M parameters: BASELINE configs[4]'s model) on 2,048 items and 512 users (fixture g15), and for BLaIR-LARGE (RoBERTa-large
+geometry, 355 M parameters: `--model_type blair_large` of the reference's scripts; 2-domain merge; fixture g16).
 
 Fixture: tests/golden/g14_realscale_recformer_base.pt, produced in the build container by oracle/gen_golden_recformer_realscale.py from the
 reference itself (its load_merging_module / get_state_dict, its RecformerModel driving transformers' LongformerEncoder, user @ item.T, its
@@ -21,21 +23,28 @@ NEAR_TIE = 2e-6        # two items whose REFERENCE scores are this close may swa
 NDCG_TOL = 1e-3        # north_star
 
 
-@pytest.fixture(scope="module")
-def setup():
+SIZES = {"recformer_base": ("g14_realscale_recformer_base.pt", "RECFORMER_BASE"), "recformer_large": ("g15_realscale_recformer_large.pt", "RECFORMER_LARGE"),
+         "blair_large": ("g16_realscale_blair_large.pt", "BLAIR_LARGE")}   # (BLaIR-base: tests/test_realscale_gpu.py, tests/test_8domain_gpu.py)
+
+
+@pytest.fixture(scope="module", params=list(SIZES))
+def setup(request):
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
     from mergerec_amd.model_batch import BatchSequence
     from mergerec_amd.module import ModelType
     from mergerec_amd.synthetic import make_domain
 
-    fx = load_golden("g14_realscale_recformer_base.pt")
-    cfg = O.EncoderConfig(max_pos=4098, token_type_size=4, max_item_embeddings=51, one_sided_window=32)
-    pre0 = O.random_state_dict(O.recformer_param_shapes(cfg), seed=fx["seed_pre"], std=0.02)
+    fixture_name, model_type = SIZES[request.param]
+    fx = load_golden(fixture_name)
+    enc = fx.get("encoder", {})
+    rec = model_type.startswith("RECFORMER")
+    cfg = O.EncoderConfig(max_pos=4098, token_type_size=4, max_item_embeddings=51, one_sided_window=32, **enc) if rec else O.EncoderConfig(**enc)
+    pre0 = O.random_state_dict(O.recformer_param_shapes(cfg) if rec else O.roberta_param_shapes(cfg), seed=fx["seed_pre"], std=0.02)
     pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])  # the reference model's key order (perturbations are drawn along it)
     fsum = lambda sd: float(sum(v.double().sum() for v in sd.values() if v.is_floating_point()))
     assert abs(fsum(pre) - fx["pre_checksum"]) < 1e-6 * abs(fx["pre_checksum"]) + 1e-9
     fts = [O.perturbed_state_dict(pre, seed=s, std=fx["ft_std"]) for s in fx["seed_ft"]]
-    model = ModelType.RECFORMER_BASE.value(model_kwargs={"init_seed": 0, "device": DEV})
+    model = ModelType[model_type].value(model_kwargs={"init_seed": 0, "device": DEV})
     model.load_state_dict(pre)
     mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, pre, fts, set(), disable_softmax=True)  # merge_test.py:35-71
     mm.load_weights_from_dict({"global_weights": {"all": [1.0]}, "global_biases": {"all": [0.0]}, "per_weights": {"all": list(fx["alphas"])}})
@@ -43,24 +52,26 @@ def setup():
     assert abs(fsum(sd) - fx["merged_checksum"]) < 1e-9 * max(1.0, abs(fx["merged_checksum"])) + 1e-5, (fsum(sd), fx["merged_checksum"])
     del mm, model, fts
     torch.cuda.empty_cache()
-    dom = make_domain("Pantry", fx["n_items"], fx["n_users"], 32, cfg.vocab, fx["seed_domain"], kind="recformer", max_seq_len=fx["max_seq_len"])
+    dom = make_domain("Pantry", fx["n_items"], fx["n_users"], 32, cfg.vocab, fx["seed_domain"], kind="recformer" if rec else "roberta",
+                      max_seq_len=fx.get("max_seq_len", 512))
     seqs, at = [], 0
     for b in dom.sequence_batches:  # the fixture's labels (the reference's rank-derived items) replace the generator's random ones
         n = b.labels.numel()
         seqs.append(BatchSequence(sequence=b.sequence, labels=fx["labels"][at:at + n].clone()))
         at += n
-    assert int(torch.cat([b.sequence["attention_mask"].sum(1) for b in seqs]).max()) == fx["longest_sequence"]
-    return fx, sd, dom.item_batches, seqs
+    if "longest_sequence" in fx:
+        assert int(torch.cat([b.sequence["attention_mask"].sum(1) for b in seqs]).max()) == fx["longest_sequence"]
+    return fx, sd, dom.item_batches, seqs, model_type
 
 
 @pytest.mark.parametrize("mode,precision", [("bf16x3", "bf16-mixed"), ("f32", "32-true")])
-def test_recformer_base_logits_ranks_and_ndcg_match_the_reference(setup, mode, precision, tmp_path):
+def test_logits_ranks_and_ndcg_match_the_reference(setup, mode, precision, tmp_path):
     from mergerec_amd.evaluator import Evaluator
     from mergerec_amd.module import ModelType, RecModule
     from mergerec_amd.utils import test_model_on_dataloaders
 
-    fx, sd, item_batches, seq_batches = setup
-    model = ModelType.RECFORMER_BASE.value(model_kwargs={"init_seed": 0, "device": DEV, "gemm_mode": mode})
+    fx, sd, item_batches, seq_batches, model_type = setup
+    model = ModelType[model_type].value(model_kwargs={"init_seed": 0, "device": DEV, "gemm_mode": mode})
     model.load_state_dict(sd)  # merge_test.py:71-80
     module = RecModule(model=model, evaluator=Evaluator(["NDCG", "RECALL"], fx["ks"]), similarity="cosine")
     _, metrics, scores, labels = test_model_on_dataloaders(module, [item_batches], [seq_batches], ["Pantry"], precision=precision,
@@ -102,5 +113,5 @@ def test_recformer_base_logits_ranks_and_ndcg_match_the_reference(setup, mode, p
         assert abs(metrics[0][k] - must[k]) < 5e-6 + slack[k], (k, metrics[0][k], must[k], slack[k])
         assert abs(metrics[0][k] - v) <= NDCG_TOL, (k, metrics[0][k], v)
     assert abs(metrics[0]["test/loss"] - fx["loss"]) < 1e-3
-    print(f"[recformer-base {mode}] logit max err {logit_err:.2e}; top-50 positions differing (all near-ties) {int(diff.sum())}; labels moved "
+    print(f"[{model_type.lower()} {mode}] logit max err {logit_err:.2e}; top-50 positions differing (all near-ties) {int(diff.sum())}; labels moved "
           f"{int((my_rank != ref_rank).sum())}; NDCG@10 {metrics[0]['test/NDCG@10']:.4f} (reference {fx['metrics']['test/NDCG@10']:.4f})")
