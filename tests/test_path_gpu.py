@@ -691,3 +691,58 @@ def test_ties_vectors_at_full_model_size_match_the_reference():
     assert n_amb < 1000, n_amb  # a handful of positions out of 8 x 125 M
     print(f"[ties full size] positions tied at a trimming threshold: {n_amb}; survivors per model equal to the reference's within that; "
           f"{int(clear.sum())} of {pos.numel()} sampled positions compared bit for bit")
+
+
+def test_lns_and_pcb_vectors_at_full_model_size_match_the_reference():
+    """8(f).1 at size (fixture g18, oracle/gen_golden_lns_pcb_fullsize.py; same inputs as g17): Localize-and-Stitch (8 models, density 0.05)
+    and PCB (4 models, density 0.2) on P = 124,645,632.  L&S trims with torch.topk like TIES, so positions on a model's trimming threshold
+    are excluded from the exact comparison; PCB is a chain of sorts, clamps, exp and tanh in fp32 -- compared to the tolerance of the g6
+    test, relative to the largest entry."""
+    from mergerec_amd import ops
+
+    fx = load_golden("g18_lns_pcb_fullsize.pt")
+    P, N = fx["P"], fx["N"]
+    g = torch.Generator().manual_seed(fx["seed"])
+    base = torch.randn(P, generator=g) * 0.02
+    tv = torch.empty(N, P, dtype=torch.float32, device=DEV)
+    for i in range(N):
+        tv[i] = ((base + torch.randn(P, generator=g) * 1e-3) - base).to(DEV)
+    pos = fx["sample_pos"].to(DEV)
+    # ---- PCB first (it reads the untouched task vectors of the first models)
+    n_pcb = fx["pcb_models"]
+    got = ops.pcb_vectors(tv[:n_pcb].contiguous(), fx["pcb_density"])
+    ref = fx["pcb"]
+    scale = float(ref["sample"].abs().max())
+    for i in range(n_pcb):
+        assert float((got[i][pos].cpu() - ref["sample"][i]).abs().max()) <= 2e-4 * scale, i
+        assert abs(float(got[i].double().abs().sum()) - ref["abs_sum"][i]) <= 2e-4 * ref["abs_sum"][i], i
+        assert abs(int((got[i] != 0).sum()) - ref["nnz"][i]) <= 1e-4 * P, (i, int((got[i] != 0).sum()), ref["nnz"][i])
+    del got
+    # ---- Localize-and-Stitch
+    k = int(fx["lns_density"] * P)
+    masks = torch.empty(N, P, dtype=torch.uint8, device=DEV)
+    ambiguous = torch.zeros(P, dtype=torch.bool, device=DEV)
+    thr = torch.empty(1, dtype=torch.float32, device=DEV)
+    n_amb, thr_max = 0, 0.0
+    scratch = torch.empty(P, dtype=torch.float32, device=DEV)
+    for i in range(N):
+        a = tv[i].abs()
+        ops.kth_largest_value(tv[i], k, False, thr)
+        at_thr = a == thr
+        if int(at_thr.sum()) != k - int((a > thr).sum()):
+            ambiguous |= at_thr
+            n_amb += int(at_thr.sum())
+            thr_max = max(thr_max, float(thr))
+        _, m = ops.abs_topk_mask(tv[i], k, out=scratch, want_mask=True)
+        masks[i] = m
+    got = ops.lns_combine(tv, masks)
+    ref = fx["lns"]
+    clear = ~ambiguous[pos]
+    for i in range(N):
+        assert abs(int((got[i] != 0).sum()) - ref["nnz"][i]) <= n_amb, (i, n_amb)
+        assert torch.equal(got[i][pos][clear].cpu(), ref["sample"][i][clear.cpu()]), i
+        slack = n_amb * thr_max + 1e-9 * ref["abs_sum"][i]
+        assert abs(float(got[i].double().sum()) - ref["sum"][i]) <= slack and abs(float(got[i].double().abs().sum()) - ref["abs_sum"][i]) <= slack, i
+    assert n_amb < 1000, n_amb
+    print(f"[lns / pcb full size] L&S: {n_amb} positions tied at a trimming threshold, {int(clear.sum())} of {pos.numel()} sampled positions bit for bit; "
+          f"PCB: sampled values within 2e-4 of the largest entry")
