@@ -406,3 +406,55 @@ def test_whole_merge_train_step_at_real_dimensions_matches_reference(case):
             assert float((got - want).abs().max()) <= 5e-3 * scale, (name, k, got, want)
     print(f"[merge_train step, BLaIR-base x 8 domains, {c['learn_type']}] loss {float(loss):.6f} (reference {float(c['loss']):.6f}); "
           f"worst gradient deviation {worst:.1e} of the group's largest entry")
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_whole_merge_train_step_recformer_large_matches_reference(case):
+    """g20 (oracle/gen_golden_merge_train_recformer_large.py): BASELINE configs[4]'s model and job -- one collaborative-merging step of the
+    reference with Recformer-LARGE (24 x 1,024, 435 M parameters; its own RecformerModel driving transformers' LongformerEncoder) and 4
+    fine-tuned checkpoints on the CPU (8 exceed the build container's memory) -- loss and d loss / d (per_weights, global_weights, global_biases), task-wise and layer-wise (25
+    groups), against the HIP step."""
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchDistillationSequence
+    from mergerec_amd.module import DistillSequenceModule, ModelType
+    from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
+
+    fx = load_golden("g20_merge_train_step_recformer_large.pt")
+    c = fx["cases"][case]
+    cfg = O.EncoderConfig(**{k: v for k, v in fx["cfg"].items() if k in O.EncoderConfig.__dataclass_fields__})
+    pre0 = O.random_state_dict(O.recformer_param_shapes(cfg), seed=fx["pretrain_seed"], std=fx["pretrain_std"])
+    pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])
+    fsum = lambda sds: float(sum(v.double().sum() for sd in sds for v in sd.values() if v.is_floating_point()))
+    assert abs(fsum([pre]) - fx["pretrain_checksum"]) < 1e-6 * abs(fx["pretrain_checksum"]) + 1e-9
+    fts = [O.perturbed_state_dict(pre, seed=s, std=fx["finetune_std"]) for s in fx["finetune_seeds"]]
+    assert abs(fsum(fts) - fx["finetune_checksum"]) < 1e-6 * abs(fx["finetune_checksum"]) + 1e-6
+    g = torch.Generator().manual_seed(fx["data_seed"])
+    B, L = fx["batch"]
+    torch.randint(3, L + 1, (B,), generator=g)            # (the generator's stream: lengths, ids, items, teachers)
+    torch.randint(3, cfg.vocab, (B, L), generator=g)
+    items = [torch.nn.functional.normalize(torch.randn(m, cfg.hidden, generator=g), dim=-1) for m in fx["catalog_sizes"]]
+    teachers = [torch.randn(B, m, generator=g).clamp(-1, 1) for m in fx["catalog_sizes"]]
+    assert abs(float(sum(x.double().sum() for x in items)) - fx["item_checksum"]) < 1e-6 * abs(fx["item_checksum"]) + 1e-6
+    assert abs(float(sum(x.double().sum() for x in teachers)) - fx["teacher_checksum"]) < 1e-6 * abs(fx["teacher_checksum"]) + 1e-6
+    model = ModelType.RECFORMER_LARGE.value(model_kwargs={"init_seed": 1, "device": DEV})
+    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[c["learn_type"]], model, pre, [dict(f) for f in fts], set(),
+                             disable_softmax=True, initial_per_weight=fx["initial_per_weight"])
+    del fts
+    assert list(mm.per_weights.keys()) == c["groups"]
+    mod = DistillSequenceModule(mm, teachers, SinglePseudoLabelKDLoss(fx["temperature"], fx["coefficient"]), "cosine")
+    mod.item_embeddings = items
+    seq = {k: fx[k] for k in ("input_ids", "attention_mask", "token_type_ids", "item_position_ids", "global_attention_mask")}
+    batch = BatchDistillationSequence(dataset_indexes=fx["dataset_indexes"], sequence_ids=torch.tensor(fx["sequence_ids"]), sequence=seq)
+    mod.train()
+    loss = mod.training_step(batch.to(DEV), 0)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), c["loss"], rtol=5e-5, atol=5e-5)
+    worst = 0.0
+    for name in ("per_weights", "global_weights", "global_biases"):
+        for k in c["groups"]:
+            want, got = c["grads"][name][k], getattr(mm, name)[k].grad.cpu()
+            scale = max(float(want.abs().max()), 1e-3)
+            worst = max(worst, float((got - want).abs().max()) / scale)
+            assert float((got - want).abs().max()) <= 5e-3 * scale, (name, k, got, want)
+    print(f"[merge_train step, Recformer-large x 4 domains, {c['learn_type']}] loss {float(loss):.6f} (reference {float(c['loss']):.6f}); "
+          f"worst gradient deviation {worst:.1e} of the group's largest entry")
