@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu as O
-from tests.conftest import load_golden
+from tests.conftest import heavy, load_golden
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -27,7 +27,7 @@ SIZES = {"recformer_base": ("g14_realscale_recformer_base.pt", "RECFORMER_BASE")
          "blair_large": ("g16_realscale_blair_large.pt", "BLAIR_LARGE")}   # (BLaIR-base: tests/test_realscale_gpu.py, tests/test_8domain_gpu.py)
 
 
-@pytest.fixture(scope="module", params=list(SIZES))
+@pytest.fixture(scope="module", params=["recformer_base", pytest.param("recformer_large", marks=heavy), pytest.param("blair_large", marks=heavy)])
 def setup(request):
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
     from mergerec_amd.model_batch import BatchSequence

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu as O
-from tests.conftest import load_golden
+from tests.conftest import heavy, load_golden
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -356,18 +356,10 @@ def test_whole_merge_train_step_matches_reference(case):
             assert float((got - want).abs().max()) <= 5e-3 * scale, (name, k, got, want)
 
 
-@pytest.mark.parametrize("case", [0, 1])
-def test_whole_merge_train_step_at_real_dimensions_matches_reference(case):
-    """g19 (oracle/gen_golden_merge_train_realscale.py): the reference's collaborative-merging step at BLaIR-base's TRUE dimensions with 8
-    fine-tuned checkpoints (a 4 GB task-vector matrix under torch autograd on the CPU), 16 pseudo users, the eight real catalog sizes --
-    loss and d loss / d (per_weights, global_weights, global_biases), task-wise and layer-wise (13 groups), against the HIP step."""
-    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
-    from mergerec_amd.model_batch import BatchDistillationSequence
-    from mergerec_amd.module import DistillSequenceModule, ModelType
-    from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
-
+@pytest.fixture(scope="module")
+def g19_inputs():
+    """the regenerated inputs of fixture g19 (pretrained + 8 fine-tuned state dicts, item matrices, teacher scores), once for both cases"""
     fx = load_golden("g19_merge_train_step_realscale.pt")
-    c = fx["cases"][case]
     cfg = O.EncoderConfig()
     pre0 = O.random_state_dict(O.roberta_param_shapes(cfg), seed=fx["pretrain_seed"], std=fx["pretrain_std"])
     pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])
@@ -378,16 +370,30 @@ def test_whole_merge_train_step_at_real_dimensions_matches_reference(case):
     g = torch.Generator().manual_seed(fx["data_seed"])
     B, L = fx["batch"]
     lens = torch.randint(3, L + 1, (B,), generator=g)
-    ids = torch.randint(3, cfg.vocab, (B, L), generator=g)
+    torch.randint(3, cfg.vocab, (B, L), generator=g)
     assert torch.equal(((torch.arange(L).view(1, L) < lens.view(B, 1)).long()), fx["attention_mask"])
     items = [torch.nn.functional.normalize(torch.randn(m, cfg.hidden, generator=g), dim=-1) for m in fx["catalog_sizes"]]
     teachers = [torch.randn(B, m, generator=g).clamp(-1, 1) for m in fx["catalog_sizes"]]
     assert abs(float(sum(x.double().sum() for x in items)) - fx["item_checksum"]) < 1e-6 * abs(fx["item_checksum"]) + 1e-6
     assert abs(float(sum(x.double().sum() for x in teachers)) - fx["teacher_checksum"]) < 1e-6 * abs(fx["teacher_checksum"]) + 1e-6
+    return fx, pre, fts, items, teachers
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_whole_merge_train_step_at_real_dimensions_matches_reference(g19_inputs, case):
+    """g19 (oracle/gen_golden_merge_train_realscale.py): the reference's collaborative-merging step at BLaIR-base's TRUE dimensions with 8
+    fine-tuned checkpoints (a 4 GB task-vector matrix under torch autograd on the CPU), 16 pseudo users, the eight real catalog sizes --
+    loss and d loss / d (per_weights, global_weights, global_biases), task-wise and layer-wise (13 groups), against the HIP step."""
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchDistillationSequence
+    from mergerec_amd.module import DistillSequenceModule, ModelType
+    from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
+
+    fx, pre, fts, items, teachers = g19_inputs
+    c = fx["cases"][case]
     model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 1, "device": DEV})
     mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[c["learn_type"]], model, pre, [dict(f) for f in fts], set(),
                              disable_softmax=True, initial_per_weight=fx["initial_per_weight"])
-    del fts
     assert list(mm.per_weights.keys()) == c["groups"]
     mod = DistillSequenceModule(mm, teachers, SinglePseudoLabelKDLoss(fx["temperature"], fx["coefficient"]), "cosine")
     mod.item_embeddings = items
@@ -404,10 +410,11 @@ def test_whole_merge_train_step_at_real_dimensions_matches_reference(case):
             scale = max(float(want.abs().max()), 1e-3)
             worst = max(worst, float((got - want).abs().max()) / scale)
             assert float((got - want).abs().max()) <= 5e-3 * scale, (name, k, got, want)
-    print(f"[merge_train step, BLaIR-base x 8 domains, {c['learn_type']}] loss {float(loss):.6f} (reference {float(c['loss']):.6f}); "
+    print(f"[merge_train step, BLaIR-base x 8 domains, {c['learn_type']}] loss {float(loss.detach()):.6f} (reference {float(c['loss']):.6f}); "
           f"worst gradient deviation {worst:.1e} of the group's largest entry")
 
 
+@heavy
 @pytest.mark.parametrize("case", [0, 1])
 def test_whole_merge_train_step_recformer_large_matches_reference(case):
     """g20 (oracle/gen_golden_merge_train_recformer_large.py): BASELINE configs[4]'s model and job -- one collaborative-merging step of the
