@@ -463,5 +463,5 @@ def test_whole_merge_train_step_recformer_large_matches_reference(case):
             scale = max(float(want.abs().max()), 1e-3)
             worst = max(worst, float((got - want).abs().max()) / scale)
             assert float((got - want).abs().max()) <= 5e-3 * scale, (name, k, got, want)
-    print(f"[merge_train step, Recformer-large x 4 domains, {c['learn_type']}] loss {float(loss):.6f} (reference {float(c['loss']):.6f}); "
+    print(f"[merge_train step, Recformer-large x 4 domains, {c['learn_type']}] loss {float(loss.detach()):.6f} (reference {float(c['loss']):.6f}); "
           f"worst gradient deviation {worst:.1e} of the group's largest entry")
