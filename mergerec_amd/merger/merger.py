@@ -1,7 +1,7 @@
 """``ModelMerger``: the fixed-weight merges of rec_retrieval/merger/merger.py:10-110 on device-resident parameter arenas.
 
-Same constructor and ``merge(merge_type, weights)`` surface as the reference; "task_vector" and "linear" run as one streaming HIP
-pass each (``mr_merge_running_f32``: the reference's running sum in model order, every operation rounded on its own, so the result
+Same constructor and ``merge(merge_type, weights, **kwargs)`` surface as the reference ("linear", "task_vector", "ties", "dare", "pcb");
+"task_vector" and "linear" run as one streaming HIP pass each (``mr_merge_running_f32``: the reference's running sum in model order, every operation rounded on its own, so the result
 is bit-for-bit the reference's).  The learnable-alpha path (``load_merging_module``) is the one merge_test.py uses; this class is
 the reference's stand-alone merger kept for callers that hold N state dicts and a weight list."""
 from __future__ import annotations
@@ -67,12 +67,75 @@ class ModelMerger:
             if self.base_model is None:
                 raise ValueError("Task vector merge requires a base model.")
             flat = ops.merge_running(self.base_model, self.models, w)
-        elif merge_type in ("ties", "dare", "pcb"):
+        elif merge_type == "ties":
             if self.base_model is None:
-                raise ValueError(f"{merge_type.upper() if merge_type != 'dare' else 'DARE'} merge requires a base model.")
-            raise NotImplementedError(f"ModelMerger.merge('{merge_type}') is not built: the TIES / PCB task vectors are built on the device by "
-                                      "load_merging_module(MergeType.TIES | PCB, ...), the path the reference's scripts use; DARE draws torch "
-                                      "dropout masks and has no entry script")
+                raise ValueError("TIES merge requires a base model.")
+            flat = self._merge_ties(weights, **kwargs)
+        elif merge_type == "dare":
+            if self.base_model is None:
+                raise ValueError("DARE merge requires a base model.")
+            flat = self._merge_dare(weights, **kwargs)
+        elif merge_type == "pcb":
+            if self.base_model is None:
+                raise ValueError("PCB merge requires a base model.")
+            flat = self._merge_pcb(w, **kwargs)
         else:
             raise ValueError(f"Merge type '{merge_type}' is not supported.")
         return self.layout.views(flat)  # unflatten_model (model_operations.py:66-90): named views, zero-copy
+
+    # ---- the three merges that pre-process the task vectors (every one needs a base model; `density` as in the reference's signatures)
+    def _scatter_compact(self, compact: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """(P,) in the reference's flat order -> arena layout (pads stay as they are in ``out``)"""
+        off = 0
+        for k, shp in self.layout.shapes.items():
+            cnt = 1
+            for x_ in shp:
+                cnt *= x_
+            out[self.layout.offsets[k]: self.layout.offsets[k] + cnt] = compact[off: off + cnt]
+            off += cnt
+        return out
+
+    def _merge_ties(self, weights: List[float], density: float, **__) -> torch.Tensor:
+        """algorithms/ties.py:74-83 (merge_ties): base + sum_i top-k_{|.|}(w_i (theta_i - base)), k = int(density * numel) -- no sign
+        election on this path (that is get_ties_vectors, the learnable module's pre-processing).  The sum runs in model order."""
+        n, base = self.models.shape[0], self.base_model
+        k = int(density * self.layout.numel)
+        sparse = torch.empty_like(self.models)
+        for i in range(n):
+            ops.task_vector(self.models[i], base, out=sparse[i])
+            sparse[i].mul_(weights[i])                       # `update *= weights[i]` (ties.py:22-23): one fp32 product
+            ops.abs_topk_mask(sparse[i], k, out=sparse[i])   # ties at the k-th magnitude: lowest indices (torch.topk leaves them unspecified)
+        delta = ops.merge_running(None, sparse, torch.ones(n, dtype=torch.float32, device=sparse.device))  # torch.sum(dim=0): rows in order
+        return base + delta
+
+    def _merge_pcb(self, w: torch.Tensor, density: float = 0.2, **__) -> torch.Tensor:
+        """algorithms/pcb.py:60-72 (merge_pcb): merged = base; merged += w_i * pcb_i in model order.  The PCB vectors are order statistics
+        of each task vector, so they are computed on the compact (unpadded) vectors and scattered back."""
+        n, base = self.models.shape[0], self.base_model
+        tv = torch.stack([self.layout.compact(ops.task_vector(self.models[i], base)) for i in range(n)]).contiguous()
+        pcb = ops.pcb_vectors(tv, density)
+        arena = torch.zeros_like(self.models)
+        for i in range(n):
+            self._scatter_compact(pcb[i], arena[i])
+        # running sum `merged += w_i * v_i` from merged = base: the "task_vector" kernel on theta_i := base + v_i would round v_i away, so the
+        # sum runs as a linear running sum over [base, v_0, ...] with weights [1, w_0, ...] (1 * base is exact, 0 + base is exact)
+        rows = torch.cat([base.unsqueeze(0), arena])
+        return ops.merge_running(None, rows, torch.cat([torch.ones(1, dtype=torch.float32, device=w.device), w]))
+
+    def _merge_dare(self, weights: List[float], density: float, **__) -> torch.Tensor:
+        """algorithms/dare.py:8-33 (merge_dare): merged += dropout(w_i (theta_i - base), p=density, training=True) in model order.  The masks
+        come from torch's global CPU generator exactly as in the reference (one ``dropout`` call per model over the P flat elements, in the
+        reference's flat order), so a run seeded like the reference reproduces it; the arithmetic runs on the device."""
+        from torch.nn.functional import dropout
+
+        n, base = self.models.shape[0], self.base_model
+        P = self.layout.numel
+        upd = torch.empty_like(self.models)
+        for i in range(n):
+            ops.task_vector(self.models[i], base, out=upd[i])
+            upd[i].mul_(weights[i])
+            keep = dropout(torch.ones(P, dtype=torch.float32), p=density, training=True)       # 0 or 1 / (1 - p), the reference's draw
+            scale = self._scatter_compact(keep.to(upd.device), torch.zeros_like(base))
+            upd[i].mul_(scale)                                # x * (1 / (1 - p)) or x * 0: what dropout computes per element
+        rows = torch.cat([base.unsqueeze(0), upd])
+        return ops.merge_running(None, rows, torch.ones(n + 1, dtype=torch.float32, device=upd.device))

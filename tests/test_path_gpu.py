@@ -184,6 +184,34 @@ def test_model_merger_fixed_weight_merges_bit_exact():
     assert torch.equal(flat(head.merge("linear", [0.2, 0.3, 0.5])), g2["model_merger_linear"])
 
 
+def test_model_merger_ties_pcb_dare_match_reference():
+    """ModelMerger.merge("ties" | "pcb" | "dare", weights, density=...) against the reference's own ModelMerger on the g2 models (fixture g21,
+    oracle/gen_golden_model_merger.py): ties (trim, sum in model order) and dare (torch's dropout draws from the global CPU generator, seeded
+    as the reference was) bit for bit; pcb to the tolerance of its exp / tanh chain."""
+    from mergerec_amd.merger import ModelMerger
+
+    g2, g21 = load_golden("g2_merger.pt"), load_golden("g21_model_merger.pt")
+    pre = g2["pretrain"]
+    fts = [OrderedDict((k, ft[k]) for k in pre) for ft in g2["finetunes"]]
+    mg = ModelMerger(models=fts, base_model=pre, align_key_order=False, device=DEV)
+    flat = lambda sd: torch.cat([sd[k].reshape(-1).float() for k in pre]).cpu()
+    w = list(g21["weights"])
+    for name in ("ties", "ties_dense"):
+        c = g21["cases"][name]
+        got = flat(mg.merge("ties", w, **c["kwargs"]))
+        assert torch.equal(got, c["merged_flat"]), (name, (got - c["merged_flat"]).abs().max())
+    c = g21["cases"]["dare"]
+    torch.manual_seed(c["seed"])
+    got = flat(mg.merge("dare", w, **c["kwargs"]))
+    assert torch.equal(got, c["merged_flat"]), (got - c["merged_flat"]).abs().max()
+    c = g21["cases"]["pcb"]
+    got = flat(mg.merge("pcb", w, **c["kwargs"]))
+    assert torch.allclose(got, c["merged_flat"], rtol=2e-4, atol=1e-7), (got - c["merged_flat"]).abs().max()
+    for mt in ("ties", "dare", "pcb"):
+        with pytest.raises(ValueError, match="requires a base model"):
+            ModelMerger(models=fts, device=DEV).merge(mt, 0.5, density=0.2)
+
+
 def test_merging_module_errors_mirror_reference():
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
 
