@@ -390,6 +390,9 @@ def _main(real_stdout):
                 workload=f"{n_dom}-domain merged BLaIR-base (alpha=1/{n_dom}), full-catalog scoring, Arts-sized catalog",
                 domains_merged=n_dom, catalog_items=M, users_per_step_per_gpu=U_step, items_per_step_per_gpu=I_step,
                 avg_user_tokens=avg_user_tokens, avg_item_tokens=avg_item_tokens, topk=50, params=merged_model.layout.numel,
+                scoring_route=("fused (selection inside the scoring kernel, no score block)"
+                               if ops._lib.load().mr_score_topk_ws_bytes_ex(U_step, M, d, 50) < 4 * U_step * M else
+                               f"staged (scoring GEMM into a {4 * U_step * M / 1e6:.0f} MB cache-resident block + row select; mr_score_fused_mode auto)"),
                 path="product objects with defaults: load_merging_module -> RecModule.forward(BatchItem) / test_step(BatchSequence) / on_test_epoch_end; "
                      "input checks in the packing kernel, no per-step host sync",
                 parallelism=(f"dp{world}: " + ("task vectors + base sliced 1/N per rank, arena-slice merge + all-gather" if sliced else
