@@ -17,6 +17,7 @@ for m in $MODES; do
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$m -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --gemm-mode $m > $OUT/${RND}_bench_under_rocprof_$m.json 2> /tmp/prof_$m.err || { tail -5 /tmp/prof_$m.err; exit 1; }
   cp $(ls /tmp/prof_$m/*/*kernel_stats.csv | head -1) $OUT/${RND}_kernel_stats_$m.csv
   python3 $R/tools/trace_summary.py $(ls /tmp/prof_$m/*/*kernel_trace.csv | head -1) $OUT/${RND}_kernel_trace_by_grid_$m.csv
+  python3 $R/tools/timed_epoch_summary.py $(ls /tmp/prof_$m/*/*kernel_trace.csv | head -1) 10 $OUT/${RND}_bench_under_rocprof_$m.json $OUT/${RND}_kernel_timed_epoch_$m.json > /dev/null
   echo "rocprof stats $m done"
   rm -rf /tmp/pmcf_$m /tmp/pmcw_$m /tmp/pmcl_$m
   B="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-profile --gemm-mode $m"
