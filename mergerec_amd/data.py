@@ -13,7 +13,7 @@ three lines that write it from the reference's DataModule.  `synthetic:<Name>[:M
 from __future__ import annotations
 
 from pathlib import Path
-from typing import Dict, Iterator, List, Optional
+from typing import Dict, Iterator, Optional
 
 import torch
 

@@ -10,7 +10,6 @@ given (synthetic benchmarks).  Hub names fail loudly.
 """
 from __future__ import annotations
 
-import math
 import os
 from collections import OrderedDict
 from enum import Enum

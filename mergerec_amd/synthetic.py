@@ -6,9 +6,8 @@ The tensors have exactly the contract of the reference collators' output (int64,
 batch max; collator/recommender/recommender.py:27-32,91-100; utils/recformer_utils.py:45-113)."""
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional
 
 import torch
 
