@@ -1,5 +1,6 @@
 """ctypes binding of oracle/oracle_c.c (TEST INFRASTRUCTURE ONLY -- see oracle/ref_cpu.py header)."""
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 
@@ -17,7 +18,8 @@ def build():
 
 
 def _lib():
-    lib = ctypes.CDLL(str(build()))
+    override = os.environ.get("ORACLE_C_LIB")  # a sanitizer build of the same source (oracle/Makefile: asan)
+    lib = ctypes.CDLL(override if override else str(build()))
     return lib
 
 
