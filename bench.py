@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- sequences/sec of MergeRec's merged-model inference path on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver may launch it under
+torch.distributed.run (one rank per GPU, RCCL); called plainly with `--gpus N > 1` (no WORLD_SIZE in the environment) it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py <same args>` itself as a CHILD process -- before anything in this
+process touches the GPU -- relays rank 0's line and exits with the child's return code.  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json metric: "sequences/sec full-catalog scoring, 8-domain merged BLaIR-base"):
   8 synthetic fine-tuned BLaIR-base checkpoints (theta_pre ~ N(0, 0.02^2), tau_i ~ N(0, 1e-3^2)) merged with
@@ -153,6 +155,10 @@ def synth_state_dicts(model, n_dom, device, seed=1001):
 
 
 def main():
+    if "WORLD_SIZE" not in os.environ:
+        pre = parse()
+        if pre.gpus > 1:
+            raise SystemExit(spawn_ranks(pre))
     # rank 0 prints ONE JSON line on stdout: everything else that writes to file descriptor 1 while the bench runs -- the product
     # objects' progress prints ("Calculating task vectors..."), gloo's connection banner from C++ -- is sent to stderr instead
     sys.stdout.flush()
@@ -166,16 +172,46 @@ def main():
         real_stdout.flush()
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as a child process group and relay rank 0's
+    JSON line.  Runs BEFORE this process initialises the GPU (no HIP call, no torch.cuda.is_available()): the parent only waits.  No
+    retry; the return code is the launcher's (non-zero as soon as any rank failed)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface (the container hostname may not resolve)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    n_json = 0
+    for line in proc.stdout:  # rank 0 writes exactly one JSON line to fd 1; anything else a launcher might print goes to stderr
+        if line.startswith("{") and n_json == 0:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            n_json += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and n_json == 0:
+        sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no result line\n")
+        rc = 1
+    return rc
+
+
 def _main(real_stdout):
     args = parse()
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world_env == 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
 
     from mergerec_amd import ops, parallel
 
     rank, world = parallel.init_from_env(verbose=False)  # one rank per GPU; MERGEREC_DIST_BACKEND=gloo rehearses several ranks on one GPU
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     backend = dist.get_backend() if world > 1 else None
     dev = torch.device("cuda", torch.cuda.current_device())
 
@@ -399,6 +435,9 @@ def _main(real_stdout):
                                                "task vectors replicated, whole-arena merge per rank (no collective)")
                              + ", catalog rows sharded + all-gather, users data-parallel (token-balanced shards), label ranks gathered"),
             ),
+            # multi-GPU record: ranks of the RCCL communicator (backend "nccl" IS RCCL on ROCm; 0 = no communicator, e.g. N = 1 or a gloo rehearsal)
+            dist_backend=backend, rccl_ranks=(dist.get_world_size() if backend == "nccl" else 0),
+            merge_placement=("sliced" if sliced else "replicated") if world > 1 else "single",
             roofline=roofline, cpu_baseline=cpu_baseline, kernels=kernels, parity=parity,
             epoch_metrics_sample={k: round(v, 6) for k, v in list(metrics.items())[:3]},
         )

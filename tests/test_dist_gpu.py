@@ -142,3 +142,23 @@ def test_two_ranks_reproduce_single_process_at_true_dimensions(tmp_path):
         for name in ("item_embeddings", "user_embeddings", "topk", "labels", "scores", "mm_forward_cls"):
             assert a[name].shape == b[name].shape and torch.equal(a[name], b[name]), (key, name)
         assert a["metrics"] == b["metrics"], key
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT torch.distributed.run in the command (the driver's scaling invocation): the parent spawns
+    the ranks as a child process before touching the GPU, relays rank 0's single JSON line and exits with the child's code.  Two ranks
+    share the box's one GPU through gloo here; under "nccl" the same path reports rccl_ranks = N."""
+    import json
+
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0", MERGEREC_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["dist_backend"] == "gloo" and out["rccl_ranks"] == 0 and out["merge_placement"] == "sliced"
+    assert out["value"] > 0 and out["config"]["parallelism"].startswith("dp2")

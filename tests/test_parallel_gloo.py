@@ -218,3 +218,21 @@ def test_deal_rows_partitions_and_single_rank_is_identity():
     loader = load_domain("synthetic:Toy:20:10", vocab=300).item_dataloader(4)
     sh = ShardedLoader(loader)  # no process group: the loader itself
     assert sh.local is loader and sh.gather_rows(torch.ones(3)).tolist() == [1, 1, 1]
+
+
+def test_bench_gpus_n_spawns_children_and_returns_their_exit_code():
+    """`python bench.py --gpus 2` outside torch.distributed.run starts its own ranks as a child process (bench.spawn_ranks) and must not
+    paper over a rank that dies: with an unusable backend every rank fails at process-group creation (or, on a box without a GPU, at the
+    device binding before it), the parent prints no result line and exits with the launcher's non-zero code."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PYTHONPATH=str(root), MERGEREC_DIST_BACKEND="no-such-backend")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not r.stdout.strip(), (r.returncode, r.stdout[-500:])
+    assert "torch.distributed.run" in r.stderr or "ChildFailedError" in r.stderr or "elastic" in r.stderr
