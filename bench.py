@@ -48,7 +48,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def parse():
@@ -387,20 +387,37 @@ def _main(real_stdout):
         # records the sha of the kernel sources it profiled: a different sha here means the figure is STALE and is reported as such.
         traffic = traffic_raw = traffic_src = None
         traffic_stale = None
-        tpath = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_traffic_{gemm_mode}.json")
         src_sha = _sha16(sorted(glob.glob(os.path.join(ROOT, "mergerec_amd", "csrc", "*.hip"))))
-        if world == 1 and os.path.exists(tpath):
-            tj = json.load(open(tpath))
+
+        def committed(kind):  # newest committed reduction of that kind for this arithmetic (this round's if it exists)
+            for rnd in (PROFILE_ROUND, "r02"):
+                path = os.path.join(ROOT, "profiles", f"{rnd}_{kind}_{gemm_mode}.json")
+                if os.path.exists(path):
+                    return json.load(open(path)), f"profiles/{rnd}_{kind}_{gemm_mode}.json"
+            return None, None
+
+        tj, tname = committed("pmc_traffic") if world == 1 else (None, None)
+        if tj:
             t = tj.get(dom[0]) or tj.get(dom[0].split("/")[0])
             if t:
                 traffic = t["fetch_bytes_x2_per_launch"] + t["write_bytes_per_launch"]
                 traffic_raw = t["fetch_bytes_raw_per_launch"] + t["write_bytes_per_launch"]
-                traffic_src = f"profiles/{PROFILE_ROUND}_pmc_traffic_{gemm_mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+                traffic_src = f"{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
                 traffic_stale = tj.get("_csrc_sha16") != src_sha
+        # matrix-pipe occupancy of the same kernel from the committed SQ passes (tools/sq_pass.sh: SQ_VALU_MFMA_BUSY_CYCLES over
+        # GRBM_GUI_ACTIVE / 8 x 1024 SIMD-cycles, the wave-cycle split, the profiled clock) -- also only collectable outside the timed run
+        mfma_busy = None
+        sj, sname = committed("pmc_sq") if world == 1 else (None, None)
+        if sj:
+            q = sj.get(dom[0]) or sj.get(dom[0].split("/")[0])
+            if q and "mfma_busy" in q:
+                mfma_busy = dict(value=q["mfma_busy"], clock_ghz_under_profiler=q.get("clock_ghz"), mfma_tflops_executed=q.get("mfma_tflops_executed"),
+                                 wave_parked=q.get("wave_parked"), wave_issue_stall=q.get("wave_issue_stall"), wave_active=q.get("wave_active"),
+                                 source=f"{sname} (rocprofv3 --pmc SQ passes of bench.py)", stale=sj.get("_csrc_sha16") != src_sha)
         roofline = dict(kernel=dom[0], **{k: dom[1][k] for k in ("mfma_flops_per_algorithmic_flop", "mfma_utilization") if k in dom[1]},
                         bound=dom[1]["bound"], achieved=dom[1]["achieved"], peak=dom[1]["peak"], unit=dom[1]["unit"], frac=dom[1]["frac"],
                         traffic=traffic, traffic_uncorrected=traffic_raw, traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
-                        traffic_stale=traffic_stale, csrc_sha16=src_sha,
+                        traffic_stale=traffic_stale, mfma_busy=mfma_busy, csrc_sha16=src_sha,
                         algorithmic_bytes_per_launch=summ[dom[0]]["bytes"] / max(dom[1]["launches"], 1),
                         algorithmic_flops_per_launch=summ[dom[0]]["flops"] / max(dom[1]["launches"], 1),
                         launches=dom[1]["launches"], avg_launch_ms=dom[1]["avg_ms"])

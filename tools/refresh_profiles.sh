@@ -3,7 +3,7 @@
 #   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh [modes...]'      (default mode list: bf16x3)
 # Everything large stays in /tmp; only the reduced summaries are written under gpurun_out/profiles/ (copy them to profiles/).
 set -o pipefail
-RND=r02
+RND=r03
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
