@@ -243,6 +243,21 @@ int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_
 int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh, int max_len,
                       float scale, int window, int products, float* ctx, mr_stream_t stream);
 
+/* Work-list form of mr_attn_split_f32 (same arguments otherwise, same masking rules, bit-identical output): the grid is a list of the
+ * (sequence, query block) pairs that exist instead of a (max_len / 128, H, B) box, so ragged batches launch no empty workgroups; a
+ * workgroup covers q_rows = mr_attn_split_q_rows(window, products) query rows (256 for full attention with products = 3: every wave owns
+ * two 32-row query tiles and K / V are staged once per 256 queries; 128 otherwise).
+ *   work (device int32, n_slots * 8 entries): entry [slot * 8 + x] = sequence | (query_block << 24), or -1 (padding).  Workgroup id
+ *   8 * (slot * H + head) + x reads entry (slot, x): the hardware deals workgroup ids to the 8 XCDs round-robin, so column x is XCD x's
+ *   queue and the query blocks of one (sequence, head) -- which read the same K / V rows -- share one L2.
+ * mr_attn_work_plan (HOST memory in and out, no GPU work) builds that list from the B sequence lengths: sequences by decreasing length,
+ * dealt over the 8 queues in snake order.  It returns n_slots; with work == NULL or capacity < n_slots * 8 nothing is written (size query).
+ * replaces: the same reference code as mr_attn_f32 (transformers RobertaSelfAttention / LongformerSelfAttention). */
+int mr_attn_split_q_rows(int window, int products);
+int64_t mr_attn_work_plan(const int64_t* lens_host, int B, int q_rows, int32_t* work_host, int64_t capacity);
+int mr_attn_split_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale,
+                           int window, int products, float* ctx, mr_stream_t stream);
+
 /* Global-token row of Longformer attention: for each sequence b, ctx[cu[b], :] =
  * softmax(qg_b kg^T * scale) vg over all tokens of b, where qg is (B, H*dh) (the global query of
  * each sequence's first token) and kvg is (T, 2*H*dh) = [k_global | v_global] per token.

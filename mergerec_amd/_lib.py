@@ -74,6 +74,9 @@ SIGNATURES = {
     "mr_layernorm_f32": (c_i, [c_p, c_i64, c_p, c_p, c_f, c_i, c_i, c_p, c_i64, c_p]),
     "mr_attn_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p]),
     "mr_attn_split_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p]),
+    "mr_attn_split_q_rows": (c_i, [c_i, c_i]),
+    "mr_attn_work_plan": (c_i64, [c_p, c_i, c_i, c_p, c_i64]),
+    "mr_attn_split_work_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_i, c_p, c_p]),
     "mr_attn_global_row_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "mr_cls_pool_normalize_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_p, c_p]),
     "mr_gather_rows_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_p, c_i64, c_p]),

@@ -18,6 +18,8 @@
 #include "common.h"
 #include <math.h>
 #include <stdint.h>
+#include <algorithm>
+#include <vector>
 
 // phase-timing hooks: empty in the library; exp/attn_phases.hip defines them (s_memtime deltas per phase)
 #ifndef MR_PH_DECL
@@ -302,6 +304,302 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Work-list form (r03).  One workgroup = QT * 128 query rows of one (sequence, head): every wave owns up to QT 32-row query tiles
+// (tile w and, for QT = 2, tile w + 4 of the block), so a staged 32-key K / V tile and every K / V fragment a wave reads from LDS
+// serve QT times the matrix work of attn_split_kernel; K and V of a sequence are split and written to LDS once per 256 queries
+// instead of once per 128.  The grid is a host-built list of the (sequence, query block) pairs that exist -- no empty workgroups --
+// dealt over the 8 XCD dispatch queues (workgroup id % 8) so that the blocks which read the same K / V sit in one XCD's L2,
+// heaviest sequences first.  K / V rows come through buffer loads whose range ends at the sequence's last row (rows past it read
+// as zeros and are masked as before): two vector adds per key tile instead of the clamped 64-bit row arithmetic.
+// Per (query row, key tile) the operations and their order are those of attn_split_kernel: results are bit-identical.
+template <int J>
+struct QIdx { static constexpr int value = J; };
+
+template <bool WINDOWED, int NP, int QT>
+__global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void attn_split_work_kernel(
+    const float* __restrict__ qkv, const int32_t* __restrict__ cu, const int32_t* __restrict__ work, int H, float scale_log2e,
+    int window, float* __restrict__ ctx) {
+    constexpr int BUFB = 2 * NP * KPIECE;  // K pieces, then V pieces
+    constexpr int QROWS = 128 * QT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUFB
+    const int id = blockIdx.x, slot = id >> 3;
+    const int e = slot / H, h = slot - e * H;
+    const int ent = __builtin_amdgcn_readfirstlane(work[e * 8 + (id & 7)]);
+    if (ent < 0) return;  // padding entry of a shorter XCD queue: the whole workgroup leaves together, before any barrier
+    const int b = ent & 0xffffff, q_base = (ent >> 24) * QROWS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int t0 = __builtin_amdgcn_readfirstlane(cu[b]), len = __builtin_amdgcn_readfirstlane(cu[b + 1]) - t0;
+    if (q_base >= len) return;
+    const int64_t ld = (int64_t)3 * H * kDh;
+    const float* __restrict__ Qb = qkv + (int64_t)t0 * ld + h * kDh;
+    const float* __restrict__ Kb = Qb + H * kDh;
+    const float* __restrict__ Vb = Qb + 2 * H * kDh;
+    const int rows = (len - q_base) < QROWS ? (len - q_base) : QROWS;
+    const int ntq = (rows + 31) >> 5;  // 32-row query tiles of this block: tile t belongs to wave t & 3
+
+    int q0[QT];
+    bool act[QT];  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        act[j] = wave + 4 * j < ntq;
+        q0[j] = q_base + 32 * (wave + 4 * j);
+    }
+
+    // Q pieces as the B operand of S^T = K Q^T: k-step s covers d = 16 s + 8 lh + j; pre-scaled by scale * log2(e)
+    u32x4 qp[QT][4][NP];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        if (act[j]) {
+            const int qi = q0[j] + lr;
+            const int qrow = qi < len ? qi : len - 1;
+            const float* qr = Qb + (int64_t)qrow * ld + 8 * lh;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float4 x0 = *reinterpret_cast<const float4*>(qr + 16 * s);
+                const float4 x1 = *reinterpret_cast<const float4*>(qr + 16 * s + 4);
+                const float x[8] = {x0.x * scale_log2e, x0.y * scale_log2e, x0.z * scale_log2e, x0.w * scale_log2e,
+                                    x1.x * scale_log2e, x1.y * scale_log2e, x1.z * scale_log2e, x1.w * scale_log2e};
+                split8<NP>(x, qp[j][s]);
+            }
+        }
+    }
+
+    // key-tile schedule of the workgroup
+    int k_lo = 0, k_hi = len;
+    if (WINDOWED) {
+        k_lo = q_base - window;
+        k_lo = k_lo < 0 ? 0 : (k_lo & ~31);
+        k_hi = q_base + rows - 1 + window + 1;
+        k_hi = k_hi > len ? len : k_hi;
+    }
+    const bool extra0 = WINDOWED && k_lo > 0;
+    const int ntiles = (k_hi - k_lo + 31) / 32 + (extra0 ? 1 : 0);
+    auto tile_base = [&](int it) { return extra0 ? (it == 0 ? 0 : k_lo + (it - 1) * 32) : k_lo + it * 32; };
+
+    // staging: thread -> (row sr / sr + 16, 4 consecutive d at sc) through range-checked buffer loads
+    const int sr = tid >> 4, sc4 = tid & 15;
+    const uint32_t ld4 = (uint32_t)ld * 4u;
+    const uint32_t span = (uint32_t)(len - 1) * ld4 + kDh * 4u;  // bytes from (row 0, d 0) of this head to the end of its last row
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Kb), 0, (int)span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vb), 0, (int)span, 0x00020000);
+    const uint32_t voff_t = (uint32_t)sr * ld4 + (uint32_t)sc4 * 16u;
+    u32x4 kreg0, kreg1, vreg0, vreg1;
+    auto gload = [&](int kb) {
+        const uint32_t o0 = (uint32_t)kb * ld4 + voff_t, o1 = o0 + 16u * ld4;
+        kreg0 = __builtin_amdgcn_raw_buffer_load_b128(krs, o0, 0, 0);
+        kreg1 = __builtin_amdgcn_raw_buffer_load_b128(krs, o1, 0, 0);
+        vreg0 = __builtin_amdgcn_raw_buffer_load_b128(vrs, o0, 0, 0);
+        vreg1 = __builtin_amdgcn_raw_buffer_load_b128(vrs, o1, 0, 0);
+    };
+    const int kw0 = sr * KROWB + ((((sc4 >> 1) ^ ((sr >> 1) & 7)) << 4) | ((sc4 & 1) << 3));
+    const int kw1 = (sr + 16) * KROWB + ((((sc4 >> 1) ^ (((sr + 16) >> 1) & 7)) << 4) | ((sc4 & 1) << 3));
+    auto store_k = [&](const u32x4 xb, unsigned char* dst) {
+        float r0 = __uint_as_float(xb[0]), r1 = __uint_as_float(xb[1]), r2 = __uint_as_float(xb[2]), r3 = __uint_as_float(xb[3]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uint32_t w0 = pack2(r0, r1), w1 = pack2(r2, r3);
+            *reinterpret_cast<uint2*>(dst + p * KPIECE) = make_uint2(w0, w1);
+            if (p + 1 < NP) { r0 -= lo_f(w0); r1 -= hi_f(w0); r2 -= lo_f(w1); r3 -= hi_f(w1); }
+        }
+    };
+    const int vw0 = sr * KROWB + ((((sc4 >> 1) ^ (((sr >> 1) & 1) << 2)) << 4) | ((sc4 & 1) << 3));
+    const int vw1 = vw0 + 16 * KROWB;
+    auto lstore = [&](unsigned char* buf) {
+        store_k(kreg0, buf + kw0);
+        store_k(kreg1, buf + kw1);
+        store_k(vreg0, buf + NP * KPIECE + vw0);
+        store_k(vreg1, buf + NP * KPIECE + vw1);
+    };
+    int vtr[2];
+    {
+        const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, g1 = (lane >> 4) & 1, bsw = (q >> 1) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            vtr[dt] = (4 * lh + q) * KROWB + ((4 * (dt ^ bsw) + 2 * g1 + (p4 >> 1)) << 4) + ((p4 & 1) << 3);
+    }
+    const int kswz = (lr >> 1) & 7;
+
+    float m[QT], l[QT];
+    f32x16 o[QT][2];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        m[j] = -INFINITY;
+        l[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[j][0][r] = 0.f; o[j][1][r] = 0.f; }
+    }
+
+    gload(tile_base(0));
+    lstore(lds);
+    __syncthreads();
+
+    for (int it = 0; it < ntiles; ++it) {
+        const unsigned char* buf = lds + (it & 1) * BUFB;
+        const int kb = tile_base(it);
+        gload(tile_base(it + 1 < ntiles ? it + 1 : it));  // unconditional: keeps the loads in flight under the math
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        bool rel[QT];
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+            rel[j] = act[j];
+            if (WINDOWED) rel[j] = rel[j] && (kb == 0 || (kb + 31 >= q0[j] - window && kb <= q0[j] + 31 + window));
+        }
+        const bool both = QT == 2 && rel[0] && rel[QT - 1];
+        if (rel[0] || rel[QT - 1]) {
+            // ---- S^T tiles = K Q^T: one read of the K fragments serves both query tiles
+            f32x16 s[QT];
+#pragma unroll
+            for (int j = 0; j < QT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
+            auto kfrag = [&](int st, u32x4 (&ka)[NP]) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    ka[p] = *reinterpret_cast<const u32x4*>(buf + p * KPIECE + lr * KROWB + (((2 * st + lh) ^ kswz) << 4));
+            };
+            if (both) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    u32x4 ka[NP];
+                    kfrag(st, ka);
+                    s[0] = mfma_split<NP>(ka, qp[0][st], s[0]);
+                    s[QT - 1] = mfma_split<NP>(ka, qp[QT - 1][st], s[QT - 1]);
+                }
+            } else if (rel[0]) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    u32x4 ka[NP];
+                    kfrag(st, ka);
+                    s[0] = mfma_split<NP>(ka, qp[0][st], s[0]);
+                }
+            } else {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    u32x4 ka[NP];
+                    kfrag(st, ka);
+                    s[QT - 1] = mfma_split<NP>(ka, qp[QT - 1][st], s[QT - 1]);
+                }
+            }
+            // ---- mask + online softmax (base 2) per query tile; s[r] is key kb + (r&3) + 8*(r>>2) + 4*lh for query q0 + lr
+            u32x4 pp[QT][2][NP];
+            auto softmax = [&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const int qi = q0[j] + lr;
+                float mx = -INFINITY;
+                if (!WINDOWED && kb + 32 <= len) {  // interior tile of full attention: every key valid, no masking work
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        bool ok = key < len;
+                        if (WINDOWED) {
+                            const int dlt = qi - key;
+                            ok = ok && (key == 0 || (dlt <= window && dlt >= -window));
+                        }
+                        s[j][r] = ok ? s[j][r] : -INFINITY;
+                        mx = fmaxf(mx, s[j][r]);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m[j], mx);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float corr =
+                    (m[j] == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : __builtin_amdgcn_exp2f(m[j] - m_use);
+                float ps = 0.f;
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = __builtin_amdgcn_exp2f(s[j][r] - m_use);  // raw v_exp_f32 (arguments <= 0; tiny results flush to 0)
+                    ps += pv[r];
+                }
+                ps += __shfl_xor(ps, 32, 64);
+                l[j] = l[j] * corr + ps;
+                m[j] = m_new;
+                if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0) {  // wave-uniform: the running maxima usually stop moving early
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[j][0][r] *= corr; o[j][1][r] *= corr; }
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const float x[8] = {pv[8 * st], pv[8 * st + 1], pv[8 * st + 2], pv[8 * st + 3],
+                                        pv[8 * st + 4], pv[8 * st + 5], pv[8 * st + 6], pv[8 * st + 7]};
+                    split8<NP>(x, pp[j][st]);
+                }
+            };
+            if (rel[0]) softmax(QIdx<0>{});
+            if (QT == 2 && rel[QT - 1]) softmax(QIdx<QT - 1>{});
+            // ---- O^T += V^T P^T: A operand element j of k-step st is V[kb + (j & 3) + 8 (2 st + (j >> 2)) + 4 lh][d]
+            const unsigned char* vbase = buf + NP * KPIECE;
+            auto vfrag = [&](int dt, int st, u32x4 (&va)[NP]) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const unsigned char* a0 = vbase + p * KPIECE + vtr[dt] + (16 * st) * KROWB;
+                    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                   (__attribute__((address_space(3))) s16x4*)a0));
+                    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                   (__attribute__((address_space(3))) s16x4*)(a0 + 8 * KROWB)));
+                    va[p][0] = lo.x; va[p][1] = lo.y; va[p][2] = hi.x; va[p][3] = hi.y;
+                }
+            };
+            if (both) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        u32x4 va[NP];
+                        vfrag(dt, st, va);
+                        o[0][dt] = mfma_split<NP>(va, pp[0][st], o[0][dt]);
+                        o[QT - 1][dt] = mfma_split<NP>(va, pp[QT - 1][st], o[QT - 1][dt]);
+                    }
+            } else if (rel[0]) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        u32x4 va[NP];
+                        vfrag(dt, st, va);
+                        o[0][dt] = mfma_split<NP>(va, pp[0][st], o[0][dt]);
+                    }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        u32x4 va[NP];
+                        vfrag(dt, st, va);
+                        o[QT - 1][dt] = mfma_split<NP>(va, pp[QT - 1][st], o[QT - 1][dt]);
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(lds + ((it + 1) & 1) * BUFB);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        const int qi = q0[j] + lr;
+        if (act[j] && qi < len && !(WINDOWED && qi == 0)) {
+            const float inv = 1.0f / l[j];
+            float* op = ctx + (int64_t)(t0 + qi) * ((int64_t)H * kDh) + h * kDh + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(op + 8 * g) = make_float4(o[j][0][4 * g] * inv, o[j][0][4 * g + 1] * inv,
+                                                                     o[j][0][4 * g + 2] * inv, o[j][0][4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(op + 32 + 8 * g) = make_float4(o[j][1][4 * g] * inv, o[j][1][4 * g + 1] * inv,
+                                                                          o[j][1][4 * g + 2] * inv, o[j][1][4 * g + 3] * inv);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh,
@@ -320,6 +618,60 @@ extern "C" int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, co
         if (products == 3) MR_ATTN_LAUNCH(true, 2); else MR_ATTN_LAUNCH(true, 3);
     } else {
         if (products == 3) MR_ATTN_LAUNCH(false, 2); else MR_ATTN_LAUNCH(false, 3);
+    }
+#undef MR_ATTN_LAUNCH
+    return mr::check_launch();
+}
+
+// ---- work-list form ------------------------------------------------------------------------------------------------------------
+extern "C" int mr_attn_split_q_rows(int window, int products) {
+    if (products != 3 && products != 6) return MR_EUNSUPPORTED;
+    return (products == 3 && window < 0) ? 256 : 128;
+}
+
+extern "C" int64_t mr_attn_work_plan(const int64_t* lens, int B, int q_rows, int32_t* work, int64_t capacity) {
+    // host side: lens[b] (host memory) -> work[n_slots][8] (host memory); returns n_slots, also when work == NULL or too small
+    // (then nothing is written: call again with n_slots * 8 entries); < 0 on bad arguments
+    if (B < 0 || (B > 0 && !lens) || (q_rows != 128 && q_rows != 256) || B > 0xffffff) return MR_EINVAL;
+    std::vector<int32_t> order((size_t)B);
+    for (int i = 0; i < B; ++i) {
+        order[(size_t)i] = i;
+        if (lens[i] < 0 || (lens[i] + q_rows - 1) / q_rows > 127) return MR_EINVAL;
+    }
+    // sequences by decreasing length (stable), dealt over the 8 queues in snake order: near-equal key-tile totals per queue
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t c) { return lens[a] > lens[c]; });
+    auto queue_of = [](int i) { return ((i >> 3) & 1) ? 7 - (i & 7) : (i & 7); };
+    int64_t qn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < B; ++i) qn[queue_of(i)] += (lens[order[(size_t)i]] + q_rows - 1) / q_rows;
+    const int64_t n_slots = *std::max_element(qn, qn + 8);
+    if (!work || capacity < n_slots * 8) return n_slots;
+    std::fill(work, work + n_slots * 8, -1);
+    int64_t fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < B; ++i) {
+        const int b = order[(size_t)i], x = queue_of(i);
+        const int nb = (int)((lens[b] + q_rows - 1) / q_rows);
+        for (int qb = 0; qb < nb; ++qb) work[(fill[x]++) * 8 + x] = b | (qb << 24);
+    }
+    return n_slots;
+}
+
+extern "C" int mr_attn_split_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh,
+                                      float scale, int window, int products, float* ctx, mr_stream_t stream) {
+    if (!qkv || !cu_seqlens || !ctx || n_slots < 0 || H < 1 || (n_slots > 0 && !work)) return MR_EINVAL;
+    if (dh != kDh || (products != 3 && products != 6)) return MR_EUNSUPPORTED;
+    if (!mr::aligned16(qkv) || !mr::aligned16(ctx)) return MR_EALIGN;
+    if (n_slots == 0) return MR_OK;
+    if (n_slots * 8 * (int64_t)H > 0x7fffffff) return MR_EINVAL;
+    const dim3 grid((unsigned)(n_slots * 8 * H));
+    const float scale_log2e = scale * 1.4426950408889634f;
+    hipStream_t st = (hipStream_t)stream;
+#define MR_ATTN_LAUNCH(W_, NP_, QT_)                                                                                          \
+    hipLaunchKernelGGL((attn_split_work_kernel<W_, NP_, QT_>), grid, dim3(kThreads), (size_t)2 * (2 * NP_ * KPIECE), st, qkv,   \
+                       cu_seqlens, work, H, scale_log2e, window, ctx)
+    if (window >= 0) {
+        if (products == 3) MR_ATTN_LAUNCH(true, 2, 1); else MR_ATTN_LAUNCH(true, 3, 1);
+    } else {
+        if (products == 3) MR_ATTN_LAUNCH(false, 2, 2); else MR_ATTN_LAUNCH(false, 3, 1);
     }
 #undef MR_ATTN_LAUNCH
     return mr::check_launch();

@@ -244,6 +244,7 @@ class PackedBatch:
     tok_ip: Optional[torch.Tensor] = None
     sum_len_sq: float = 0.0  # sum_b L_b^2 (algorithmic attention work, for the profiler)
     seq_order: Optional[torch.Tensor] = None  # int32 (B): sequence ids by decreasing length (attention scheduling hint)
+    attn_work: Optional[Dict[int, Tuple[torch.Tensor, int]]] = None  # q_rows -> (device int32 work list, n_slots): ops.attn_work_plan
 
 
 def _lens_from_mask(attention_mask: torch.Tensor) -> torch.Tensor:
@@ -321,7 +322,14 @@ class EncoderRunner:
                                            self.spec.vocab, self.spec.token_type_size, self.spec.max_item_embeddings)
         if validate == "now":
             self.check_inputs()
-        return PackedBatch(B=B, T=T, max_len=int(lens.max()) if B else 0, cu_seqlens=cu_d, cls_rows=cu_d[:-1].contiguous(),
+        # work lists of the split attention kernels (host-built from the lengths, ONE small copy for both block heights)
+        attn_work = None
+        if B:
+            plans = [ops.attn_work_plan(lens, q) for q in (128, 256)]
+            both = torch.cat([p[0] for p in plans]).to(device, non_blocking=True)
+            n128 = plans[0][0].numel()
+            attn_work = {128: (both[:n128], plans[0][1]), 256: (both[n128:], plans[1][1])}
+        return PackedBatch(B=B, T=T, max_len=int(lens.max()) if B else 0, cu_seqlens=cu_d, cls_rows=cu_d[:-1].contiguous(), attn_work=attn_work,
                            tok_word=tw, tok_pos=tp, tok_tt=ttp, tok_ip=tip, sum_len_sq=float((lens.double() ** 2).sum()) if B else 0.0,
                            seq_order=torch.argsort(lens, descending=True, stable=True).to(torch.int32).to(device, non_blocking=True) if B > 1 else None)
 
@@ -381,7 +389,7 @@ class EncoderRunner:
                 w_ = sp.one_sided_window
                 ops.ATTN_FLOPS_HINT[0] = 4.0 * sp.hidden * (pb.sum_len_sq if not rec else pb.T * (2 * w_ + 2))
             ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=sp.one_sided_window if rec else -1,
-                                seq_order=pb.seq_order, products={"f32": 0, "bf16x6": 6, "bf16x3": 3}[w.mode])
+                                seq_order=pb.seq_order, products={"f32": 0, "bf16x6": 6, "bf16x3": 3}[w.mode], work=pb.attn_work)
             if rec:
                 qg = self._proj(w, lp, ("query_global",), ops.gather_rows(x, pb.cls_rows))
                 kvg = self._proj(w, lp, ("key_global", "value_global"), x)

@@ -140,7 +140,7 @@ class EncoderTrainGraph:
                                   biases=[w[n + ".bias"] for n in names], out=qkv, products=3)
             # (bf16x3 mode: the split-precision attention of the inference path; its backward recomputes the probabilities in fp32)
             ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=self.window, seq_order=pb.seq_order,
-                                products=3 if self.mode == "bf16x3" else 0)
+                                products=3 if self.mode == "bf16x3" else 0, work=pb.attn_work)
             qg = kvg = None
             if self.rec:  # Longformer global row: CLS attends to every token through the *_global projections and overwrites ctx[cls]
                 x_cls = ops.gather_rows(x, pb.cls_rows)

@@ -6,7 +6,8 @@ tensors and the shared library must be present, otherwise MergeRecHipError / Val
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence
+import os
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -379,16 +380,42 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float, out=None) -> torch.Tenso
 ATTN_FLOPS_HINT = [0.0]  # algorithmic 4 * sum(L_b^2) * d of the next attention launch (set by the engine)
 
 
+def attn_work_plan(lens: torch.Tensor, q_rows: int) -> Tuple[torch.Tensor, int]:
+    """Host-side work list of the split attention kernels (mr_attn_work_plan): lens = int64 CPU tensor (B) -> (int32 CPU tensor
+    (n_slots * 8), n_slots).  Pure host code: no GPU call, no synchronisation."""
+    lens = lens.to(torch.int64).contiguous()
+    lib = _lib.load()
+    n = int(lib.mr_attn_work_plan(ptr(lens), lens.numel(), q_rows, None, 0))
+    if n < 0:
+        check(n, "mr_attn_work_plan")
+    work = torch.empty(n * 8, dtype=torch.int32)
+    if n:
+        got = int(lib.mr_attn_work_plan(ptr(lens), lens.numel(), q_rows, ptr(work), work.numel()))
+        assert got == n
+    return work, n
+
+
+def attn_q_rows(window: int, products: int) -> int:
+    return int(_lib.load().mr_attn_split_q_rows(window, products))
+
+
 def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, window: int = -1, out=None,
-              seq_order: Optional[torch.Tensor] = None, products: int = 0) -> torch.Tensor:
-    """products = 0: exact fp32 MFMA kernel; 3 / 6: split-precision bf16 MFMA kernel (mr_attn_split_f32)."""
+              seq_order: Optional[torch.Tensor] = None, products: int = 0, work=None) -> torch.Tensor:
+    """products = 0: exact fp32 MFMA kernel; 3 / 6: split-precision bf16 MFMA kernel.  work: {q_rows: (device int32 work list, n_slots)}
+    from ``attn_work_plan`` (the engine builds it while packing) -> the work-list launch (mr_attn_split_work_f32); without it the
+    (max_len / 128, H, B) grid of mr_attn_split_f32."""
     T = qkv.shape[0]
     dh = qkv.shape[1] // (3 * H)
     out = torch.empty(T, H * dh, dtype=torch.float32, device=qkv.device) if out is None else out
     ev = PROF.begin(qkv.device)
     if products:
-        check(_lib.load().mr_attn_split_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, products,
-                                            ptr(out), _stream(qkv)), "mr_attn_split_f32")
+        wl = work.get(attn_q_rows(window, products)) if work else None
+        if wl is not None and os.environ.get("MR_ATTN_WORKLIST", "1") != "0":
+            check(_lib.load().mr_attn_split_work_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, products,
+                                                     ptr(out), _stream(qkv)), "mr_attn_split_work_f32")
+        else:
+            check(_lib.load().mr_attn_split_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, products,
+                                                ptr(out), _stream(qkv)), "mr_attn_split_f32")
     else:
         check(_lib.load().mr_attn_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, ptr(out), _stream(qkv)), "mr_attn_f32")
     PROF.end(ev, qkv.device, "attention" if not products else f"attention_bf16x{products}", flops=ATTN_FLOPS_HINT[0], nbytes=4.0 * T * 4 * H * dh)

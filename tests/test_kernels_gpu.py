@@ -267,6 +267,50 @@ def test_attention_split_precision(ops, products, tol, window):
     assert torch.allclose(got[keep], want[keep], atol=tol, rtol=tol), (got[keep] - want[keep]).abs().max()
 
 
+@pytest.mark.parametrize("products", [3, 6])
+@pytest.mark.parametrize("window", [-1, 4, 32])
+def test_attention_work_list_is_bit_identical_to_the_box_grid(ops, products, window):
+    """mr_attn_split_work_f32 (host-built (sequence, query block) list, 256-row blocks with two query tiles per wave for full attention in
+    bf16x3) against mr_attn_split_f32 on a ragged batch that exercises every tile-count case of a block (1..8 query tiles, partial
+    tiles, one-token sequences): the same bits, rows that belong to the global-row kernel untouched, and within tolerance of fp64."""
+    g = _g(300 + products + window)
+    H, lens = 3, [512, 1, 2, 31, 32, 33, 64, 65, 127, 128, 129, 160, 191, 224, 255, 256, 257, 300, 384, 385, 511, 700, 1024]
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    T = int(cu[-1])
+    qkv = torch.randn(T, 3 * H * 64, generator=g).to(DEV)
+    lens_t = torch.tensor(lens)
+    work = {}
+    for q in (128, 256):
+        w, n = ops.attn_work_plan(lens_t, q)
+        ents = w[w >= 0]
+        cnt = torch.bincount(ents & 0xFFFFFF, minlength=len(lens))
+        assert torch.equal(cnt, (lens_t + q - 1) // q) and w.numel() == 8 * n  # every (sequence, block) exactly once
+        work[q] = (w.to(DEV), n)
+    box = torch.full((T, H * 64), 7.5, device=DEV)
+    lst = torch.full((T, H * 64), 7.5, device=DEV)
+    ops.attention(qkv, cu.to(DEV), len(lens), H, max(lens), window=window, out=box, products=products)
+    ops.attention(qkv, cu.to(DEV), len(lens), H, max(lens), window=window, out=lst, products=products, work=work)
+    assert torch.equal(box, lst), (box - lst).abs().max()
+    want = _attn_ref(qkv.cpu().double(), cu, H, window).float()
+    keep = torch.ones(T, dtype=torch.bool)
+    if window >= 0:
+        keep[cu[:-1].long()] = False
+        assert bool((lst.cpu()[~keep] == 7.5).all())
+    tol = 3e-4 if products == 3 else 5e-6
+    assert torch.allclose(lst.cpu()[keep], want[keep], atol=tol, rtol=tol)
+
+
+def test_attention_work_plan_rejects_bad_arguments(ops):
+    from mergerec_amd._lib import MergeRecHipError
+
+    with pytest.raises(MergeRecHipError):
+        ops.attn_work_plan(torch.tensor([5, -1]), 256)
+    with pytest.raises(MergeRecHipError):
+        ops.attn_work_plan(torch.tensor([5]), 64)
+    w, n = ops.attn_work_plan(torch.zeros(0, dtype=torch.int64), 256)
+    assert n == 0 and w.numel() == 0
+
+
 @pytest.mark.parametrize("window", [4, 32])
 def test_attention_band_global(ops, window):
     g = _g(window)
