@@ -287,12 +287,15 @@ int mr_gather_rows_f32(const float* x, int64_t ldx, const int32_t* row_idx, int 
  *   row_lse[r]   = logsumexp(scores[r,:] * inv_temp)
  *   row_lab[r]   = scores[r, labels[r]] * inv_temp          (CE loss = mean(row_lse - row_lab))
  *   label_rank[r]= position of labels[r] in top_idx[r,:] or -1
- * ncols >= k, k <= 64.
+ * ncols >= k; k <= mr_topk_max_k() (1024) for rows of up to 49,152 scores (one 1024-thread workgroup per row, the row's keys in
+ * registers), k <= 64 for longer rows.  `--ks` is a free flag upstream (evaluator/evaluator.py:43): the Python surface rejects
+ * max(ks) > mr_topk_max_k() when the Evaluator is built.
  * replaces: evaluator/evaluator.py:43 (torch.topk), the `true in pred` / `pred.index(true)` scans of
  *           evaluator/metrics.py:51-57,79-86 and the cross-entropy of module/recommender/module.py:356. */
 int mr_topk_rows_f32(const float* scores, int64_t ld, int nrows, int ncols, int k, float* top_val, int64_t* top_idx,
                      const int64_t* labels, float inv_temp, float* row_lse, float* row_lab, int32_t* label_rank,
                      mr_stream_t stream);
+int mr_topk_max_k(void);
 
 /* Full-catalog scoring + top-k in one call: scores = U E^T (U: (nU, d), E: (M, d), both row-major),
  * then mr_topk_rows_f32 semantics.  scores_out != NULL: the (nU, M) block is written there (predictions were asked for).

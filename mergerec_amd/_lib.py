@@ -81,6 +81,7 @@ SIGNATURES = {
     "mr_cls_pool_normalize_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_p, c_p]),
     "mr_gather_rows_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_p, c_i64, c_p]),
     "mr_topk_rows_f32": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
+    "mr_topk_max_k": (c_i, []),
     "mr_score_topk_ws_bytes": (c_sz, [c_i64, c_i64]),
     "mr_score_topk_ws_bytes_ex": (c_sz, [c_i64, c_i64, c_i, c_i]),
     "mr_score_fused_mode": (c_i, [c_i]),

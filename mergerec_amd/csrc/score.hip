@@ -10,6 +10,7 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -190,29 +191,295 @@ __global__ __launch_bounds__(kThreads) void topk_rows_kernel(const float* __rest
 #undef s
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Register-resident form (r03): one 1024-thread workgroup per row, the row's order-preserving keys live in registers (NV float4 loads
+// per thread, all in flight at once: ONE memory latency instead of a dependent load per 256 columns), so the four radix passes, the
+// collection and the log-sum-exp never touch memory again; the bucket scan after each pass is one wavefront's suffix sum instead of
+// a serial walk over 256 LDS words.  Same canonical result as topk_rows_kernel (score desc, index asc; NaN first; -0 == +0), also
+// for k up to 1024 (the candidates are then sorted by the whole workgroup).  Covers ncols <= 4096 * NV (NV <= 12: 49,152 columns; longer rows take topk_rows_kernel).
+constexpr int kRegThreads = 1024;
+constexpr int kRegWaves = kRegThreads / MR_WAVE;
+
+__device__ __forceinline__ float key_value(unsigned key) {  // inverse of ord_key up to the sign of zero and the NaN payload
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+
+template <int NV, int KCAP>
+__global__ __launch_bounds__(kRegThreads) void topk_rows_reg_kernel(const float* __restrict__ scores, int64_t ld, int ncols, int k,
+                                                                   float* __restrict__ top_val, int64_t* __restrict__ top_idx,
+                                                                   const int64_t* __restrict__ labels, float inv_temp,
+                                                                   float* __restrict__ row_lse, float* __restrict__ row_lab,
+                                                                   int32_t* __restrict__ label_rank) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_remaining, s_ngt, s_neq, s_eqtotal, s_rank;
+    __shared__ unsigned wcnt[kRegWaves];
+    __shared__ float red[kRegWaves];
+    __shared__ unsigned long long cand[KCAP];
+
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ g = scores + (int64_t)row * ld;
+    // element (j, c) of this thread is column (j * 1024 + tid) * 4 + c; columns past ncols carry key 0 (below every real key)
+    unsigned key[NV * 4];
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15u) == 0);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {  // the loads first (bit patterns straight into the key registers), all in flight together
+        const int c0 = (j * kRegThreads + tid) * 4;
+        if (vec && c0 + 3 < ncols) {
+            const uint4 v = *reinterpret_cast<const uint4*>(g + c0);
+            key[4 * j] = v.x; key[4 * j + 1] = v.y; key[4 * j + 2] = v.z; key[4 * j + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) key[4 * j + c] = (c0 + c < ncols) ? __float_as_uint(g[c0 + c]) : 0u;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NV * 4; ++e) {
+        const int i = ((e >> 2) * kRegThreads + tid) * 4 + (e & 3);
+        key[e] = i < ncols ? ord_key(__uint_as_float(key[e])) : 0u;
+    }
+
+    if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)k; s_ngt = 0u; s_neq = 0u; s_eqtotal = 0u; s_rank = 0xffffffffu; }
+    for (int i = tid; i < KCAP; i += kRegThreads) cand[i] = 0ull;
+    unsigned mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_prefix, rem = s_remaining;
+        // run-length pre-aggregation per thread (cosine scores share sign, exponent and the top mantissa bits: one atomic per run)
+        unsigned run_b = 0xffffffffu, run_n = 0u;
+#pragma unroll
+        for (int e = 0; e < NV * 4; ++e) {
+            if ((key[e] & mask) == prefix) {
+                const unsigned bk = (key[e] >> shift) & 0xffu;
+                if (bk == run_b) {
+                    ++run_n;
+                } else {
+                    if (run_n) atomicAdd(&hist[run_b], run_n);
+                    run_b = bk;
+                    run_n = 1u;
+                }
+            }
+        }
+        if (run_n) atomicAdd(&hist[run_b], run_n);
+        __syncthreads();
+        if (wave == 0) {  // lane l owns buckets 4 l .. 4 l + 3; `above` = elements in the buckets of higher lanes
+            const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const unsigned c4 = (h0 + h1) + (h2 + h3);
+            unsigned incl = c4;  // inclusive suffix sum over lanes >= lane
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_down(incl, o, 64);
+                if (lane + o < 64) incl += t;
+            }
+            const unsigned above = incl - c4;
+            // the bucket of the rem-th largest: the one lane with above < rem <= above + c4, then its highest bucket that reaches rem
+            const bool mine = above < rem && rem <= incl;
+            if (mine) {
+                unsigned c = above;
+                int bkt;
+                if (c + h3 >= rem) { bkt = 3; }
+                else { c += h3; if (c + h2 >= rem) { bkt = 2; } else { c += h2; if (c + h1 >= rem) { bkt = 1; } else { c += h1; bkt = 0; } } }
+                const unsigned hsel = bkt == 3 ? h3 : bkt == 2 ? h2 : bkt == 1 ? h1 : h0;
+                s_remaining = rem - c;
+                s_prefix = prefix | ((unsigned)(4 * lane + bkt) << shift);
+                s_eqtotal = hsel;  // after the last pass: how many keys equal the k-th largest
+            }
+        }
+        mask |= 0xffu << shift;
+        __syncthreads();
+    }
+    const unsigned thr = s_prefix;          // key of the k-th largest element
+    const unsigned need_eq = s_remaining;   // how many elements equal to it belong to the top-k
+    const unsigned n_gt = (unsigned)k - need_eq;
+    const bool ties_cut = s_eqtotal > need_eq;  // block-uniform: more keys equal the threshold than fit -> lowest indices win
+
+    // collection: keys > thr in any order (the sort below orders them)
+#pragma unroll
+    for (int e = 0; e < NV * 4; ++e) {
+        if (key[e] > thr) {
+            const unsigned slot = atomicAdd(&s_ngt, 1u);
+            const unsigned i = (unsigned)(((e >> 2) * kRegThreads + tid) * 4 + (e & 3));
+            if (slot < (unsigned)KCAP) cand[slot] = ((unsigned long long)key[e] << 32) | (unsigned long long)(0xffffffffu - i);
+        }
+    }
+    if (!ties_cut) {  // every key == thr belongs to the top-k
+#pragma unroll
+        for (int e = 0; e < NV * 4; ++e) {
+            if (key[e] == thr) {
+                const unsigned slot = n_gt + atomicAdd(&s_neq, 1u);
+                const unsigned i = (unsigned)(((e >> 2) * kRegThreads + tid) * 4 + (e & 3));
+                if (slot < (unsigned)KCAP) cand[slot] = ((unsigned long long)thr << 32) | (unsigned long long)(0xffffffffu - i);
+            }
+        }
+    } else {  // keys == thr by ascending column: columns ascend with (j, tid, c)
+        unsigned eq_seen = 0u;
+#pragma unroll 1
+        for (int j = 0; j < NV; ++j) {
+            unsigned cnt = 0u;
+#pragma unroll
+            for (int e = 0; e < NV * 4; ++e)
+                if ((e >> 2) == j && key[e] == thr) ++cnt;
+            unsigned incl = cnt;  // inclusive prefix over the wave's lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) wcnt[wave] = incl;
+            __syncthreads();
+            unsigned before = eq_seen + (incl - cnt), total = 0u;
+#pragma unroll
+            for (int w = 0; w < kRegWaves; ++w) {
+                if (w < wave) before += wcnt[w];
+                total += wcnt[w];
+            }
+            unsigned r = before;
+#pragma unroll
+            for (int e = 0; e < NV * 4; ++e) {
+                if ((e >> 2) == j && key[e] == thr) {
+                    const unsigned i = (unsigned)((j * kRegThreads + tid) * 4 + (e & 3));
+                    if (r < need_eq) cand[n_gt + r] = ((unsigned long long)thr << 32) | (unsigned long long)(0xffffffffu - i);
+                    ++r;
+                }
+            }
+            eq_seen += total;
+            __syncthreads();
+            if (eq_seen >= need_eq) break;  // block-uniform
+        }
+    }
+    __syncthreads();
+
+    // sort the candidates descending by (key, -index); unused slots are 0 and sink
+    const int64_t lab = labels ? labels[row] : -1;
+    if (KCAP == 64) {
+        if (wave == 0) {
+            unsigned long long v = cand[lane];
+#pragma unroll
+            for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    const unsigned long long o = __shfl_xor(v, stride, 64);
+                    const bool up = ((lane & size) == 0);
+                    const bool lower = ((lane & stride) == 0);
+                    const bool take_max = (up == lower);
+                    v = take_max ? (v > o ? v : o) : (v < o ? v : o);
+                }
+            }
+            cand[lane] = v;
+        }
+    } else {
+        for (int size = 2; size <= KCAP; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < KCAP / 2; t += kRegThreads) {
+                    const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), hi = lo | stride;
+                    const unsigned long long a = cand[lo], c = cand[hi];
+                    const bool desc = ((lo & size) == 0);
+                    if (desc ? (a < c) : (a > c)) { cand[lo] = c; cand[hi] = a; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < k; t += kRegThreads) {
+        unsigned idx = 0xffffffffu - (unsigned)(cand[t] & 0xffffffffull);
+        if (idx >= (unsigned)ncols) idx = 0u;  // cannot happen for ncols >= k; never read out of bounds
+        top_idx[(int64_t)row * k + t] = (int64_t)idx;
+        top_val[(int64_t)row * k + t] = g[idx];
+        if (labels && (int64_t)idx == lab) atomicMin(&s_rank, (unsigned)t);
+    }
+    if (labels) {
+        __syncthreads();
+        if (tid == 0 && label_rank) label_rank[row] = s_rank == 0xffffffffu ? -1 : (int32_t)s_rank;
+    }
+
+    if (labels && row_lse) {
+        // row max = best candidate's score (NaN rows propagate NaN like torch.cross_entropy)
+        unsigned best = 0xffffffffu - (unsigned)(cand[0] & 0xffffffffull);
+        if (best >= (unsigned)ncols) best = 0u;
+        const float mx = g[best] * inv_temp;
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < NV * 4; ++e)
+            if (key[e] != 0u) acc += expf(key_value(key[e]) * inv_temp - mx);
+        acc = mr::wave_sum(acc);
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < kRegWaves; ++w) tot += red[w];
+            row_lse[row] = mx + logf(tot);
+            if (row_lab) row_lab[row] = (lab >= 0 && lab < ncols) ? g[lab] * inv_temp : NAN;
+        }
+    }
+}
+
 }  // namespace
+
+constexpr int kMaxTopK = 1024;
+
+extern "C" int mr_topk_max_k(void) { return kMaxTopK; }
+
+template <int NV>
+static void launch_topk_reg(int k, const float* scores, int64_t ld, int nrows, int ncols, float* top_val, int64_t* top_idx, const int64_t* labels,
+                            float inv_temp, float* row_lse, float* row_lab, int32_t* label_rank, hipStream_t st) {
+    if (k <= 64)
+        hipLaunchKernelGGL((topk_rows_reg_kernel<NV, 64>), dim3(nrows), dim3(kRegThreads), 0, st, scores, ld, ncols, k, top_val, top_idx, labels,
+                           inv_temp, row_lse, row_lab, label_rank);
+    else if (k <= 256)
+        hipLaunchKernelGGL((topk_rows_reg_kernel<NV, 256>), dim3(nrows), dim3(kRegThreads), 0, st, scores, ld, ncols, k, top_val, top_idx, labels,
+                           inv_temp, row_lse, row_lab, label_rank);
+    else
+        hipLaunchKernelGGL((topk_rows_reg_kernel<NV, kMaxTopK>), dim3(nrows), dim3(kRegThreads), 0, st, scores, ld, ncols, k, top_val, top_idx,
+                           labels, inv_temp, row_lse, row_lab, label_rank);
+}
 
 extern "C" int mr_topk_rows_f32(const float* scores, int64_t ld, int nrows, int ncols, int k, float* top_val,
                                 int64_t* top_idx, const int64_t* labels, float inv_temp, float* row_lse, float* row_lab,
                                 int32_t* label_rank, mr_stream_t stream) {
     if (!scores || !top_val || !top_idx || nrows < 0 || ncols < 1 || k < 1) return MR_EINVAL;
-    if (k > 64 || k > ncols) return MR_EUNSUPPORTED;
+    if (k > ncols) return MR_EUNSUPPORTED;
     if (ld < ncols) return MR_EINVAL;
     if (nrows == 0) return MR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    static const bool force_lds = [] { const char* e = getenv("MR_TOPK_LDS"); return e && e[0] == '1'; }();  // A/B: the r02 kernel
+    if (ncols <= 4096 * 12 && k <= kMaxTopK && !force_lds) {
+        // register-resident rows: NV float4 per thread of a 1024-thread workgroup
+#define MR_TOPK_REG(NV_) launch_topk_reg<NV_>(k, scores, ld, nrows, ncols, top_val, top_idx, labels, inv_temp, row_lse, row_lab, label_rank, st)
+        if (ncols <= 4096 * 2) MR_TOPK_REG(2);
+        else if (ncols <= 4096 * 4) MR_TOPK_REG(4);
+        else if (ncols <= 4096 * 6) MR_TOPK_REG(6);
+        else if (ncols <= 4096 * 8) MR_TOPK_REG(8);
+        else MR_TOPK_REG(12);
+#undef MR_TOPK_REG
+        return mr::check_launch();
+    }
+    if (k > 64) return MR_EUNSUPPORTED;  // rows beyond 49,152 columns: the LDS / L2 kernel below (k <= 64)
     const bool cached = ncols <= kMaxCachedCols && (ld & 3) == 0 && mr::aligned16(scores);
     if (cached) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kMaxCachedCols * (int)sizeof(float));
-            attr_done = true;
+        // per-device, checked: a failed attribute call would otherwise surface as an opaque launch error on that device only
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MR_ELAUNCH;
+        static std::atomic<int> attr_state[64];  // 0 = not tried, 1 = ok, 2 = failed
+        int stt = attr_state[dev].load(std::memory_order_acquire);
+        if (stt == 0) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_rows_kernel<true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxCachedCols * (int)sizeof(float));
+            stt = e == hipSuccess ? 1 : 2;
+            if (e != hipSuccess) (void)hipGetLastError();
+            attr_state[dev].store(stt, std::memory_order_release);
         }
-        hipLaunchKernelGGL(topk_rows_kernel<true>, dim3(nrows), dim3(kThreads), (size_t)((ncols + 3) & ~3) * sizeof(float), (hipStream_t)stream,
-                           scores, ld, ncols, k, top_val, top_idx, labels, inv_temp, row_lse, row_lab, label_rank);
-    } else {
-        hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(nrows), dim3(kThreads), 0, (hipStream_t)stream, scores, ld, ncols, k, top_val,
-                           top_idx, labels, inv_temp, row_lse, row_lab, label_rank);
+        if (stt == 1) {
+            hipLaunchKernelGGL(topk_rows_kernel<true>, dim3(nrows), dim3(kThreads), (size_t)((ncols + 3) & ~3) * sizeof(float), st,
+                               scores, ld, ncols, k, top_val, top_idx, labels, inv_temp, row_lse, row_lab, label_rank);
+            return mr::check_launch();
+        }
     }
+    hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(nrows), dim3(kThreads), 0, st, scores, ld, ncols, k, top_val,
+                       top_idx, labels, inv_temp, row_lse, row_lab, label_rank);
     return mr::check_launch();
 }
 

@@ -62,11 +62,18 @@ class MetricType(Enum):
         self.metric_cls = metric_cls
 
 
+MAX_K = 1024  # == mr_topk_max_k() (include/mergerec_hip.h); checked against the library in tests/test_cabi_symbols.py
+
+
 class Evaluator:
     def __init__(self, metrics: List[str], ks: List[int]):
         self.metric_names = metrics
         self.ks = ks
         self._max_k = max(ks)
+        # `--ks` is a free flag upstream (torch.topk takes any k, evaluator/evaluator.py:43); the HIP row select holds at most MAX_K
+        # candidates per row: reject larger values here, where the flag is parsed into an Evaluator, not at the first batch
+        if min(ks) < 1 or self._max_k > MAX_K:
+            raise ValueError(f"--ks: every k must be in 1..{MAX_K} (got {sorted(ks)}); the top-k kernel keeps at most {MAX_K} candidates per row")
         self._metrics = [MetricType[m].metric_cls(k) for m in metrics for k in ks]
 
     def evaluate(self, scores, labels, metric_prefix: str = "") -> Dict[str, float]:

@@ -49,6 +49,39 @@ def test_argument_validation_without_gpu():
     assert lib.mr_score_topk_ws_bytes_ex(4096, 22855, 768, 50) < 4096 * 22855  # auto: a 374 MB block would not -> fused route
 
 
+def test_topk_limit_and_attention_work_plan_are_host_side():
+    """mr_topk_max_k is what the Python surface's `--ks` check uses; the attention work list is built on the host (no GPU call)."""
+    import pytest
+    import torch
+
+    from mergerec_amd import ops
+    from mergerec_amd.evaluator import MAX_K, Evaluator
+
+    lib = _lib.load()
+    assert lib.mr_topk_max_k() == MAX_K == 1024
+    Evaluator(["NDCG"], [1, 5, 10, 50, 200, 1024])
+    with pytest.raises(ValueError, match="--ks"):
+        Evaluator(["NDCG"], [10, 2000])
+    with pytest.raises(ValueError, match="--ks"):
+        Evaluator(["RECALL"], [0, 5])
+    assert lib.mr_attn_split_q_rows(-1, 3) == 256 and lib.mr_attn_split_q_rows(32, 3) == 128 and lib.mr_attn_split_q_rows(-1, 6) == 128
+    lens = torch.tensor([512, 300, 129, 128, 5, 0, 257, 64, 33, 400, 256, 1])
+    for q in (128, 256):
+        work, n = ops.attn_work_plan(lens, q)
+        w = work.view(n, 8)
+        ents = work[work >= 0]
+        assert torch.equal(torch.bincount(ents & 0xFFFFFF, minlength=lens.numel()), (lens + q - 1) // q)
+        for x in range(8):  # a sequence's query blocks sit in ONE queue (column), consecutive and in order: they share K / V in that XCD's L2
+            col = w[:, x][w[:, x] >= 0]
+            seqs, blocks = (col & 0xFFFFFF).tolist(), (col >> 24).tolist()
+            seen = {}
+            for i, (sq, b) in enumerate(zip(seqs, blocks)):
+                assert b == seen.get(sq, -1) + 1 and (b == 0 or seqs[i - 1] == sq)
+                seen[sq] = b
+        # heaviest first: the first slot holds the eight longest sequences
+        assert sorted((w[0] & 0xFFFFFF).tolist()) == sorted(torch.argsort(lens, descending=True, stable=True)[:8].tolist())
+
+
 def test_ops_refuse_cpu_tensors():
     import pytest
     import torch

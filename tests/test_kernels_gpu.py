@@ -368,6 +368,54 @@ def test_topk_rows_canonical_with_ties(ops):
     assert torch.allclose(lab.cpu()[ok], (s[torch.arange(R), labels] * 20.0)[ok], atol=1e-6)
 
 
+@pytest.mark.parametrize("C,k", [(22855, 50), (22855, 64), (8191, 65), (8193, 200), (4968, 1000), (27932, 1024), (49152, 300), (1030, 1024),
+                                 (50000, 50), (300, 7)])
+def test_topk_rows_register_kernel_every_width_and_k(ops, C, k):
+    """The register-resident row select (csrc/score.hip topk_rows_reg_kernel: every float4-count variant, k <= 64 sorted by one wavefront,
+    larger k by the workgroup) and the LDS / L2 kernel behind it (C = 50,000) against the C oracle's canonical order: ties that straddle
+    the k-th value, more equal maxima than k, NaN, +-inf, +-0, constant rows, an unaligned leading dimension."""
+    g = _g(C + k)
+    R = 9
+    s = torch.randn(R, C, generator=g)
+    s[0, torch.randperm(C, generator=g)[: k + 37]] = float(s[0].max()) + 1.0       # more equal maxima than k: lowest indices win
+    s[1, :] = 0.25
+    s[2, 5] = float("nan"); s[2, C - 1] = float("nan")
+    kth = float(s[3].topk(k).values[-1])
+    s[3, C // 2 : C // 2 + 40] = kth                                               # ties straddling the k-th value
+    s[4, 7] = float("inf"); s[4, 9] = float("-inf")
+    s[5, 10] = 0.0; s[5, 11] = -0.0; s[5, 12:] = -1.0; s[5, :10] = -2.0
+    s[6] = torch.round(s[6] * 4) / 4                                               # heavy ties everywhere
+    s[7] = -torch.rand(C, generator=g) * 1e-30                                     # tiny negatives: top byte of the key shared with nothing else
+    labels = torch.randint(0, C, (R,), generator=g)
+    labels[0] = int(torch.nonzero(s[0] == s[0].max())[3])
+    wv, wi = CO.topk_rows(s, k)
+    want_rank = torch.tensor([(wi[r] == labels[r]).nonzero()[0, 0].item() if (wi[r] == labels[r]).any() else -1 for r in range(R)], dtype=torch.int32)
+    for pad in (0, 3):  # pad 3: leading dimension not a multiple of 4 -> the scalar load path
+        buf = torch.full((R, C + pad), 9e9)
+        buf[:, :C] = s
+        val, idx, lse, lab, rank = ops.topk_rows(buf.to(DEV)[:, :C], k, labels.to(DEV), 20.0)
+        assert torch.equal(idx.cpu(), wi), (pad, (idx.cpu() != wi).nonzero()[:5])
+        assert torch.equal(val.cpu().nan_to_num(7.0), wv.nan_to_num(7.0))
+        assert torch.equal(val.cpu()[5].view(torch.int32), wv[5].view(torch.int32))   # -0.0 keeps its sign bit
+        assert torch.equal(rank.cpu(), want_rank)
+        ok = ~torch.isnan(s).any(1) & ~torch.isinf(s).any(1)
+        assert torch.allclose(lse.cpu()[ok], torch.logsumexp(s * 20.0, dim=1)[ok], atol=1e-4, rtol=1e-5)
+        assert bool(torch.isnan(lse.cpu()[2]))
+        assert torch.equal(lab.cpu()[ok], (s[torch.arange(R), labels] * 20.0)[ok])
+
+
+def test_topk_rows_rejects_k_beyond_the_limit(ops):
+    from mergerec_amd._lib import MergeRecHipError
+
+    s = torch.randn(2, 3000).to(DEV)
+    with pytest.raises(MergeRecHipError):
+        ops.topk_rows(s, 1025)
+    with pytest.raises(MergeRecHipError):
+        ops.topk_rows(torch.randn(2, 50001).to(DEV), 65)   # rows beyond the register kernel: k <= 64
+    with pytest.raises(MergeRecHipError):
+        ops.topk_rows(torch.randn(2, 40).to(DEV), 41)      # k > ncols
+
+
 @pytest.mark.parametrize("nU,M", [(33, 4968), (128, 18357), (5, 50)])
 def test_score_topk_full_catalog(ops, nU, M):
     g = _g(M)
