@@ -381,7 +381,16 @@ def _main(real_stdout):
                 ent.update(bound="hbm", achieved=r["bytes"] / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
             ent["frac"] = ent["achieved"] / ent["peak"]
             kernels[name] = ent
-        dom = max(kernels.items(), key=lambda kv: kv[1]["share_of_step"])
+        if "score_gemm" in kernels and "topk_rows" in kernels:
+            # full-catalog scoring = scoring GEMM + row select TOGETHER against the fp32-MFMA peak (north_star's ">= 40 % on full-catalog
+            # scoring" is about the pair, not the GEMM half)
+            sg, tk = summ["score_gemm"], summ["topk_rows"]
+            sec = (sg["ms"] + tk["ms"]) / 1e3
+            kernels["score_plus_topk"] = dict(launches=sg["launches"], avg_ms=(sg["ms"] + tk["ms"]) / max(sg["launches"], 1),
+                                              share_of_step=(sg["ms"] + tk["ms"]) / (elapsed * 1e3), bound="mfma", achieved=sg["flops"] / sec / 1e12,
+                                              peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=sg["flops"] / sec / 1e12 / MFMA_F32_PEAK_TF,
+                                              note="score_gemm + topk_rows as one unit of work")
+        dom = max((kv for kv in kernels.items() if kv[0] != "score_plus_topk"), key=lambda kv: kv[1]["share_of_step"])
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command (separate FETCH_SIZE /
         # WRITE_SIZE passes, FETCH_SIZE x2 on gfx950; tools/pmc_summary.py) -- PMC cannot be collected from inside the timed run.  The pass
         # records the sha of the kernel sources it profiled: a different sha here means the figure is STALE and is reported as such.

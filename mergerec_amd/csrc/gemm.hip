@@ -11,6 +11,7 @@
 // the b128 reads conflict-free.  fp32 MFMA needs only ~8 B/clk/CU of operand traffic, far below L2/LDS
 // limits: the kernel is MFMA-issue bound by construction.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -22,13 +23,17 @@ constexpr int kThreads = 256;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int ACT, bool HAS_R>
+// BMT = rows of the block tile: 128 (waves 2 x 2, wave tile 64 x 64) or 64 (wave tile 32 x 64: half the work per workgroup, for shapes whose
+// 128-row tiling leaves the CUs unevenly loaded -- 256 users x 22,855 items is 358 tiles on 256 CUs, i.e. 2 rounds of time for 1.4 of
+// work; 716 half tiles are 3 half-rounds).  Every output element's k chain is the same in both: results are bit-identical.
+template <int ACT, bool HAS_R, int BMT = BM>
 __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ w0, const float* __restrict__ w1,
     const float* __restrict__ w2, const float* __restrict__ b0, const float* __restrict__ b1,
     const float* __restrict__ b2, int M, int seg_n, int K, const float* __restrict__ R, int64_t ldr,
     float* __restrict__ C, int64_t ldc, int tiles_n_seg, int tiles_n, int nwg, int kchunk, int64_t split_stride) {
-    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_STRIDE];
+    constexpr int MI = BMT / 64;  // 32-row MFMA tiles per wave along M
+    __shared__ __attribute__((aligned(16))) float lds[2][(BMT + BN) * LDS_STRIDE];
     // split-K (mr_gemm_nt_splitk_f32 only; every other caller passes kchunk = K, gridDim.y = 1): slice blockIdx.y of the k range,
     // raw partial sums to C + blockIdx.y * split_stride
     const int k_begin = blockIdx.y * kchunk;
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
     const int tm = pid / tiles_n, tn = pid - tm * tiles_n;
     const int seg = tn / tiles_n_seg;
     const int n0 = (tn - seg * tiles_n_seg) * BN;  // column inside the segment
-    const int m0 = tm * BM;
+    const int m0 = tm * BMT;
     const float* __restrict__ W = seg == 0 ? w0 : (seg == 1 ? w1 : w2);
     const float* __restrict__ bias = seg == 0 ? b0 : (seg == 1 ? b1 : b2);
 
@@ -61,14 +66,14 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
     const float* gb1 = W + (int64_t)br1 * K + kq * 4 + k_begin;
     // LDS write offsets (floats): even half at 2*kq, odd half at 8 + 2*kq
     const int wa0 = sr * LDS_STRIDE + 2 * kq, wa1 = (sr + 64) * LDS_STRIDE + 2 * kq;
-    const int wb0 = (BM + sr) * LDS_STRIDE + 2 * kq, wb1 = (BM + sr + 64) * LDS_STRIDE + 2 * kq;
+    const int wb0 = (BMT + sr) * LDS_STRIDE + 2 * kq, wb1 = (BMT + sr + 64) * LDS_STRIDE + 2 * kq;
     // LDS read offsets (floats)
-    const int ra = (wm * 64 + lr) * LDS_STRIDE + lh * 8;
-    const int rb = (BM + wn * 64 + lr) * LDS_STRIDE + lh * 8;
+    const int ra = (wm * 32 * MI + lr) * LDS_STRIDE + lh * 8;
+    const int rb = (BMT + wn * 64 + lr) * LDS_STRIDE + lh * 8;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -77,15 +82,17 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
     float4 sa0, sa1, sb0, sb1;
     auto gload = [&](int k0) {
         sa0 = *reinterpret_cast<const float4*>(ga0 + k0);
-        sa1 = *reinterpret_cast<const float4*>(ga1 + k0);
+        if (MI == 2) sa1 = *reinterpret_cast<const float4*>(ga1 + k0);
         sb0 = *reinterpret_cast<const float4*>(gb0 + k0);
         sb1 = *reinterpret_cast<const float4*>(gb1 + k0);
     };
     auto lstore = [&](float* buf) {
         *reinterpret_cast<float2*>(buf + wa0) = make_float2(sa0.x, sa0.z);
         *reinterpret_cast<float2*>(buf + wa0 + 8) = make_float2(sa0.y, sa0.w);
-        *reinterpret_cast<float2*>(buf + wa1) = make_float2(sa1.x, sa1.z);
-        *reinterpret_cast<float2*>(buf + wa1 + 8) = make_float2(sa1.y, sa1.w);
+        if (MI == 2) {
+            *reinterpret_cast<float2*>(buf + wa1) = make_float2(sa1.x, sa1.z);
+            *reinterpret_cast<float2*>(buf + wa1 + 8) = make_float2(sa1.y, sa1.w);
+        }
         *reinterpret_cast<float2*>(buf + wb0) = make_float2(sb0.x, sb0.z);
         *reinterpret_cast<float2*>(buf + wb0 + 8) = make_float2(sb0.y, sb0.w);
         *reinterpret_cast<float2*>(buf + wb1) = make_float2(sb1.x, sb1.z);
@@ -106,25 +113,30 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
         // reuse the fragment registers and then waits for them at once (memory latency exposed per k-tile).
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        float4 a[2][2], b[2][2];
+        float4 a[MI][2], b[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            a[i][0] = *reinterpret_cast<const float4*>(buf + ra + i * 32 * LDS_STRIDE);
-            a[i][1] = *reinterpret_cast<const float4*>(buf + ra + i * 32 * LDS_STRIDE + 4);
+            if (i < MI) {
+                a[i][0] = *reinterpret_cast<const float4*>(buf + ra + i * 32 * LDS_STRIDE);
+                a[i][1] = *reinterpret_cast<const float4*>(buf + ra + i * 32 * LDS_STRIDE + 4);
+            }
             b[i][0] = *reinterpret_cast<const float4*>(buf + rb + i * 32 * LDS_STRIDE);
             b[i][1] = *reinterpret_cast<const float4*>(buf + rb + i * 32 * LDS_STRIDE + 4);
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            float av[2], bv[2];
+            float av[MI], bv[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float4 fa = a[i][s >> 2], fb = b[i][s >> 2];
-                av[i] = (s & 3) == 0 ? fa.x : ((s & 3) == 1 ? fa.y : ((s & 3) == 2 ? fa.z : fa.w));
+                const float4 fb = b[i][s >> 2];
                 bv[i] = (s & 3) == 0 ? fb.x : ((s & 3) == 1 ? fb.y : ((s & 3) == 2 ? fb.z : fb.w));
+                if (i < MI) {
+                    const float4 fa = a[i][s >> 2];
+                    av[i] = (s & 3) == 0 ? fa.x : ((s & 3) == 1 ? fa.y : ((s & 3) == 2 ? fa.z : fa.w));
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
     // num_records ends at the tile's last valid element, so rows past M are dropped by the hardware bounds check and
     // lanes whose column is past seg_n carry an out-of-range offset.  (Per-element guards put every store in its own
     // basic block behind `s_waitcnt vmcnt(0)`, i.e. each store waited for the previous one to complete.)
-    const int rows_valid = (M - m0) < BM ? (M - m0) : BM;
+    const int rows_valid = (M - m0) < BMT ? (M - m0) : BMT;
     const int cols_valid = (seg_n - n0) < BN ? (seg_n - n0) : BN;
     const int64_t col0 = (int64_t)seg * seg_n + n0;
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
@@ -161,8 +173,8 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
         coff[j] = ok ? (uint32_t)colt * 4u : 0x80000000u;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const uint32_t rowt = wm * 64 + i * 32 + 4 * lh_e;
+    for (int i = 0; i < MI; ++i) {
+        const uint32_t rowt = wm * 32 * MI + i * 32 + 4 * lh_e;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -251,13 +263,27 @@ extern "C" int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float*
         return MR_EALIGN;
     if (ldc < 1 || ldc > (1 << 21) || (R && (ldr < 1 || ldr > (1 << 21)))) return MR_EUNSUPPORTED;  // 32-bit tile-local offsets in the epilogue
     if (M == 0) return MR_OK;
-    const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n_seg = (seg_n + BN - 1) / BN;
     const int tiles_n = tiles_n_seg * nseg;
+    hipStream_t st = (hipStream_t)stream;
+    if (act == MR_ACT_NONE && !R) {
+        // plain product (the scoring GEMM): 64-row tiles when they load the 256 CUs more evenly than 128-row tiles.  The kernel is
+        // matrix-pipe bound, so a launch takes ceil(workgroups / CUs) rounds of one workgroup's time (5 % charged to the half tile
+        // for its extra LDS traffic per MFMA).
+        const int64_t n128 = (int64_t)((M + 127) / 128) * tiles_n, n64 = (int64_t)((M + 63) / 64) * tiles_n;
+        static const int force = [] { const char* e = getenv("MR_GEMM_F32_BM"); return e ? atoi(e) : 0; }();  // A/B: 64 / 128
+        const bool half = force ? force == 64 : (double)((n64 + 255) / 256) * 0.5 * 1.05 < (double)((n128 + 255) / 256);
+        if (half) {
+            if (n64 > 0x7fffffff) return MR_EUNSUPPORTED;
+            hipLaunchKernelGGL((gemm_nt_kernel<MR_ACT_NONE, false, 64>), dim3((unsigned)n64), dim3(kThreads), 0, st, A, lda, w0, w1, w2, b0, b1, b2,
+                               M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, (int)n64, K, (int64_t)0);
+            return mr::check_launch();
+        }
+    }
+    const int tiles_m = (M + BM - 1) / BM;
     const int64_t nwg64 = (int64_t)tiles_m * tiles_n;
     if (nwg64 > 0x7fffffff) return MR_EUNSUPPORTED;
     const int nwg = (int)nwg64;
-    hipStream_t st = (hipStream_t)stream;
 #define MR_GEMM_LAUNCH(ACT_, HASR_)                                                                                   \
     hipLaunchKernelGGL((gemm_nt_kernel<ACT_, HASR_>), dim3(nwg), dim3(kThreads), 0, st, A, lda, w0, w1, w2, b0, b1, b2, \
                        M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg, K, (int64_t)0)

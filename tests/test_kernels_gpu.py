@@ -83,8 +83,10 @@ def test_merge_bwd_alpha(ops):
 
 
 # ------------------------------------------------------------------ K3 GEMM (bit-exact vs k-ordered fmaf chain)
-@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (130, 768, 768), (257, 200, 3072), (64, 333, 16)])
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (130, 768, 768), (257, 200, 3072), (64, 333, 16), (1024, 4096, 64), (1000, 4000, 32)])
 def test_gemm_bitexact_vs_fma_chain(ops, M, N, K):
+    # the plain product picks 64- or 128-row block tiles by how evenly they load the CUs (csrc/gemm.hip): the first four shapes and the
+    # last take the half tile, (1024, 4096, 64) exactly one round of 128-row tiles -- the k chain per element is the same in both
     g = _g(M + N + K)
     A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
     got = ops.gemm_nt(A.to(DEV), [W.to(DEV)], [b.to(DEV)]).cpu()
