@@ -78,15 +78,15 @@ def parse(argv=None):
     ap.add_argument("--item_embeddings_path", default=None)
     ap.add_argument("--user_embeddings_path", default=None)
     cfg, unknown = ap.parse_known_args(argv)
-    skip = False
+    skip = False  # True only for the ONE token that directly follows a --lora* flag (its value)
     for u in unknown:
         if u.startswith("--lora"):
             print(f"note: {u} ignored (LoRA wrappers are outside the merged-inference path)")
-            skip = True      # its value, if any, follows
-        elif u.startswith("--"):
+            skip = "=" not in u  # `--lora.r 8`: the value follows; `--lora.r=8`: nothing to skip
+        elif u.startswith("--") or not skip:
             ap.error(f"unrecognized argument {u}")
-        elif not skip:
-            ap.error(f"unrecognized argument {u}")
+        else:
+            skip = False
     if cfg.data_split is not None:  # configs/base.py:91-101: the alias never overrides test_data_split
         import warnings
 

@@ -13,6 +13,7 @@
 // against 23 MB written + 23 MB re-read before); candidates: users x parts x k x 12 B.
 #include "common.h"
 #include <math.h>
+#include <mutex>
 
 namespace {
 
@@ -354,6 +355,8 @@ size_t score_fused_ws_bytes(int64_t nU, int64_t M, int k) {
     return (size_t)nU * P * (size_t)k * 12 + (size_t)nU * P * 8 + 512;
 }
 
+constexpr int kMaxDevices = 64;
+
 int score_fused_launch(const float* U, const float* E, int64_t nU, int64_t M, int d, int k, float* top_val, int64_t* top_idx, const int64_t* labels,
                        float inv_temp, float* row_lse, float* row_lab, int32_t* label_rank, void* ws, hipStream_t st) {
     const int pc = score_part_cols(nU, M), P = score_parts(nU, M);
@@ -363,21 +366,37 @@ int score_fused_launch(const float* U, const float* E, int64_t nU, int64_t M, in
     float* pmax = cand_val + (size_t)nU * P * k;
     float* psum = pmax + (size_t)nU * P;
     const size_t shm = (size_t)(2 * STAGE_F + SBM * PART) * sizeof(float) + kWaves * 256 * 4 + kWaves * 64 * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&score_part_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_done = true;
+    // dynamic-LDS ceilings: per device, return code checked (a failed call would otherwise surface as an opaque launch error, or only on
+    // the second device of a process)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return MR_ELAUNCH;
+    static std::mutex attr_mu;
+    static size_t attr_part[kMaxDevices], attr_merge[kMaxDevices];
+    {
+        std::lock_guard<std::mutex> lock(attr_mu);
+        if (shm > attr_part[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_part_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
+                (void)hipGetLastError();
+                return MR_EUNSUPPORTED;
+            }
+            attr_part[dev] = shm;
+        }
     }
-    hipLaunchKernelGGL(score_part_topk_kernel, dim3(P, (unsigned)((nU + SBM - 1) / SBM)), dim3(kThreads), shm, st, U, E, (int)nU, (int)M, d, k, P, pc, cand,
-                       cand_val, pmax, psum, labels, inv_temp, row_lab);
     const int last = (int)(M - (int64_t)(P - 1) * pc);
     const int n_valid = (P - 1) * k + (k < last ? k : last);
     const size_t shm_m = (size_t)((n_valid + 3) & ~3) * sizeof(float) + 256 * 4 + 64 * 8;
-    static size_t attr_m = 0;
-    if (shm_m > attr_m) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&score_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m);
-        attr_m = shm_m;
+    {
+        std::lock_guard<std::mutex> lock(attr_mu);
+        if (shm_m > attr_merge[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m) != hipSuccess) {
+                (void)hipGetLastError();
+                return MR_EUNSUPPORTED;
+            }
+            attr_merge[dev] = shm_m;
+        }
     }
+    hipLaunchKernelGGL(score_part_topk_kernel, dim3(P, (unsigned)((nU + SBM - 1) / SBM)), dim3(kThreads), shm, st, U, E, (int)nU, (int)M, d, k, P, pc, cand,
+                       cand_val, pmax, psum, labels, inv_temp, row_lab);
     hipLaunchKernelGGL(score_merge_kernel, dim3((unsigned)nU), dim3(64), shm_m, st, cand, cand_val, pmax, psum, P, k, n_valid, top_val, top_idx, labels,
                        row_lse, label_rank);
     return check_launch();

@@ -101,6 +101,13 @@ class RecDataset(Dataset):
     def __len__(self):
         return len(self.sequence)
 
+    def balance_weights(self):
+        """Length proxy per sample for ``parallel.ShardedLoader``'s token-balanced deal (items per sequence), from the stored lists --
+        no sample is built; None while prefixes are drawn at random (training)."""
+        if self.sample:
+            return None
+        return [min(len(s), self.max_items + 1) for s in self.sequence]
+
     def __getitem__(self, index) -> Tuple[int, List[int]]:
         seq = self.sequence[index]
         if self.sample:

@@ -256,6 +256,25 @@ class InputError(ValueError):
     """A batch violated the encoder's input contract (found by the packing kernel, reported at the next ``check_inputs``)."""
 
 
+def check_module_inputs(*objs) -> None:
+    """Surface deferred input-contract violations (``InputError``) of every encoder reachable from the given modules: the object itself,
+    its ``.model`` / ``.merged_model`` and theirs.  ONE device read per encoder: the loops call it where they synchronise anyway (after a
+    catalog encode, at a logged training step, at an epoch end)."""
+    seen, todo = set(), [o for o in objs if o is not None]
+    while todo:
+        o = todo.pop()
+        if id(o) in seen:
+            continue
+        seen.add(id(o))
+        runner = getattr(o, "runner", None)
+        if isinstance(runner, EncoderRunner):
+            runner.check_inputs()
+        for name in ("model", "merged_model"):
+            child = getattr(o, name, None)
+            if child is not None and not isinstance(child, (str, bytes)):
+                todo.append(child)
+
+
 class EncoderRunner:
     """Runs the BLaIR (RoBERTa) or Recformer (Longformer) forward on packed tokens with HIP kernels.
 

@@ -126,6 +126,16 @@ class TaskVectorMergingModuleBase(nn.Module):
         self.load_weights()
         return self.model(batch)
 
+    def encode_normalized(self, batch, normalize: bool, lens=None, validate=True) -> torch.Tensor:
+        """The evaluation loops' form of ``forward`` (RecModule._encode): re-merge, then the model's encode with the L2 normalisation
+        fused into the pooling kernel and the input checks deferred to ``check_inputs()``."""
+        self.load_weights()
+        return self.model.encode_normalized(batch, normalize=normalize, lens=lens, validate=validate)
+
+    def check_inputs(self) -> None:
+        """Deferred input-contract check of the wrapped encoder (``BaseEncoderModel.check_inputs``): raises ``engine.InputError``."""
+        self.model.check_inputs()
+
     train_mode = "f32"  # "bf16x3": split-precision MFMA products in the training graph (DistillTrainer sets it for bf16-mixed / 16-mixed)
 
     def forward_with_grad(self, batch):

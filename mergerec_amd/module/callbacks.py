@@ -39,7 +39,11 @@ class ItemEncoderMixin:
                 local = torch.cat(rows, dim=0)
             else:  # a rank may own no rows of a tiny catalog
                 local = torch.empty(0, pl_module.model.spec.hidden, dtype=torch.float32, device=pl_module.device)
-            return shard.gather_rows(local)
+            table = shard.gather_rows(local)
+            from ..engine import check_module_inputs
+
+            check_module_inputs(pl_module)  # a catalog row with an out-of-range id must not become an embedding silently
+            return table
         finally:
             pl_module.train(was_training)
 

@@ -144,7 +144,9 @@ class BaseEncoderModel(nn.Module):
     def forward(self, batch) -> torch.Tensor:
         if not isinstance(batch, Mapping) and not hasattr(batch, "keys"):
             raise TypeError("Input must be a BatchEncoding object.")  # encoder/_base.py:34-35
-        return self.runner.encode(self._weights, batch, self.device, normalize=False)
+        # the public forward reports a bad batch at once, like nn.Embedding's IndexError upstream (one device read); the evaluation
+        # and training loops go through encode_normalized / forward_with_grad, whose checks are deferred to ``check_inputs()``
+        return self.runner.encode(self._weights, batch, self.device, normalize=False, validate="now")
 
     # -- fine-tuning (finetune_train.py): the same forward with an autograd edge to the arena ------
     def train_leaf(self) -> torch.Tensor:

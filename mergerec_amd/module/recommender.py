@@ -12,6 +12,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..engine import check_module_inputs
 from ..autograd import cross_entropy_rows, matmul_nt
 from ..configs import NegativeSampleOption
 from ..evaluator import Evaluator
@@ -188,7 +189,10 @@ class RecModule(_Base):
         """Epoch end of the test / validation loop.  With several ranks (``self._shard`` set by the Trainer: each rank stepped through
         its own share of the users) the per-user results are put back into the dataloader's row order on every rank first -- two
         all-gathers: one float block (lse, label logit, user embedding), one int block (label rank, label, top-k ids) -- so the
-        metrics, the loss and every ``eval_*`` attribute are those of the single-process run, bit for bit."""
+        metrics, ranked indices, label ranks, label logits, embeddings and every ``eval_*`` attribute are those of the single-process run
+        bit for bit.  The loss (mean of log-sum-exp minus label logit) agrees to rounding: a shard's batches hold fewer users, and the
+        scoring entry picks its route per call from users x M (selection inside the scoring kernel beyond 128 MB of scores, the staged
+        pair below), whose log-sum-exp sums differ in order -- at catalog sizes where every batch is staged anyway it is bit-equal too."""
         cat = lambda xs, empty: torch.cat(xs, dim=0) if xs else empty
         dev = self.device
         d = self.item_embeddings.shape[1] if self.item_embeddings is not None else 0
@@ -199,8 +203,7 @@ class RecModule(_Base):
         ranks = cat(self._ranks, torch.empty(0, dtype=torch.int32, device=dev))
         lse, lab = cat(self._lse, torch.empty(0, device=dev)), cat(self._lab, torch.empty(0, device=dev))
         scores = torch.cat(self.eval_scores, dim=0) if (self.keep_scores and self.eval_scores) else None
-        if hasattr(self.model, "check_inputs"):
-            self.model.check_inputs()
+        check_module_inputs(self)  # deferred input checks of every encoder under this module (also a merging module's)
         shard = getattr(self, "_shard", None)
         if shard is not None and shard.world > 1:
             fl = shard.gather_rows(torch.cat([lse.view(-1, 1), lab.view(-1, 1), users], dim=1))

@@ -1,11 +1,12 @@
 """One-process-per-GPU sharding of the path over the 8 GPUs of a node (RCCL over xGMI via
 torch.distributed backend "nccl").  The reference is single-GPU; this partitioning is new.
 
-  merge      : two placements.  "replicated" (bench default): every rank keeps all task vectors (8 x 0.5 GB of 288 GB) and merges the
-               whole arena locally with the N = 1 kernel call -- no collective (HBM streams a merge in < 1 ms; the all-gather below alone
-               would take longer over xGMI).  "sliced" (``sharded_merge``): rank r merges arena elements [lo_r, hi_r) (64-float aligned
-               slices) with the same kernel, then ONE all-gather of the merged slices fills every rank's arena (P_pad/8 * 4 B = 62 MB per
-               rank for BLaIR-base) -- for task vectors that do not fit replicated.  No other collective touches parameters.
+  merge      : two placements.  "sliced" (``sharded_merge``; the default of ``load_merging_module`` and of bench.py with several ranks:
+               north_star's split): rank r holds elements [lo_r, hi_r) of the base vector and of every task vector (64-float aligned
+               slices), merges that arena slice with the same kernel, then ONE all-gather of the merged slices fills every rank's arena
+               (P_pad/8 * 4 B = 62 MB per rank for BLaIR-base).  "replicated" (alpha learning, ``merge_train.py``; ``--merge-placement
+               replicated`` in the bench): every rank keeps all task vectors (8 x 0.5 GB of 288 GB) and merges the whole arena locally
+               with the N = 1 kernel call -- no collective.  No other collective touches parameters.
   catalog    : item rows are split in contiguous blocks; each rank encodes its block, one all-gather of the
                (M/world, d) embedding blocks gives every rank the full E (row index == item id is kept).
   users      : data-parallel over test sequences, token-balanced across ranks (``balanced_share``); scoring is local against the full E.
@@ -228,14 +229,15 @@ class ShardedLoader:
                 and hasattr(loader.dataset, "__getitem__") and loader.batch_size is not None:
             ds = loader.dataset
             n = len(ds)
-            wts = None
-            if balance and n:
-                probe = ds[0]
-                if isinstance(probe, (tuple, list)) and len(probe) == 2 and hasattr(probe[1], "__len__"):
-                    wts = torch.tensor([len(ds[i][1]) for i in range(n)])
+            wts = self._balance_weights(ds, n) if balance and n else None
             self.index_lists = deal_rows(wts, n, W)
+            # the same loader over this rank's rows: every DataLoader option that does not depend on the sampler is kept
+            extra = dict(pin_memory=loader.pin_memory, worker_init_fn=loader.worker_init_fn, timeout=loader.timeout)
+            if loader.num_workers > 0:
+                extra.update(persistent_workers=loader.persistent_workers, prefetch_factor=loader.prefetch_factor,
+                             multiprocessing_context=loader.multiprocessing_context)
             self.local = DataLoader(Subset(ds, self.index_lists[r].tolist()), batch_size=loader.batch_size, collate_fn=loader.collate_fn,
-                                    shuffle=False, num_workers=loader.num_workers, drop_last=False)
+                                    shuffle=False, num_workers=loader.num_workers, drop_last=False, **extra)
             return
         batches = loader if isinstance(loader, (list, tuple)) else list(loader)
         sizes = [_batch_rows(b) for b in batches]
@@ -246,6 +248,28 @@ class ShardedLoader:
         self.index_lists = [torch.arange(starts[lo], starts[hi]) for lo, hi in blocks]
         lo, hi = blocks[r]
         self.local = batches[lo:hi]
+
+    def _balance_weights(self, ds, n: int) -> Optional[torch.Tensor]:
+        """One weight per sample for the token-balanced deal, computed ONCE: from the dataset's own length table when it has one
+        (``balance_weights()``: no sample is materialised), else by rank 0 walking the dataset and one broadcast -- not by every rank
+        calling ``ds[i]`` n times before its first batch.  None: samples carry no length proxy -> contiguous blocks."""
+        if hasattr(ds, "balance_weights"):
+            w = ds.balance_weights()
+            return None if w is None else torch.as_tensor(w, dtype=torch.int64)
+        probe = ds[0]
+        if not (isinstance(probe, (tuple, list)) and len(probe) == 2 and hasattr(probe[1], "__len__")):
+            return None
+        wts = torch.zeros(n, dtype=torch.int64)
+        if self.rank == 0:
+            wts = torch.tensor([len(ds[i][1]) for i in range(n)], dtype=torch.int64)
+        if dist.get_backend(self.group) == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device())
+            buf = wts.to(dev)
+            dist.broadcast(buf, src=0, group=self.group)
+            wts = buf.cpu()
+        else:
+            dist.broadcast(wts, src=0, group=self.group)
+        return wts
 
     def __iter__(self):
         return iter(self.local)

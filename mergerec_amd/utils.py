@@ -9,6 +9,7 @@ from typing import Dict, Iterable, List, Optional, Sequence
 
 import torch
 
+from .engine import check_module_inputs
 from .module.callbacks import ItemEncodingCallback
 from .module.recommender import RecModule
 from .parallel import allreduce_mean_grads, shard_indices
@@ -210,12 +211,15 @@ class DistillTrainer:
                 opt.step()
                 self.global_step += 1
                 self.history.append(loss.detach())  # stays on the device: no host sync per step unless this step is logged
+                if self.global_step == 1 or (self.verbose and self.global_step % self.log_every_n_steps == 0):
+                    check_module_inputs(module)  # bad ids must not train alpha on clamped embeddings: first step + every logged step
                 if self.verbose and self.global_step % self.log_every_n_steps == 0:
                     print(f"step {self.global_step}: train/loss {float(self.history[-1]):.6f}")
                 self._hook("on_train_batch_end", module, loss, batch, batch_idx)
                 if self.max_steps is not None and self.max_steps >= 0 and self.global_step >= self.max_steps:
                     done = True
                     break
+            check_module_inputs(module)
             self._hook("on_train_epoch_end", module)
             vals = datamodule.val_dataloader() if hasattr(datamodule, "val_dataloader") else []
             if vals:
@@ -229,6 +233,7 @@ class DistillTrainer:
                         cnt += n
                     # Lightning's on_epoch aggregation of self.log("val/loss", ...): batch-size-weighted mean per dataloader
                     self.callback_metrics[f"val/loss_epoch/dataloader_idx_{di}"] = torch.tensor(tot / max(cnt, 1))
+                check_module_inputs(module)
                 module.on_validation_epoch_end()
                 self._hook("on_validation_epoch_end", module)
             self.current_epoch += 1
@@ -358,6 +363,8 @@ class FinetuneTrainer:
                 leaf.grad = None
                 module.model.arena_changed()
                 self.global_step += 1
+                if self.global_step == 1 or (self.verbose and self.global_step % self.log_every_n_steps == 0):
+                    check_module_inputs(module)  # first optimizer step + every logged step (they synchronise anyway)
                 if self.verbose and self.global_step % self.log_every_n_steps == 0:
                     print(f"epoch {self.current_epoch} step {self.global_step}: train/loss {float(self.history[-1]):.6f} lr {self.lr_history[-1]:.3e}",
                           flush=True)
@@ -365,6 +372,7 @@ class FinetuneTrainer:
                     stop = True
                     break
             module.model.weights_updated()  # the arena changed under the inference path's bf16 weight pieces
+            check_module_inputs(module)
             self._hook("on_train_epoch_end", module)
             metrics = self._validate(module, datamodule)
             score = metrics.get(self.monitor)

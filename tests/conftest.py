@@ -13,37 +13,35 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "heavy: large-model parity check (minutes); skipped once the session is past its time budget")
+    config.addinivalue_line("markers", "heavy: large-model parity check (minutes); runs first in the session, MERGEREC_HEAVY_TESTS=0 opts out")
 
 
-# The large-model parity checks (Recformer-large / BLaIR-large inference, the Recformer-large collaborative-merging step: 355-435 M
-# parameters, several state dicts regenerated from seeds on the host) add about five minutes to the GPU suite (eight in all).  They run by
-# default while the session is inside its time budget -- a slow box skips the remaining ones instead of running into a caller's time
-# limit; MERGEREC_HEAVY_TESTS=1 always runs them, =0 never.  Their last outputs are kept in profiles/r02_recformer_realscale_parity.txt
-# and profiles/r02_merge_train_step_parity.txt.
+# The large-model parity checks (Recformer-large / BLaIR-large inference, the Recformer-large collaborative-merging steps: 355-435 M
+# parameters, state dicts regenerated from seeds on the host once per module) are DETERMINISTIC members of the GPU suite: they are moved
+# to the front of the session, so which of them run no longer depends on how fast the box got through the other tests (a
+# time-budget gate made "148 passed" unreproducible on a slower box).  MERGEREC_HEAVY_TESTS=0 is the one explicit opt-out (then every
+# heavy test is reported as skipped, loudly, in the summary line).
 heavy = pytest.mark.heavy
-_T0 = [None]
-HEAVY_BUDGET_S = float(os.environ.get("MERGEREC_HEAVY_BUDGET_S", "420"))
 
 
-def pytest_sessionstart(session):
-    import time
-
-    _T0[0] = time.monotonic()
+def pytest_collection_modifyitems(config, items):
+    first = [it for it in items if it.get_closest_marker("heavy") is not None]
+    rest = [it for it in items if it.get_closest_marker("heavy") is None]
+    # keep module-scoped fixtures together: stable sort by file inside the heavy block
+    first.sort(key=lambda it: str(it.fspath))
+    items[:] = first + rest
 
 
 def pytest_runtest_setup(item):
-    if item.get_closest_marker("heavy") is None:
-        return
-    import time
+    if item.get_closest_marker("heavy") is not None and os.environ.get("MERGEREC_HEAVY_TESTS", "") == "0":
+        pytest.skip("large-model parity check switched off by MERGEREC_HEAVY_TESTS=0")
 
-    mode = os.environ.get("MERGEREC_HEAVY_TESTS", "")
-    if mode == "0":
-        pytest.skip("large-model parity check switched off (MERGEREC_HEAVY_TESTS=0); outputs of the last run are in profiles/")
-    elapsed = time.monotonic() - (_T0[0] or time.monotonic())
-    if mode != "1" and elapsed > HEAVY_BUDGET_S:
-        pytest.skip(f"large-model parity check skipped: the session is {elapsed:.0f} s in, past its {HEAVY_BUDGET_S:.0f} s budget for starting one "
-                    "(MERGEREC_HEAVY_TESTS=1 runs it regardless); outputs of the last run are in profiles/")
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    skipped = [r for r in terminalreporter.stats.get("skipped", []) if "MERGEREC_HEAVY_TESTS=0" in str(getattr(r, "longrepr", ""))]
+    if skipped:
+        terminalreporter.write_line(f"WARNING: {len(skipped)} large-model parity check(s) were switched off by MERGEREC_HEAVY_TESTS=0 -- "
+                                    "this run does not cover BLaIR-large / Recformer-large", red=True, bold=True)
 
 
 @pytest.fixture(scope="session")

@@ -174,6 +174,83 @@ def test_alpha_gradient_end_to_end_matches_oracle_autograd(learn, mode):
         assert float((got - p.grad).abs().max()) <= 5e-3 * scale, (k, got, p.grad)
 
 
+def test_bad_token_ids_raise_on_every_path_that_packs():
+    """the packing kernel clamps a bad id and flags it; every loop that packs must read the flag.  The bare public
+    forwards report at once (like nn.Embedding's IndexError upstream); the alpha-learning loop at its first step; a RecModule that wraps
+    a merging module at the epoch end; a catalog encode right after the encode."""
+    from mergerec_amd.engine import InputError, check_module_inputs
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchDistillationSequence, BatchItem, BatchSequence
+    from mergerec_amd.module import DistillSequenceModule, RecModule
+    from mergerec_amd.module.callbacks import ItemEncoderMixin
+    from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
+    from mergerec_amd.utils import DistillTrainer
+    from tests.test_path_gpu import _tiny_model
+
+    g2 = load_golden("g2_merger.pt")
+    cfgd = g2["cfg"]
+    ids, mask = g2["input_ids"], g2["attention_mask"]
+    B = ids.shape[0]
+    bad_ids = ids.clone()
+    bad_ids[1, 2] = cfgd["vocab"] + 5
+    good, bad = {"input_ids": ids, "attention_mask": mask}, {"input_ids": bad_ids, "attention_mask": mask}
+    model = _tiny_model(cfgd)
+    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, g2["pretrain"], [dict(f) for f in g2["finetunes"]], set(),
+                             disable_softmax=True, initial_per_weight=0.3)
+    dev = lambda b: {k: v.to(DEV) for k, v in b.items()}
+    # bare forwards: at once
+    with pytest.raises(InputError, match="input_ids"):
+        model.forward(dev(bad))
+    with torch.no_grad():
+        with pytest.raises(InputError, match="input_ids"):
+            mm.forward(dev(bad))
+        mm.forward(dev(good))
+    # the training graph under the merging module: deferred, visible through the module tree
+    out = mm.forward_with_grad(dev(bad))
+    assert torch.isfinite(out).all()
+    with pytest.raises(InputError, match="input_ids"):
+        check_module_inputs(mm)
+    check_module_inputs(mm)  # cleared
+    # a RecModule around the merging module (the hasattr guard of r02 skipped it)
+    rec = RecModule(model=mm, evaluator=Evaluator(["NDCG"], [5]), similarity="cosine")
+    rec.eval()
+    gen = torch.Generator().manual_seed(3)
+    rec.item_embeddings = torch.nn.Parameter(torch.nn.functional.normalize(torch.randn(40, cfgd["hidden"], generator=gen), dim=-1).to(DEV), requires_grad=False)
+    rec.on_test_epoch_start()
+    with torch.no_grad():
+        rec.test_step(BatchSequence(sequence=bad, labels=torch.randint(0, 40, (B,), generator=gen)).to(DEV), 0)
+        with pytest.raises(InputError, match="input_ids"):
+            rec.on_test_epoch_end()
+    # the catalog encode
+    rec2 = RecModule(model=model, evaluator=Evaluator(["NDCG"], [5]), similarity="cosine")
+    with pytest.raises(InputError, match="input_ids"):
+        ItemEncoderMixin.encode_items([BatchItem(items=good), BatchItem(items=bad)], rec2)
+    assert ItemEncoderMixin.encode_items([BatchItem(items=good)], rec2).shape == (B, cfgd["hidden"])
+
+    # one alpha-learning step on a bad batch: the trainer stops at step 1 instead of optimising alpha on clamped embeddings
+    items = [torch.nn.functional.normalize(torch.randn(m, cfgd["hidden"], generator=gen), dim=-1) for m in (50, 77)]
+    teachers = [torch.randn(B, m, generator=gen).clamp(-1, 1) for m in (50, 77)]
+    mod = DistillSequenceModule(mm, teachers, SinglePseudoLabelKDLoss(0.05, 1000.0), "cosine",
+                                trainable_args_kwargs={"freeze_global_weight": True, "freeze_global_bias": True})
+    mod.item_embeddings = items
+
+    class OneBatch:
+        def __init__(self, enc):
+            self.enc = enc
+
+        def setup(self, stage):
+            pass
+
+        def train_dataloader(self):
+            return [BatchDistillationSequence(dataset_indexes=[i % 2 for i in range(B)], sequence_ids=torch.arange(B), sequence=self.enc)]
+
+    with pytest.raises(InputError, match="input_ids"):
+        DistillTrainer(max_steps=1, verbose=False).fit(mod, OneBatch(bad))
+    hist = DistillTrainer(max_steps=1, verbose=False).fit(mod, OneBatch(good))
+    assert len(hist) == 1 and hist[0] == hist[0]
+
+
 def test_merge_train_cli_runs_and_moves_alpha(tmp_path):
     import sys
 
@@ -414,20 +491,11 @@ def test_whole_merge_train_step_at_real_dimensions_matches_reference(g19_inputs,
           f"worst gradient deviation {worst:.1e} of the group's largest entry")
 
 
-@heavy
-@pytest.mark.parametrize("case", [0, 1])
-def test_whole_merge_train_step_recformer_large_matches_reference(case):
-    """g20 (oracle/gen_golden_merge_train_recformer_large.py): BASELINE configs[4]'s model and job -- one collaborative-merging step of the
-    reference with Recformer-LARGE (24 x 1,024, 435 M parameters; its own RecformerModel driving transformers' LongformerEncoder) and 4
-    fine-tuned checkpoints on the CPU (8 exceed the build container's memory) -- loss and d loss / d (per_weights, global_weights, global_biases), task-wise and layer-wise (25
-    groups), against the HIP step."""
-    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
-    from mergerec_amd.model_batch import BatchDistillationSequence
-    from mergerec_amd.module import DistillSequenceModule, ModelType
-    from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
-
+@pytest.fixture(scope="module")
+def g20_inputs():
+    """the regenerated inputs of fixture g20 (Recformer-large: pretrained + 4 fine-tuned state dicts of 435 M parameters each, item
+    matrices, teacher scores), built ONCE for the four tests that use them (two reference cases, two 8-domain property cases)"""
     fx = load_golden("g20_merge_train_step_recformer_large.pt")
-    c = fx["cases"][case]
     cfg = O.EncoderConfig(**{k: v for k, v in fx["cfg"].items() if k in O.EncoderConfig.__dataclass_fields__})
     pre0 = O.random_state_dict(O.recformer_param_shapes(cfg), seed=fx["pretrain_seed"], std=fx["pretrain_std"])
     pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])
@@ -443,10 +511,21 @@ def test_whole_merge_train_step_recformer_large_matches_reference(case):
     teachers = [torch.randn(B, m, generator=g).clamp(-1, 1) for m in fx["catalog_sizes"]]
     assert abs(float(sum(x.double().sum() for x in items)) - fx["item_checksum"]) < 1e-6 * abs(fx["item_checksum"]) + 1e-6
     assert abs(float(sum(x.double().sum() for x in teachers)) - fx["teacher_checksum"]) < 1e-6 * abs(fx["teacher_checksum"]) + 1e-6
+    return fx, pre, fts, items, teachers
+
+
+def _g20_step(g20_inputs, case, copies, per_weight):
+    """one collaborative-merging step on g20's inputs with the fine-tuned checkpoints listed `copies` times -> (module, loss)"""
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchDistillationSequence
+    from mergerec_amd.module import DistillSequenceModule, ModelType
+    from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
+
+    fx, pre, fts, items, teachers = g20_inputs
+    c = fx["cases"][case]
     model = ModelType.RECFORMER_LARGE.value(model_kwargs={"init_seed": 1, "device": DEV})
-    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[c["learn_type"]], model, pre, [dict(f) for f in fts], set(),
-                             disable_softmax=True, initial_per_weight=fx["initial_per_weight"])
-    del fts
+    mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[c["learn_type"]], model, pre, [dict(f) for _ in range(copies) for f in fts], set(),
+                             disable_softmax=True, initial_per_weight=per_weight)
     assert list(mm.per_weights.keys()) == c["groups"]
     mod = DistillSequenceModule(mm, teachers, SinglePseudoLabelKDLoss(fx["temperature"], fx["coefficient"]), "cosine")
     mod.item_embeddings = items
@@ -455,6 +534,19 @@ def test_whole_merge_train_step_recformer_large_matches_reference(case):
     mod.train()
     loss = mod.training_step(batch.to(DEV), 0)
     loss.backward()
+    return mm, loss
+
+
+@heavy
+@pytest.mark.parametrize("case", [0, 1])
+def test_whole_merge_train_step_recformer_large_matches_reference(g20_inputs, case):
+    """g20 (oracle/gen_golden_merge_train_recformer_large.py): BASELINE configs[4]'s model and job -- one collaborative-merging step of the
+    reference with Recformer-LARGE (24 x 1,024, 435 M parameters; its own RecformerModel driving transformers' LongformerEncoder) and 4
+    fine-tuned checkpoints on the CPU (8 exceed the build container's memory) -- loss and d loss / d (per_weights, global_weights, global_biases), task-wise and layer-wise (25
+    groups), against the HIP step."""
+    fx = g20_inputs[0]
+    c = fx["cases"][case]
+    mm, loss = _g20_step(g20_inputs, case, copies=1, per_weight=fx["initial_per_weight"])
     torch.testing.assert_close(loss.detach().cpu(), c["loss"], rtol=5e-5, atol=5e-5)
     worst = 0.0
     for name in ("per_weights", "global_weights", "global_biases"):
@@ -465,3 +557,37 @@ def test_whole_merge_train_step_recformer_large_matches_reference(case):
             assert float((got - want).abs().max()) <= 5e-3 * scale, (name, k, got, want)
     print(f"[merge_train step, Recformer-large x 4 domains, {c['learn_type']}] loss {float(loss.detach()):.6f} (reference {float(c['loss']):.6f}); "
           f"worst gradient deviation {worst:.1e} of the group's largest entry")
+
+
+@heavy
+@pytest.mark.parametrize("case", [0, 1])
+def test_eight_domain_recformer_large_step_reproduces_the_four_domain_reference(g20_inputs, case):
+    """BASELINE configs[4] at its stated size -- 8 domains x Recformer-large (a 13.9 GB task-vector matrix, 25 alpha groups layer-wise) --
+    as a property of fixture g20, no new fixture: with task vectors 5-8 equal to 1-4 and every coefficient halved, the merged model is
+    g20's 4-domain model (to the rounding of an 8-term instead of a 4-term sum), so the loss must reproduce the reference's, d loss /
+    d per_weight_i must equal the reference's d / d per_weight_i (the contraction of the same gradient with the same task vector: the
+    coefficient's value does not enter it), and the twin coefficients' gradients must agree BIT FOR BIT (d_{i+4} == d_i: same kernel, same
+    operands, deterministic reduction order).  weight_learning/module/layer_wise.py:64-83, _base.py:78-81."""
+    fx = g20_inputs[0]
+    c = fx["cases"][case]
+    n = len(fx["finetune_seeds"])
+    mm, loss = _g20_step(g20_inputs, case, copies=2, per_weight=fx["initial_per_weight"] / 2)
+    assert mm.task_vectors_tensor.shape[0] == 2 * n
+    torch.testing.assert_close(loss.detach().cpu(), c["loss"], rtol=5e-5, atol=5e-5)
+    worst = 0.0
+    for k in c["groups"]:
+        got = mm.per_weights[k].grad.cpu()
+        assert got.shape == (2 * n,)
+        assert torch.equal(got[:n], got[n:]), (k, got)               # twins: bit for bit
+        want = c["grads"]["per_weights"][k]
+        scale = max(float(want.abs().max()), 1e-3)
+        worst = max(worst, float((got[:n] - want).abs().max()) / scale)
+        assert float((got[:n] - want).abs().max()) <= 5e-3 * scale, (k, got, want)
+        # global weight / bias multiply the (halved) per-weights / add to all 8 coefficients: d/d gw = sum_i per_i * d_i is the reference's,
+        # d/d gb = sum over 8 = twice the reference's sum over 4
+        gw, gb = mm.global_weights[k].grad.cpu(), mm.global_biases[k].grad.cpu()
+        wgw, wgb = c["grads"]["global_weights"][k], c["grads"]["global_biases"][k]
+        assert float((gw - wgw).abs().max()) <= 5e-3 * max(float(wgw.abs().max()), 1e-3), (k, gw, wgw)
+        assert float((gb - 2 * wgb).abs().max()) <= 5e-3 * max(float((2 * wgb).abs().max()), 1e-3), (k, gb, wgb)
+    print(f"[merge_train step, Recformer-large x 8 domains (4 + 4 twins), {c['learn_type']}] loss {float(loss.detach()):.6f} (reference, 4 domains: "
+          f"{float(c['loss']):.6f}); twin gradients bit-equal; worst deviation from the reference's d/d per_weights {worst:.1e} of the group's largest entry")
