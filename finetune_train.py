@@ -113,7 +113,7 @@ def main(argv=None):
     random.seed(config.seed + rank)
     np.random.seed(config.seed + rank)
     torch.manual_seed(config.seed)
-    print("note: the training graph has no dropout (the reference trains under HF's hidden / attention dropout 0.1); see DESIGN.md section 7")
+    config.model_kwargs.setdefault("dropout_seed", config.seed + rank)  # HF dropout in train() mode, mask keyed by --seed (csrc/dropout.h)
     if not config.tokenizer_path:
         raise SystemExit("--tokenizer_path <local tokenizer directory> is required (the box is offline)")
     negative_sample = NegativeSampleConfig(k=config.negative_k, in_batch=config.negative_in_batch)

@@ -279,6 +279,35 @@ int mr_cls_pool_normalize_f32(const float* x, int64_t ldx, const int32_t* cu_seq
 int mr_gather_rows_f32(const float* x, int64_t ldx, const int32_t* row_idx, int n, int d, float* out, int64_t ldo,
                        mr_stream_t stream);
 
+/* ---- training graph: dropout ------------------------------------------------------------------ */
+
+/* The reference optimises alpha (merge_train.py:178-196) and fine-tunes under lightning.Trainer.fit, i.e. in train() mode with HF's
+ * hidden_dropout_prob = attention_probs_dropout_prob = 0.1 and RecformerEmbeddings.dropout (recformer/models.py:93,135).  torch's Philox
+ * stream cannot be reproduced outside torch, so the mask here is a documented pure function (csrc/dropout.h, restated in
+ * oracle/ref_cpu.py dropout_keep):   keep = lowbias32(row * 0x9E3779B1 + col * 0x85EBCA77 + key) >= floor(p * 2^32),  y = keep ? x / (1 - p) : 0,
+ * recomputed in the backward kernels (nothing is stored).  key = mr_dropout_site_key(seed, step, layer, site); sites: 0 embedding
+ * LayerNorm output, 1 attention probabilities (row = query token * H + head, col = key position), 2 attention-output dense, 3 FFN-output
+ * dense (row = packed token, col = feature), 4 Longformer global row (row = sequence * H + head, col = key position).
+ * drop_p = 0 in any *_train_* entry point is the plain kernel, bit for bit; inference never calls these. */
+int mr_dropout_site_key(uint32_t seed, uint32_t step, uint32_t layer, uint32_t site, uint32_t* key_out);
+/* out[t, c] = dropout(x[t, c]) (+ residual[t, c]); in place allowed (out == x).  The backward of the same site is the same call on dY. */
+int mr_dropout_rows_f32(const float* x, int64_t ldx, int T, int d, float drop_p, uint32_t drop_key, const float* residual, int64_t ldr,
+                        float* out, int64_t ldo, mr_stream_t stream);
+/* mr_attn_f32 / mr_attn_split_work_f32 / mr_attn_global_row_f32 and their backward kernels with dropout on the attention
+ * probabilities (transformers RobertaSelfAttention / LongformerSelfAttention: nn.functional.dropout(attn_probs, p, training)). */
+int mr_attn_train_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh, int max_len, float scale,
+                      int window, float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream);
+int mr_attn_split_work_train_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale,
+                                 int window, int products, float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream);
+int mr_attn_global_row_train_f32(const float* qg, const float* kvg, const int32_t* cu_seqlens, int B, int H, int dh, int max_len, float scale,
+                                 float drop_p, uint32_t drop_key, float* ctx, int compact, mr_stream_t stream);
+int mr_attn_bwd_train_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H,
+                          int dh, int max_len, float scale, int window, float drop_p, uint32_t drop_key, float* rowstat, float* dqkv,
+                          mr_stream_t stream);
+int mr_attn_global_row_bwd_train_f32(const float* qg, const float* kvg, const float* ctx_cls, const float* dctx_cls, const int32_t* cu_seqlens,
+                                     int B, int H, int dh, float scale, float drop_p, uint32_t drop_key, float* dqg, float* dkvg,
+                                     mr_stream_t stream);
+
 /* ---- scoring + evaluator -------------------------------------------------------------------- */
 
 /* Per row of scores (nrows, ncols; leading dimension ld): the k largest entries in canonical order

@@ -99,9 +99,9 @@ def main(argv=None):
     from mergerec_amd.utils import DistillTrainer, remove_duplicate_prefix, test_model
 
     torch.manual_seed(config.seed)
-    if rank == 0:
-        print("note: the training graph has no dropout (the reference optimises alpha under HF's hidden / attention dropout 0.1, "
-              "Lightning's train() mode); see DESIGN.md section 7")
+    # the training graph applies HF's dropout (hidden / attention 0.1 unless --model_kwargs overrides them) in train() mode; its
+    # counter-based mask is keyed by --seed (offset by the rank: shards are not masked identically) unless dropout_seed is given
+    config.model_kwargs.setdefault("dropout_seed", config.seed + rank)
     recformer = config.model_type.startswith("RECFORMER")
     if not config.tokenizer_path:
         raise SystemExit("--tokenizer_path <local tokenizer directory> is required (the box is offline)")

@@ -27,6 +27,7 @@ c_i64 = ctypes.c_int64
 c_f = ctypes.c_float
 c_d = ctypes.c_double
 c_sz = ctypes.c_size_t
+c_u32 = ctypes.c_uint32
 
 # name -> (restype, argtypes); mirrors include/mergerec_hip.h
 SIGNATURES = {
@@ -77,6 +78,13 @@ SIGNATURES = {
     "mr_attn_split_q_rows": (c_i, [c_i, c_i]),
     "mr_attn_work_plan": (c_i64, [c_p, c_i, c_i, c_p, c_i64]),
     "mr_attn_split_work_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_i, c_p, c_p]),
+    "mr_dropout_site_key": (c_i, [c_u32, c_u32, c_u32, c_u32, c_p]),
+    "mr_dropout_rows_f32": (c_i, [c_p, c_i64, c_i, c_i, c_f, c_u32, c_p, c_i64, c_p, c_i64, c_p]),
+    "mr_attn_train_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p]),
+    "mr_attn_split_work_train_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_i, c_f, c_u32, c_p, c_p]),
+    "mr_attn_global_row_train_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u32, c_p, c_i, c_p]),
+    "mr_attn_bwd_train_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p, c_p]),
+    "mr_attn_global_row_bwd_train_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_u32, c_p, c_p, c_p]),
     "mr_attn_global_row_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "mr_cls_pool_normalize_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_p, c_p]),
     "mr_gather_rows_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_p, c_i64, c_p]),

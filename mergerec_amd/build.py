@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "lib" / "obj"
 LIB = HERE / "lib" / "libmergerec_hip.so"
-SOURCES = ["capi.hip", "merge.hip", "embed.hip", "gemm.hip", "gemm_bf16.hip", "attn.hip", "attn_bf16.hip", "score.hip", "score_fused.hip", "select.hip", "distill.hip", "backward.hip", "attn_bwd.hip", "optim.hip"]
+SOURCES = ["capi.hip", "merge.hip", "embed.hip", "gemm.hip", "gemm_bf16.hip", "attn.hip", "attn_bf16.hip", "score.hip", "score_fused.hip", "select.hip", "distill.hip", "backward.hip", "attn_bwd.hip", "optim.hip", "dropout.hip"]
 # merge.hip must not contract a*b+c into an FMA: the reference rounds the products separately.
 EXTRA = {"merge.hip": ["-ffp-contract=off"], "gemm_bf16.hip": os.environ.get("MR_GEMM_DEFS", "").split(),
          "score_fused.hip": os.environ.get("MR_SCORE_DEFS", "").split()}
@@ -39,7 +39,7 @@ def _stale(out: Path, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> Path:
     cc = hipcc()
     OBJ.mkdir(parents=True, exist_ok=True)
-    headers = [CSRC / "common.h", HERE.parent / "include" / "mergerec_hip.h"]
+    headers = [CSRC / "common.h", CSRC / "dropout.h", HERE.parent / "include" / "mergerec_hip.h"]
 
     def compile_one(src: str):
         s, o = CSRC / src, OBJ / (src.replace(".hip", ".o"))

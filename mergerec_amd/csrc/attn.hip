@@ -8,6 +8,7 @@
 // round trip or cross-lane traffic is needed for it except one lane^32 exchange for the row max / row sum.
 // Attention is ~6 % of the encoder's FLOPs.
 #include "common.h"
+#include "dropout.h"
 #include <math.h>
 
 namespace {
@@ -24,11 +25,14 @@ constexpr int kTileFloats = 32 * kKS + 32 * kVS;
 // [q_base + 32w, +32).  All 256 threads stage each 32-key K and V tile through double-buffered LDS
 // (coalesced 256-B rows; the next tile's global loads are issued before the current tile's 64 MFMAs and
 // stored to the idle buffer after them, one barrier per tile), every wave reads its MFMA operands from LDS.
-template <bool WINDOWED>
+// DROP (training graph only): the normalised probabilities are masked by mr::dropout_keep(key, query token * H + head, key position)
+// and scaled by 1 / (1 - p) before they multiply V -- the row sum l keeps the un-dropped probabilities, as softmax-then-dropout does.
+template <bool WINDOWED, bool DROP = false>
 __global__ __launch_bounds__(kThreads, 4) void attn_kernel(const float* __restrict__ qkv,
                                                        const int32_t* __restrict__ cu,
                                                        const int32_t* __restrict__ seq_order, int H,
-                                                       float scale_log2e, int window, float* __restrict__ ctx) {
+                                                       float scale_log2e, int window, float* __restrict__ ctx,
+                                                       uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u) {
     __shared__ __attribute__((aligned(16))) float lds[2][kTileFloats];
     // seq_order (optional): sequence ids by decreasing length, so the heaviest workgroups are dispatched first
     const int b = seq_order ? seq_order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
@@ -152,6 +156,14 @@ __global__ __launch_bounds__(kThreads, 4) void attn_kernel(const float* __restri
             m = m_new;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+            if (DROP) {
+                const uint32_t drow = (uint32_t)(t0 + qi) * (uint32_t)H + (uint32_t)h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t key = (uint32_t)(kb + (r & 3) + 8 * (r >> 2) + 4 * lh);
+                    s[r] = mr::dropout_keep(drop_key, drow, key, drop_thresh) ? s[r] * drop_inv : 0.f;
+                }
+            }
             // ---- O^T += V^T P^T: A operand = V[kb + kappa(r, lh)][dt*32 + lr] from LDS, B operand = s[r]
             const float* vp = buf + 32 * kKS + (4 * lh) * kVS + lr;
 #pragma unroll
@@ -182,10 +194,12 @@ __global__ __launch_bounds__(kThreads, 4) void attn_kernel(const float* __restri
 // Longformer global row: one wave per (sequence, head); scores staged in LDS.
 // kbase / vbase: column 0 of head 0 of the keys / values, row stride ld (kvg layout: vbase = kbase + H * 64, ld = 2 H 64; packed qkv:
 // kbase = qkv + H * 64, vbase = qkv + 2 H * 64, ld = 3 H 64).  compact: write row b of a (B, H 64) matrix instead of row cu[b] of ctx.
+// drop_thresh != 0 (training graph): probabilities masked by mr::dropout_keep(key, sequence * H + head, key position) after normalisation.
 __global__ __launch_bounds__(MR_WAVE) void attn_global_row_kernel(const float* __restrict__ qg, const float* __restrict__ kbase,
                                                                  const float* __restrict__ vbase, int64_t ld,
                                                                  const int32_t* __restrict__ cu, int H, float scale,
-                                                                 float* __restrict__ ctx, int compact) {
+                                                                 float* __restrict__ ctx, int compact, uint32_t drop_thresh = 0u,
+                                                                 float drop_inv = 1.f, uint32_t drop_key = 0u) {
     extern __shared__ __attribute__((aligned(16))) float sc[];
     const int b = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
     const int t0 = cu[b], len = cu[b + 1] - t0;
@@ -215,8 +229,8 @@ __global__ __launch_bounds__(MR_WAVE) void attn_global_row_kernel(const float* _
     float sum = 0.f;
     for (int j = lane; j < len; j += MR_WAVE) {
         const float p = expf(sc[j] - mx);
-        sc[j] = p;
         sum += p;
+        sc[j] = (drop_thresh == 0u || mr::dropout_keep(drop_key, (uint32_t)b * (uint32_t)H + (uint32_t)h, (uint32_t)j, drop_thresh)) ? p * drop_inv : 0.f;
     }
     sum = mr::wave_sum(sum);
     __syncthreads();
@@ -239,6 +253,44 @@ extern "C" int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, const in
         hipLaunchKernelGGL((attn_kernel<true>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, seq_order, H, scale_log2e, window, ctx);
     else
         hipLaunchKernelGGL((attn_kernel<false>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, seq_order, H, scale_log2e, window, ctx);
+    return mr::check_launch();
+}
+
+// training-graph forms: dropout on the attention probabilities (drop_p in [0, 1); 0 = the kernels above, bit for bit)
+extern "C" int mr_attn_train_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh, int max_len,
+                                 float scale, int window, float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream) {
+    uint32_t thresh;
+    float inv;
+    if (!mr::dropout_params(drop_p, &thresh, &inv)) return MR_EINVAL;
+    if (thresh == 0u) return mr_attn_f32(qkv, cu_seqlens, seq_order, B, H, dh, max_len, scale, window, ctx, stream);
+    if (!qkv || !cu_seqlens || !ctx || B < 0 || H < 1 || max_len < 0) return MR_EINVAL;
+    if (dh != kDh) return MR_EUNSUPPORTED;
+    if (!mr::aligned16(qkv) || !mr::aligned16(ctx)) return MR_EALIGN;
+    if (B == 0 || max_len == 0) return MR_OK;
+    const dim3 grid((max_len + 127) / 128, H, B);
+    const float scale_log2e = scale * 1.4426950408889634f;
+    if (window >= 0)
+        hipLaunchKernelGGL((attn_kernel<true, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, seq_order, H, scale_log2e, window,
+                           ctx, thresh, inv, drop_key);
+    else
+        hipLaunchKernelGGL((attn_kernel<false, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, qkv, cu_seqlens, seq_order, H, scale_log2e, window,
+                           ctx, thresh, inv, drop_key);
+    return mr::check_launch();
+}
+
+extern "C" int mr_attn_global_row_train_f32(const float* qg, const float* kvg, const int32_t* cu_seqlens, int B, int H, int dh, int max_len,
+                                            float scale, float drop_p, uint32_t drop_key, float* ctx, int compact, mr_stream_t stream) {
+    uint32_t thresh;
+    float inv;
+    if (!mr::dropout_params(drop_p, &thresh, &inv)) return MR_EINVAL;
+    if (!qg || !kvg || !cu_seqlens || !ctx || B < 0 || H < 1 || max_len < 0) return MR_EINVAL;
+    if (dh != kDh) return MR_EUNSUPPORTED;
+    if (max_len > 16384) return MR_EUNSUPPORTED;
+    if (!mr::aligned16(qg) || !mr::aligned16(kvg)) return MR_EALIGN;
+    if (B == 0 || max_len == 0) return MR_OK;
+    const size_t shm = ((size_t)max_len * sizeof(float) + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(attn_global_row_kernel, dim3(H, B), dim3(MR_WAVE), shm, (hipStream_t)stream, qg, kvg, kvg + H * kDh, (int64_t)2 * H * kDh,
+                       cu_seqlens, H, scale, ctx, compact, thresh, thresh ? inv : 1.f, drop_key);
     return mr::check_launch();
 }
 

@@ -16,6 +16,7 @@
 //     row are XOR-swizzled by 4 * ((row >> 1) & 1), which makes the 4 rows x 64 B of a 32-lane half hit all 64 banks once.
 //     (Splitting V in registers per wave, as before, cost more VALU time than both MFMA products together.)
 #include "common.h"
+#include "dropout.h"
 #include <math.h>
 #include <stdint.h>
 #include <algorithm>
@@ -317,10 +318,12 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
 template <int J>
 struct QIdx { static constexpr int value = J; };
 
-template <bool WINDOWED, int NP, int QT>
+// DROP (training graph only): probabilities masked by mr::dropout_keep(key, query token * H + head, key position), scaled by 1 / (1 - p),
+// after the row sum has taken the un-dropped values (softmax, then dropout).
+template <bool WINDOWED, int NP, int QT, bool DROP = false>
 __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void attn_split_work_kernel(
     const float* __restrict__ qkv, const int32_t* __restrict__ cu, const int32_t* __restrict__ work, int H, float scale_log2e,
-    int window, float* __restrict__ ctx) {
+    int window, float* __restrict__ ctx, uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u) {
     constexpr int BUFB = 2 * NP * KPIECE;  // K pieces, then V pieces
     constexpr int QROWS = 128 * QT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUFB
@@ -526,6 +529,14 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { o[j][0][r] *= corr; o[j][1][r] *= corr; }
                 }
+                if (DROP) {
+                    const uint32_t drow = (uint32_t)(t0 + qi) * (uint32_t)H + (uint32_t)h;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t key = (uint32_t)(kb + (r & 3) + 8 * (r >> 2) + 4 * lh);
+                        pv[r] = mr::dropout_keep(drop_key, drow, key, drop_thresh) ? pv[r] * drop_inv : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     const float x[8] = {pv[8 * st], pv[8 * st + 1], pv[8 * st + 2], pv[8 * st + 3],
@@ -655,8 +666,26 @@ extern "C" int64_t mr_attn_work_plan(const int64_t* lens, int B, int q_rows, int
     return n_slots;
 }
 
+static int attn_split_work_launch(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale,
+                                  int window, int products, float* ctx, uint32_t thresh, float inv, uint32_t key, mr_stream_t stream);
+
 extern "C" int mr_attn_split_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh,
                                       float scale, int window, int products, float* ctx, mr_stream_t stream) {
+    return attn_split_work_launch(qkv, cu_seqlens, work, n_slots, H, dh, scale, window, products, ctx, 0u, 1.f, 0u, stream);
+}
+
+// training-graph form: dropout on the attention probabilities (drop_p in [0, 1); 0 = mr_attn_split_work_f32, bit for bit)
+extern "C" int mr_attn_split_work_train_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh,
+                                            float scale, int window, int products, float drop_p, uint32_t drop_key, float* ctx,
+                                            mr_stream_t stream) {
+    uint32_t thresh;
+    float inv;
+    if (!mr::dropout_params(drop_p, &thresh, &inv)) return MR_EINVAL;
+    return attn_split_work_launch(qkv, cu_seqlens, work, n_slots, H, dh, scale, window, products, ctx, thresh, inv, drop_key, stream);
+}
+
+static int attn_split_work_launch(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale,
+                                  int window, int products, float* ctx, uint32_t thresh, float inv, uint32_t key, mr_stream_t stream) {
     if (!qkv || !cu_seqlens || !ctx || n_slots < 0 || H < 1 || (n_slots > 0 && !work)) return MR_EINVAL;
     if (dh != kDh || (products != 3 && products != 6)) return MR_EUNSUPPORTED;
     if (!mr::aligned16(qkv) || !mr::aligned16(ctx)) return MR_EALIGN;
@@ -665,13 +694,18 @@ extern "C" int mr_attn_split_work_f32(const float* qkv, const int32_t* cu_seqlen
     const dim3 grid((unsigned)(n_slots * 8 * H));
     const float scale_log2e = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
-#define MR_ATTN_LAUNCH(W_, NP_, QT_)                                                                                          \
-    hipLaunchKernelGGL((attn_split_work_kernel<W_, NP_, QT_>), grid, dim3(kThreads), (size_t)2 * (2 * NP_ * KPIECE), st, qkv,   \
-                       cu_seqlens, work, H, scale_log2e, window, ctx)
-    if (window >= 0) {
-        if (products == 3) MR_ATTN_LAUNCH(true, 2, 1); else MR_ATTN_LAUNCH(true, 3, 1);
-    } else {
-        if (products == 3) MR_ATTN_LAUNCH(false, 2, 2); else MR_ATTN_LAUNCH(false, 3, 1);
+#define MR_ATTN_LAUNCH(W_, NP_, QT_, D_)                                                                                         \
+    hipLaunchKernelGGL((attn_split_work_kernel<W_, NP_, QT_, D_>), grid, dim3(kThreads), (size_t)2 * (2 * NP_ * KPIECE), st, qkv, \
+                       cu_seqlens, work, H, scale_log2e, window, ctx, thresh, inv, key)
+    if (thresh == 0u) {
+        if (window >= 0) {
+            if (products == 3) MR_ATTN_LAUNCH(true, 2, 1, false); else MR_ATTN_LAUNCH(true, 3, 1, false);
+        } else {
+            if (products == 3) MR_ATTN_LAUNCH(false, 2, 2, false); else MR_ATTN_LAUNCH(false, 3, 1, false);
+        }
+    } else {  // training graph with dropout: the bf16x3 arithmetic only (the six-product form is an inference mode)
+        if (products != 3) return MR_EUNSUPPORTED;
+        if (window >= 0) MR_ATTN_LAUNCH(true, 2, 1, true); else MR_ATTN_LAUNCH(false, 2, 2, true);
     }
 #undef MR_ATTN_LAUNCH
     return mr::check_launch();

@@ -19,6 +19,7 @@
 // 8 - 16 reads ahead of the 16 - 32 MFMAs that consume them (one read per MFMA behind an lgkmcnt(0) leaves the matrix pipe 60 % idle).
 // Deterministic: every output element has one owner, fixed order.
 #include "common.h"
+#include "dropout.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -144,7 +145,10 @@ template <bool STATS, int NW>
 __global__ __launch_bounds__(64 * NW, (STATS ? 4 : 3)) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
                                                                 const float* __restrict__ dctx, const int32_t* __restrict__ cu,
                                                                 const int32_t* __restrict__ order, int H, float scale, int window,
-                                                                float* __restrict__ rowstat, float* __restrict__ dqkv) {
+                                                                float* __restrict__ rowstat, float* __restrict__ dqkv,
+                                                                uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u) {
+    // drop_thresh != 0: the forward dropped attention probabilities (mask = mr::dropout_keep(key, query token * H + head, key position)):
+    // dP = (dO . v) * mask / (1 - p); delta = dO . O already holds the dropped forward
     __shared__ float ks[kTile], vs[STATS ? 1 : kTile];
     const int b = order ? order[blockIdx.z] : blockIdx.z, h = blockIdx.y;  // longest sequences first when the caller passes the order
     const int t0 = cu[b], len = cu[b + 1] - t0;
@@ -218,7 +222,9 @@ __global__ __launch_bounds__(64 * NW, (STATS ? 4 : 3)) void attn_bwd_q_kernel(co
                 const int key = jc + crow(i, lh);
                 const bool ok = key < len && allowed(q, key, window);
                 const float p = ok ? __expf(st[i] * scale - lse) : 0.f;
-                ds[i] = p * (dpt[i] - dl) * scale;
+                float dpv = dpt[i];
+                if (drop_thresh) dpv = mr::dropout_keep(drop_key, (uint32_t)(t0 + q) * (uint32_t)H + (uint32_t)h, (uint32_t)key, drop_thresh) ? dpv * drop_inv : 0.f;
+                ds[i] = p * (dpv - dl) * scale;
             }
             // dQ[query lr][d] += sum_key dS[query][key] K[key][d]: A = dS^T in its result layout, k = key crow(i, lh).  Registers
             // 4 b .. 4 b + 3 are four consecutive keys: their 8 K values are read together ahead of the 8 MFMAs
@@ -277,7 +283,8 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                                  const float* __restrict__ rowstat, const int32_t* __restrict__ cu,
                                                                  const int32_t* __restrict__ order, int H, float scale, int window,
-                                                                 float* __restrict__ dqkv) {
+                                                                 float* __restrict__ dqkv, uint32_t drop_thresh = 0u, float drop_inv = 1.f,
+                                                                 uint32_t drop_key = 0u) {
     __shared__ float qs[kTile], gs[kTile], stat[32][2];
     const int b = order ? order[blockIdx.z] : blockIdx.z, h = blockIdx.y;
     const int t0 = cu[b], len = cu[b + 1] - t0;
@@ -333,7 +340,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_kernel(const float* __
             const int r = crow(i, lh), qi = ic + r;
             const bool ok = qi < len && allowed(qi, key, window);
             p[i] = ok ? __expf(s[i] * scale - stat[r][0]) : 0.f;
-            ds[i] = p[i] * (dp[i] - stat[r][1]) * scale;
+            float dpv = dp[i];
+            if (drop_thresh) {  // dV takes the dropped probabilities, dS the masked dP
+                const bool keep = mr::dropout_keep(drop_key, (uint32_t)(t0 + qi) * (uint32_t)H + (uint32_t)h, (uint32_t)key, drop_thresh);
+                dpv = keep ? dpv * drop_inv : 0.f;
+                ds[i] = p[i] * (dpv - stat[r][1]) * scale;
+                p[i] = keep ? p[i] * drop_inv : 0.f;
+            } else {
+                ds[i] = p[i] * (dpv - stat[r][1]) * scale;
+            }
         }
         // dV[key lr][d] += sum_query P[query][key] dO[query][d];  dK[key][d] += sum_query dS[query][key] Q[query][d]
         // (registers 4 b .. 4 b + 3 are four consecutive queries: their 16 operand values are read together ahead of the 16 MFMAs)
@@ -373,8 +388,29 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_kernel(const float* __
 
 }  // namespace
 
+static int attn_bwd_launch(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H,
+                           int dh, int max_len, float scale, int window, float* rowstat, float* dqkv, uint32_t thresh, float inv, uint32_t key,
+                           mr_stream_t stream);
+
 extern "C" int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order, int B,
                                int H, int dh, int max_len, float scale, int window, float* rowstat, float* dqkv, mr_stream_t stream) {
+    return attn_bwd_launch(qkv, ctx, dctx, cu_seqlens, seq_order, B, H, dh, max_len, scale, window, rowstat, dqkv, 0u, 1.f, 0u, stream);
+}
+
+// backward of mr_attn_train_f32 / mr_attn_split_work_train_f32: the same drop_p / drop_key as the forward (the mask is recomputed)
+extern "C" int mr_attn_bwd_train_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order,
+                                     int B, int H, int dh, int max_len, float scale, int window, float drop_p, uint32_t drop_key, float* rowstat,
+                                     float* dqkv, mr_stream_t stream) {
+    uint32_t thresh;
+    float inv;
+    if (!mr::dropout_params(drop_p, &thresh, &inv)) return MR_EINVAL;
+    return attn_bwd_launch(qkv, ctx, dctx, cu_seqlens, seq_order, B, H, dh, max_len, scale, window, rowstat, dqkv, thresh, thresh ? inv : 1.f, drop_key,
+                           stream);
+}
+
+static int attn_bwd_launch(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H,
+                           int dh, int max_len, float scale, int window, float* rowstat, float* dqkv, uint32_t thresh, float inv, uint32_t key,
+                           mr_stream_t stream) {
     if (!qkv || !ctx || !dctx || !cu_seqlens || !rowstat || !dqkv || B < 0 || H < 1 || max_len < 0) return MR_EINVAL;
     if (dh != kDh) return MR_EUNSUPPORTED;
     if (!mr::aligned16(qkv) || !mr::aligned16(ctx) || !mr::aligned16(dctx)) return MR_EALIGN;
@@ -386,14 +422,14 @@ extern "C" int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* 
     hipStream_t st = (hipStream_t)stream;
     if (rows == 128) {
         const dim3 grid((max_len + 127) / 128, H, B);
-        hipLaunchKernelGGL((attn_bwd_q_kernel<true, 4>), grid, dim3(256), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv);
-        hipLaunchKernelGGL((attn_bwd_q_kernel<false, 4>), grid, dim3(256), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv);
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<4>), grid, dim3(256), 0, st, qkv, dctx, rowstat, cu_seqlens, seq_order, H, scale, window, dqkv);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<true, 4>), grid, dim3(256), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv, thresh, inv, key);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<false, 4>), grid, dim3(256), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv, thresh, inv, key);
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<4>), grid, dim3(256), 0, st, qkv, dctx, rowstat, cu_seqlens, seq_order, H, scale, window, dqkv, thresh, inv, key);
     } else {
         const dim3 grid((max_len + 63) / 64, H, B);
-        hipLaunchKernelGGL((attn_bwd_q_kernel<true, 2>), grid, dim3(128), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv);
-        hipLaunchKernelGGL((attn_bwd_q_kernel<false, 2>), grid, dim3(128), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv);
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<2>), grid, dim3(128), 0, st, qkv, dctx, rowstat, cu_seqlens, seq_order, H, scale, window, dqkv);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<true, 2>), grid, dim3(128), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv, thresh, inv, key);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<false, 2>), grid, dim3(128), 0, st, qkv, ctx, dctx, cu_seqlens, seq_order, H, scale, window, rowstat, dqkv, thresh, inv, key);
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<2>), grid, dim3(128), 0, st, qkv, dctx, rowstat, cu_seqlens, seq_order, H, scale, window, dqkv, thresh, inv, key);
     }
     return mr::check_launch();
 }

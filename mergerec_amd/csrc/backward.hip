@@ -13,6 +13,7 @@
 //   attn_bwd           softmax attention backward per (sequence, head): row statistics, dQ (query-owned), dK / dV (key-owned)
 //   scatter_add_rows   embedding-table gradients (atomic adds), CLS-row scatter
 #include "common.h"
+#include "dropout.h"
 #include <math.h>
 
 namespace {
@@ -198,7 +199,9 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_params_kernel(const fl
 __global__ __launch_bounds__(kThreads) void attn_global_row_bwd_kernel(const float* __restrict__ qg, const float* __restrict__ kvg,
                                                                       const float* __restrict__ ctx_cls, const float* __restrict__ dctx_cls,
                                                                       const int32_t* __restrict__ cu, int H, float scale,
-                                                                      float* __restrict__ dqg, float* __restrict__ dkvg) {
+                                                                      float* __restrict__ dqg, float* __restrict__ dkvg,
+                                                                      uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u) {
+    // drop_thresh != 0: the forward dropped the row's probabilities (mask = mr::dropout_keep(key, sequence * H + head, key position))
     __shared__ float red[kThreads / 64][kDh + 1];
     __shared__ float bc[2];
     const int b = blockIdx.x, h = blockIdx.y;
@@ -257,13 +260,19 @@ __global__ __launch_bounds__(kThreads) void attn_global_row_bwd_kernel(const flo
             dp = fmaf(g[d], v[d], dp);
         }
         const float p = expf(s * scale - lse);
+        float pd = p;
+        if (drop_thresh) {
+            const bool keep = mr::dropout_keep(drop_key, (uint32_t)b * (uint32_t)H + (uint32_t)h, (uint32_t)j, drop_thresh);
+            dp = keep ? dp * drop_inv : 0.f;
+            pd = keep ? p * drop_inv : 0.f;
+        }
         const float ds = p * (dp - dl) * scale;
         float* ok = dkvg + (int64_t)(t0 + j) * ld + h * kDh;
         float* ov = ok + H * kDh;
 #pragma unroll
         for (int d = 0; d < kDh; ++d) {
             ok[d] = ds * q[d];
-            ov[d] = p * g[d];
+            ov[d] = pd * g[d];
             dq[d] = fmaf(ds, k[d], dq[d]);
         }
     }
@@ -387,6 +396,21 @@ extern "C" int mr_attn_global_row_bwd_f32(const float* qg, const float* kvg, con
     if (B == 0) return MR_OK;
     hipLaunchKernelGGL(attn_global_row_bwd_kernel, dim3(B, H), dim3(kThreads), 0, (hipStream_t)stream, qg, kvg, ctx_cls, dctx_cls, cu_seqlens,
                        H, scale, dqg, dkvg);
+    return mr::check_launch();
+}
+
+// backward of mr_attn_global_row_train_f32: the same drop_p / drop_key as the forward
+extern "C" int mr_attn_global_row_bwd_train_f32(const float* qg, const float* kvg, const float* ctx_cls, const float* dctx_cls,
+                                                const int32_t* cu_seqlens, int B, int H, int dh, float scale, float drop_p, uint32_t drop_key,
+                                                float* dqg, float* dkvg, mr_stream_t stream) {
+    uint32_t thresh;
+    float inv;
+    if (!mr::dropout_params(drop_p, &thresh, &inv)) return MR_EINVAL;
+    if (!qg || !kvg || !ctx_cls || !dctx_cls || !cu_seqlens || !dqg || !dkvg || B < 0 || H < 1) return MR_EINVAL;
+    if (dh != kDh) return MR_EUNSUPPORTED;
+    if (B == 0) return MR_OK;
+    hipLaunchKernelGGL(attn_global_row_bwd_kernel, dim3(B, H), dim3(kThreads), 0, (hipStream_t)stream, qg, kvg, ctx_cls, dctx_cls, cu_seqlens,
+                       H, scale, dqg, dkvg, thresh, thresh ? inv : 1.f, drop_key);
     return mr::check_launch();
 }
 

@@ -12,6 +12,7 @@ Recformer: the band + global-key attention backward is the same pair of kernels 
 (query_global / key_global / value_global projections) has its own one-query backward kernel; four embedding tables."""
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import Optional
 
 import torch
@@ -19,7 +20,27 @@ import torch
 from . import ops
 from .engine import ArenaLayout, EncoderSpec, PackedBatch
 
-__all__ = ["EncoderTrainGraph", "RobertaTrainGraph", "SplitWeights", "encode_with_grad"]
+__all__ = ["Dropout", "EncoderTrainGraph", "RobertaTrainGraph", "SplitWeights", "encode_with_grad"]
+
+
+@dataclass(frozen=True)
+class Dropout:
+    """Dropout of ONE training forward (and its backward): HF's two rates and the (seed, step) pair that keys the counter-based mask
+    (csrc/dropout.h).  The reference's sites: the embedding LayerNorm output (transformers RobertaEmbeddings; recformer/models.py:93,135),
+    the attention probabilities, the attention-output and FFN-output dense results before their residual adds (transformers
+    RobertaSelfOutput / RobertaOutput, LongformerSelfOutput / LongformerOutput), the Longformer global row's probabilities."""
+
+    p_hidden: float = 0.1
+    p_attn: float = 0.1
+    seed: int = 0
+    step: int = 0
+
+    def key(self, layer: int, site: int) -> int:
+        return ops.dropout_site_key(self.seed, self.step, layer, site)
+
+    @property
+    def active(self) -> bool:
+        return self.p_hidden > 0.0 or self.p_attn > 0.0
 
 _LINEARS = ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "intermediate.dense", "output.dense")
 
@@ -88,7 +109,8 @@ class EncoderTrainGraph:
     "bf16x3" -- the split-precision MFMA GEMM of the inference path (three bf16 products per fp32 product, ~1e-6 relative) for the
     token-sized batches of fine-tuning, with split-K weight gradients; needs ``split_weights`` (a refreshed SplitWeights)."""
 
-    def __init__(self, spec: EncoderSpec, layout: ArenaLayout, prefix: str = "model.", mode: str = "f32", split_weights: Optional[SplitWeights] = None):
+    def __init__(self, spec: EncoderSpec, layout: ArenaLayout, prefix: str = "model.", mode: str = "f32", split_weights: Optional[SplitWeights] = None,
+                 dropout: Optional[Dropout] = None):
         if spec.hidden // spec.heads != 64:
             raise ValueError("attention kernels are built for head_dim == 64")
         if mode not in ("f32", "bf16x3"):
@@ -99,6 +121,7 @@ class EncoderTrainGraph:
         self.mode, self.sw = mode, split_weights
         self.rec = spec.kind == "recformer"
         self.window = spec.one_sided_window if self.rec else -1
+        self.drop = dropout if (dropout is not None and dropout.active) else None  # None: the deterministic graph, bit for bit
         self._saved = None
 
     # ---------------------------------------------------------------------------------------------- products
@@ -127,6 +150,10 @@ class EncoderTrainGraph:
         else:
             emb = emb + w[e + "token_type_embeddings.weight"][0]
         x = ops.layernorm(emb, w[e + "LayerNorm.weight"], w[e + "LayerNorm.bias"], sp.ln_eps)
+        dr = self.drop
+        ph, pa = (dr.p_hidden, dr.p_attn) if dr else (0.0, 0.0)
+        if ph > 0.0:
+            ops.dropout_rows(x, ph, dr.key(0, ops.DROP_SITE_EMBED), out=x)
         saved = dict(pb=pb, flat=flat, emb=emb, layers=[])
         for l in range(sp.layers):
             lp = f"{p}encoder.layer.{l}."
@@ -140,7 +167,8 @@ class EncoderTrainGraph:
                                   biases=[w[n + ".bias"] for n in names], out=qkv, products=3)
             # (bf16x3 mode: the split-precision attention of the inference path; its backward recomputes the probabilities in fp32)
             ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=self.window, seq_order=pb.seq_order,
-                                products=3 if self.mode == "bf16x3" else 0, work=pb.attn_work)
+                                products=3 if self.mode == "bf16x3" else 0, work=pb.attn_work,
+                                drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_ATTN_PROBS) if pa > 0.0 else 0)
             qg = kvg = None
             if self.rec:  # Longformer global row: CLS attends to every token through the *_global projections and overwrites ctx[cls]
                 x_cls = ops.gather_rows(x, pb.cls_rows)
@@ -148,12 +176,21 @@ class EncoderTrainGraph:
                 kvg = torch.empty(pb.T, 2 * sp.hidden, dtype=torch.float32, device=x.device)
                 for s, n in enumerate(("key_global", "value_global")):
                     self._linear(x, w, f"{lp}attention.self.{n}", out=kvg[:, s * sp.hidden:(s + 1) * sp.hidden])
-                ops.attention_global_row(qg, kvg, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx)
-            a = self._linear(ctx, w, lp + "attention.output.dense", residual=x)
+                ops.attention_global_row(qg, kvg, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx,
+                                         drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_GLOBAL_ROW) if pa > 0.0 else 0)
+            if ph > 0.0:  # a = dropout(ctx Wo^T + bo) + x ; o = dropout(i W2^T + b2) + h: the residual joins after the mask
+                a = self._linear(ctx, w, lp + "attention.output.dense")
+                ops.dropout_rows(a, ph, dr.key(l, ops.DROP_SITE_ATTN_OUT), residual=x, out=a)
+            else:
+                a = self._linear(ctx, w, lp + "attention.output.dense", residual=x)
             h = ops.layernorm(a, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps)
             u = self._linear(h, w, lp + "intermediate.dense")
             i = ops.gelu_fwd(u)
-            o = self._linear(i, w, lp + "output.dense", residual=h)
+            if ph > 0.0:
+                o = self._linear(i, w, lp + "output.dense")
+                ops.dropout_rows(o, ph, dr.key(l, ops.DROP_SITE_FFN_OUT), residual=h, out=o)
+            else:
+                o = self._linear(i, w, lp + "output.dense", residual=h)
             x_next = ops.layernorm(o, w[lp + "output.LayerNorm.weight"], w[lp + "output.LayerNorm.bias"], sp.ln_eps)
             saved["layers"].append(dict(x=x, qkv=qkv, ctx=ctx, a=a, h=h, u=u, i=i, o=o, qg=qg, kvg=kvg, l=l))
             x = x_next
@@ -205,17 +242,20 @@ class EncoderTrainGraph:
         d = sp.hidden
         dx = torch.zeros(pb.T, d, dtype=torch.float32, device=d_cls.device)
         ops.scatter_add_rows(d_cls.contiguous(), pb.cls_rows, dx)
+        dr = self.drop
+        ph, pa = (dr.p_hidden, dr.p_attn) if dr else (0.0, 0.0)
         for l in reversed(range(sp.layers)):
             lp = f"{p}encoder.layer.{l}."
             s = sv["layers"][l]
             # x_next = LN2(o)
             do = ops.layernorm_bwd(s["o"], dx, w[lp + "output.LayerNorm.weight"], sp.ln_eps, g[lp + "output.LayerNorm.weight"],
                                    g[lp + "output.LayerNorm.bias"])
-            # o = i W2^T + b2 + h
-            do_t = self._tpad(do)
+            # o = dropout(i W2^T + b2) + h: the dense sees the masked gradient, the residual path (below) the whole one
+            dod = ops.dropout_rows(do, ph, dr.key(l, ops.DROP_SITE_FFN_OUT)) if ph > 0.0 else do
+            do_t = self._tpad(dod)
             ops.rowsum(do_t, g[lp + "output.dense.bias"])  # bias gradient = row sums of dY^T
             self._wgrad(do_t, self._xt(s["i"]), g[lp + "output.dense.weight"])
-            di = self._dgrad(do, w, l, "output.dense")
+            di = self._dgrad(dod, w, l, "output.dense")
             # i = gelu(u), u = h W1^T + b1
             du = ops.gelu_bwd(s["u"], di)
             du_t = self._tpad(du)
@@ -225,16 +265,19 @@ class EncoderTrainGraph:
             # h = LN1(a)
             da = ops.layernorm_bwd(s["a"], dh, w[lp + "attention.output.LayerNorm.weight"], sp.ln_eps,
                                    g[lp + "attention.output.LayerNorm.weight"], g[lp + "attention.output.LayerNorm.bias"])
-            # a = ctx Wo^T + bo + x
-            da_t = self._tpad(da)
+            # a = dropout(ctx Wo^T + bo) + x
+            dad = ops.dropout_rows(da, ph, dr.key(l, ops.DROP_SITE_ATTN_OUT)) if ph > 0.0 else da
+            da_t = self._tpad(dad)
             ops.rowsum(da_t, g[lp + "attention.output.dense.bias"])
             self._wgrad(da_t, self._xt(s["ctx"]), g[lp + "attention.output.dense.weight"])
-            dctx = self._dgrad(da, w, l, "attention.output.dense")
-            dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window, max_len=pb.max_len, seq_order=pb.seq_order)
+            dctx = self._dgrad(dad, w, l, "attention.output.dense")
+            dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window, max_len=pb.max_len, seq_order=pb.seq_order,
+                                     drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_ATTN_PROBS) if pa > 0.0 else 0)
             xt = self._xt(s["x"])
             if self.rec:
                 dqg, dkvg = ops.attention_global_row_bwd(s["qg"], s["kvg"], ops.gather_rows(s["ctx"], pb.cls_rows), ops.gather_rows(dctx, pb.cls_rows),
-                                                         pb.cu_seqlens, pb.B, sp.heads)
+                                                         pb.cu_seqlens, pb.B, sp.heads,
+                                                         drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_GLOBAL_ROW) if pa > 0.0 else 0)
                 # key_global / value_global read every token
                 dkvg_t = self._tpad(dkvg)
                 bs2 = ops.rowsum(dkvg_t)
@@ -258,6 +301,8 @@ class EncoderTrainGraph:
             dx = self._dgrad(dqkv, w, l, "qkv", residual=da)  # + the residual path of a
         # x0 = LN(emb), emb = word[ids] + pos[pos_ids] + type[0]
         e = p + "embeddings."
+        if ph > 0.0:  # x0 = dropout(LN(emb))
+            dx = ops.dropout_rows(dx, ph, dr.key(0, ops.DROP_SITE_EMBED), out=dx)
         de = ops.layernorm_bwd(sv["emb"], dx, w[e + "LayerNorm.weight"], sp.ln_eps, g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"])
         ops.scatter_add_rows(de, pb.tok_word, g[e + "word_embeddings.weight"])
         ops.scatter_add_rows(de, pb.tok_pos, g[e + "position_embeddings.weight"])

@@ -152,7 +152,10 @@ class TaskVectorMergingModuleBase(nn.Module):
             if sw is None:
                 sw = self._split_weights = SplitWeights(self.model.spec, self.layout, self.model.runner.prefix, self.base_model_tensor.device)
             sw.refresh(merged.detach())
-        graph = RobertaTrainGraph(self.model.spec, self.layout, prefix=self.model.runner.prefix, mode=mode, split_weights=sw)
+        # dropout as the reference's functional call of the HF model in train() mode has it (merge_train.py:178-196): active iff THIS module
+        # is in training mode, rates / seed / counter from the wrapped model
+        graph = RobertaTrainGraph(self.model.spec, self.layout, prefix=self.model.runner.prefix, mode=mode, split_weights=sw,
+                                  dropout=self.model.next_dropout(training=self.training))
         pb = self.model.runner.pack(batch, self.base_model_tensor.device)
         return encode_with_grad(graph, merged, pb)
 

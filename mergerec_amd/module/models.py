@@ -65,12 +65,18 @@ class BaseEncoderModel(nn.Module):
         self.tokenizer = self._load_tokenizer(tokenizer_name_or_path, tokenizer_kwargs or {})
         ckpt_path = model_kwargs.pop("ckpt_path", None)  # Recformer (interface.py:38-41)
         init_seed = model_kwargs.pop("init_seed", None)
-        # HF config overrides the reference forwards to from_pretrained: dropout rates do not change inference; the training graph
-        # (merge_train / finetune_train) has no dropout at all -- say so instead of dropping the keys silently
-        for key in ("hidden_dropout_prob", "attention_probs_dropout_prob", "classifier_dropout"):
-            rate = model_kwargs.pop(key, None)
-            if rate:
-                print(f"note: model_kwargs {key}={rate} has no effect here: evaluation never applies dropout and the training graph is built without it")
+        # HF config overrides the reference forwards to from_pretrained.  Dropout never changes inference; the training graph
+        # (merge_train / finetune_train under train()) applies it at HF's sites with HF's default rates (RobertaConfig / LongformerConfig:
+        # hidden_dropout_prob = attention_probs_dropout_prob = 0.1), mask = the counter-based function of csrc/dropout.h keyed by
+        # (dropout_seed, training-forward counter)
+        self.hidden_dropout_prob = float(model_kwargs.pop("hidden_dropout_prob", 0.1))
+        self.attention_probs_dropout_prob = float(model_kwargs.pop("attention_probs_dropout_prob", 0.1))
+        self.dropout_seed = int(model_kwargs.pop("dropout_seed", 0))
+        self._dropout_step = 0
+        for rate in (self.hidden_dropout_prob, self.attention_probs_dropout_prob):
+            if not 0.0 <= rate < 1.0:
+                raise ValueError("dropout probabilities must be in [0, 1)")
+        model_kwargs.pop("classifier_dropout", None)  # no classifier head on this path
         if model_kwargs:
             print(f"note: model_kwargs {sorted(model_kwargs)} are not used by the HIP encoder")
         src = ckpt_path or model_name_or_path
@@ -175,8 +181,20 @@ class BaseEncoderModel(nn.Module):
                 sw = self._split_weights = SplitWeights(self.spec, layout, self.runner.prefix, self.device)
             sw.refresh(self._flat, (self._flat.data_ptr(), getattr(self, "_arena_version", 0)))
         # one graph object per forward: it owns the saved activations
-        graph = EncoderTrainGraph(self.spec, layout, prefix=self.runner.prefix, mode=self.train_mode, split_weights=sw)
+        graph = EncoderTrainGraph(self.spec, layout, prefix=self.runner.prefix, mode=self.train_mode, split_weights=sw, dropout=self.next_dropout())
         return encode_with_grad(graph, self.train_leaf(), self.runner.pack(batch, self.device))
+
+    def next_dropout(self, training: Optional[bool] = None):
+        """The dropout of the next training forward: None in eval() mode or with both rates 0 (the deterministic graph), else HF's rates
+        with this model's seed and a counter that advances once per training forward (every forward draws a fresh mask, as torch does)."""
+        from ..engine_train import Dropout
+
+        on = self.training if training is None else training
+        if not on or (self.hidden_dropout_prob == 0.0 and self.attention_probs_dropout_prob == 0.0):
+            return None
+        d = Dropout(self.hidden_dropout_prob, self.attention_probs_dropout_prob, self.dropout_seed, self._dropout_step)
+        self._dropout_step += 1
+        return d
 
     def encode_normalized(self, batch, normalize: bool, lens=None, validate=True) -> torch.Tensor:
         """forward + F.normalize fused into the pooling kernel (module/recommender/module.py:74-77)."""

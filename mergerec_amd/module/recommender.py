@@ -50,6 +50,17 @@ except Exception:  # noqa: BLE001
 __all__ = ["RecModule"]
 
 
+def score_matrix(users: torch.Tensor, items: torch.Tensor, device, rows_per_call: int = 4096) -> torch.Tensor:
+    """(U, M) fp32 host matrix ``users @ items.T`` through the exact-fp32 k-ordered GEMM of the scoring path (module.py:137), a block of
+    user rows at a time."""
+    E = items.to(device, torch.float32).contiguous()
+    out = torch.empty(users.shape[0], E.shape[0], dtype=torch.float32)
+    for r0 in range(0, users.shape[0], rows_per_call):
+        u = users[r0:r0 + rows_per_call].to(device, torch.float32).contiguous()
+        out[r0:r0 + u.shape[0]] = ops.gemm_nt(u, [E]).cpu()
+    return out
+
+
 class RecModule(_Base):
     def __init__(self, model, evaluator: Evaluator, negative_sample=None, similarity: Literal["dot", "cosine"] = "cosine",
                  temperature: float = 0.05, learning_rate: float = 5e-5, warmup_steps: int = 0, weight_decay: float = 0.0):
@@ -64,6 +75,7 @@ class RecModule(_Base):
         self.temperature = temperature
         self.learning_rate, self.warmup_steps, self.weight_decay = learning_rate, warmup_steps, weight_decay
         self.item_embeddings: Optional[nn.Parameter] = None
+        self._eval_scores, self._eval_scores_lazy = None, None
         self.eval_scores = []
         self.eval_labels = []
         self.eval_user_embeddings = []
@@ -164,6 +176,23 @@ class RecModule(_Base):
                           num_warmup_steps=warmup, num_training_steps=total,
                           max_grad_norm=getattr(self.trainer, "gradient_clip_val", None))
 
+    # -- the (users, items) score matrix of the last evaluation epoch (module.py:344-352 keeps it on the host, always) -----------------
+    @property
+    def eval_scores(self):
+        """The reference's ``eval_scores``: ALWAYS available after an evaluation epoch.  With ``keep_scores`` the matrix was written by
+        the scoring kernel while the epoch ran; otherwise (the fused / staged scoring kept only top-k, log-sum-exp and label ranks) it is
+        produced on first access from the epoch's user embeddings and the item matrix by the same exact-fp32 k-ordered product
+        (``ops.gemm_nt``) -- the very bits the scoring kernel ranked -- and cached."""
+        if self._eval_scores is None and self._eval_scores_lazy is not None:
+            users, items = self._eval_scores_lazy
+            self._eval_scores = score_matrix(users, items, self.device)
+            self._eval_scores_lazy = None
+        return self._eval_scores
+
+    @eval_scores.setter
+    def eval_scores(self, value):
+        self._eval_scores, self._eval_scores_lazy = value, None
+
     # -- evaluation loops (module.py:283-361; validation = the test loop under the "val/" prefix) ----
     def _eval_start(self):
         self.eval_scores, self.eval_labels, self.eval_user_embeddings = [], [], []
@@ -217,6 +246,8 @@ class RecModule(_Base):
                 scores = torch.cat([p_.cpu() for p_ in parts], dim=1) if shard.rank == 0 else None
         self.eval_labels, self.eval_user_embeddings, self.eval_topk_indices = labels.cpu(), users.cpu(), topk.cpu()
         self.eval_scores = scores
+        if scores is None and self.item_embeddings is not None and (shard is None or shard.world == 1 or shard.rank == 0):
+            self._eval_scores_lazy = (self.eval_user_embeddings, self.item_embeddings.data)  # materialised on first access
         # cross_entropy(scores / T, labels) = mean(logsumexp(row / T) - row[label] / T)   (module.py:318, 356)
         loss = float((lse.double() - lab.double()).mean()) if lse.numel() else float("nan")
         metrics = self.evaluator.from_ranks(ranks, metric_prefix=prefix)

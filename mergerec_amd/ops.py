@@ -400,15 +400,24 @@ def attn_q_rows(window: int, products: int) -> int:
 
 
 def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, window: int = -1, out=None,
-              seq_order: Optional[torch.Tensor] = None, products: int = 0, work=None) -> torch.Tensor:
+              seq_order: Optional[torch.Tensor] = None, products: int = 0, work=None, drop_p: float = 0.0, drop_key: int = 0) -> torch.Tensor:
     """products = 0: exact fp32 MFMA kernel; 3 / 6: split-precision bf16 MFMA kernel.  work: {q_rows: (device int32 work list, n_slots)}
     from ``attn_work_plan`` (the engine builds it while packing) -> the work-list launch (mr_attn_split_work_f32); without it the
-    (max_len / 128, H, B) grid of mr_attn_split_f32."""
+    (max_len / 128, H, B) grid of mr_attn_split_f32.  drop_p > 0 (training graph only): dropout on the attention probabilities with the
+    mask of csrc/dropout.h under ``drop_key``."""
     T = qkv.shape[0]
     dh = qkv.shape[1] // (3 * H)
     out = torch.empty(T, H * dh, dtype=torch.float32, device=qkv.device) if out is None else out
     ev = PROF.begin(qkv.device)
-    if products:
+    if drop_p > 0.0:
+        wl = work.get(attn_q_rows(window, products)) if (work and products == 3) else None
+        if wl is not None:
+            check(_lib.load().mr_attn_split_work_train_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, products, drop_p,
+                                                           drop_key, ptr(out), _stream(qkv)), "mr_attn_split_work_train_f32")
+        else:  # exact-fp32 kernel (also the bf16x3 graph's route when a batch carries no work list)
+            check(_lib.load().mr_attn_train_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, drop_p, drop_key,
+                                                ptr(out), _stream(qkv)), "mr_attn_train_f32")
+    elif products:
         wl = work.get(attn_q_rows(window, products)) if work else None
         if wl is not None and os.environ.get("MR_ATTN_WORKLIST", "1") != "0":
             check(_lib.load().mr_attn_split_work_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, products,
@@ -424,9 +433,14 @@ def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_l
 
 
 def attention_global_row(qg: torch.Tensor, kvg: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_len: int, ctx: torch.Tensor,
-                         compact: bool = False):
-    """Longformer global row into ctx[cu[b]] (ctx (T, d)) or, compact, into row b of a (B, d) matrix."""
+                         compact: bool = False, drop_p: float = 0.0, drop_key: int = 0):
+    """Longformer global row into ctx[cu[b]] (ctx (T, d)) or, compact, into row b of a (B, d) matrix.  drop_p > 0: training-graph dropout
+    on the row's probabilities."""
     dh = qg.shape[1] // H
+    if drop_p > 0.0:
+        check(_lib.load().mr_attn_global_row_train_f32(ptr(qg), ptr(kvg), ptr(cu_seqlens), B, H, dh, max_len, dh ** -0.5, drop_p, drop_key, ptr(ctx),
+                                                       int(compact), _stream(qg)), "mr_attn_global_row_train_f32")
+        return ctx
     check(_lib.load().mr_attn_global_row_f32(ptr(qg), ptr(kvg), ptr(cu_seqlens), B, H, dh, max_len, dh ** -0.5, ptr(ctx), int(compact), _stream(qg)),
           "mr_attn_global_row_f32")
     return ctx
@@ -632,7 +646,7 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
 
 
 def attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, scale: Optional[float] = None,
-                  window: int = -1, max_len: Optional[int] = None, seq_order: Optional[torch.Tensor] = None):
+                  window: int = -1, max_len: Optional[int] = None, seq_order: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_key: int = 0):
     _dev(qkv, "qkv", torch.float32), _dev(ctx, "ctx", torch.float32), _dev(dctx, "dctx", torch.float32)
     T = qkv.shape[0]
     if not (qkv.is_contiguous() and ctx.is_contiguous() and dctx.is_contiguous()) or qkv.shape[1] != 3 * H * 64:
@@ -642,22 +656,62 @@ def attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, cu_s
     if max_len is None:  # (one small D2H sync; the training graph passes the packed batch's own maximum)
         max_len = int((cu_seqlens[1:] - cu_seqlens[:-1]).max()) if B else 0
     ev = PROF.begin(qkv.device)
-    check(_lib.load().mr_attn_bwd_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), ptr(seq_order), B, H, 64, max_len, 0.125 if scale is None else scale, window,
-                                      ptr(rowstat), ptr(dqkv), _stream(qkv)), "mr_attn_bwd_f32")
+    if drop_p > 0.0:
+        check(_lib.load().mr_attn_bwd_train_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), ptr(seq_order), B, H, 64, max_len,
+                                                0.125 if scale is None else scale, window, drop_p, drop_key, ptr(rowstat), ptr(dqkv), _stream(qkv)),
+              "mr_attn_bwd_train_f32")
+    else:
+        check(_lib.load().mr_attn_bwd_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), ptr(seq_order), B, H, 64, max_len, 0.125 if scale is None else scale, window,
+                                          ptr(rowstat), ptr(dqkv), _stream(qkv)), "mr_attn_bwd_f32")
     PROF.end(ev, qkv.device, "attention_bwd", flops=0.0, nbytes=4.0 * T * H * 64 * 8)
     return dqkv
 
 
-def attention_global_row_bwd(qg: torch.Tensor, kvg: torch.Tensor, ctx_cls: torch.Tensor, dctx_cls: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int):
+def attention_global_row_bwd(qg: torch.Tensor, kvg: torch.Tensor, ctx_cls: torch.Tensor, dctx_cls: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int,
+                             drop_p: float = 0.0, drop_key: int = 0):
     """-> (dqg (B, H 64), dkvg (T, 2 H 64)) of the Longformer global row."""
     for t, n in ((qg, "qg"), (kvg, "kvg"), (ctx_cls, "ctx_cls"), (dctx_cls, "dctx_cls")):
         _dev(t, n, torch.float32)
         if not t.is_contiguous():
             raise ValueError(f"{n} must be contiguous")
     dqg, dkvg = torch.empty_like(qg), torch.empty_like(kvg)
+    if drop_p > 0.0:
+        check(_lib.load().mr_attn_global_row_bwd_train_f32(ptr(qg), ptr(kvg), ptr(ctx_cls), ptr(dctx_cls), ptr(cu_seqlens), B, H, 64, 0.125, drop_p,
+                                                           drop_key, ptr(dqg), ptr(dkvg), _stream(qg)), "mr_attn_global_row_bwd_train_f32")
+        return dqg, dkvg
     check(_lib.load().mr_attn_global_row_bwd_f32(ptr(qg), ptr(kvg), ptr(ctx_cls), ptr(dctx_cls), ptr(cu_seqlens), B, H, 64, 0.125, ptr(dqg), ptr(dkvg),
                                                  _stream(qg)), "mr_attn_global_row_bwd_f32")
     return dqg, dkvg
+
+
+# ------------------------------------------------------------------------------------------ training-graph dropout (csrc/dropout.h)
+DROP_SITE_EMBED, DROP_SITE_ATTN_PROBS, DROP_SITE_ATTN_OUT, DROP_SITE_FFN_OUT, DROP_SITE_GLOBAL_ROW = range(5)
+
+
+def _lowbias32(x: int) -> int:
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def dropout_site_key(seed: int, step: int, layer: int, site: int) -> int:
+    """== mr_dropout_site_key (host arithmetic on both sides; tests/test_cabi_symbols.py holds them together)."""
+    return _lowbias32(_lowbias32(_lowbias32(seed) + step) + layer * 8 + site)
+
+
+def dropout_rows(x: torch.Tensor, p: float, key: int, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = dropout(x) (+ residual) with the mask of csrc/dropout.h (row = x's row index, col = column); the same call on dY is the
+    site's backward.  p == 0: x (+ residual) unchanged."""
+    _dev(x, "x", torch.float32)
+    T, d = x.shape
+    out = torch.empty(T, d, dtype=torch.float32, device=x.device) if out is None else out
+    check(_lib.load().mr_dropout_rows_f32(ptr(x), x.stride(0), T, d, float(p), key, ptr(residual), residual.stride(0) if residual is not None else 0,
+                                          ptr(out), out.stride(0), _stream(x)), "mr_dropout_rows_f32")
+    return out
 
 
 def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, table: torch.Tensor):

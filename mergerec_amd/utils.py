@@ -112,8 +112,8 @@ def test_model(module: RecModule, model_type, data_paths: Sequence, model_tokeni
                metrics_path: Optional[Path] = None, predictions_path: Optional[Path] = None,
                item_embeddings_path: Optional[Path] = None, user_embeddings_path: Optional[Path] = None) -> tuple:
     """The reference's ``test_model`` (utils.py:32-134), argument for argument: dataset paths in, (metric_dict, metrics, scores,
-    labels) out; ``metric_dict`` keys ``test/dataset_{i}/{k}``.  ``scores`` entries are None unless ``predictions_path`` is given (the
-    fused scoring kernel does not materialise the (users, items) matrix otherwise).  Runs sharded over the ranks when launched under
+    labels) out; ``metric_dict`` keys ``test/dataset_{i}/{k}``.  ``scores[i]`` is domain i's (users, items) matrix as upstream: written by the
+    scoring kernel when ``predictions_path`` is given, otherwise produced on first access (``LazyScores``: same bits, no cost if unread).  Runs sharded over the ranks when launched under
     ``torch.distributed.run`` (see ``Trainer.test``)."""
     vocab = getattr(getattr(module.model, "spec", None), "vocab", 50265)
     names, item_dls, seq_dls = [], [], []
@@ -142,7 +142,7 @@ def test_model_on_dataloaders(module: RecModule, item_dataloaders: Sequence[Iter
         cb.item_dataloader = item_dl
         module.item_embeddings = None  # utils.py:110: catalog re-encoded per domain
         metric = trainer.test(module, seq_dl, verbose=False)
-        scores.append(None if module.eval_scores is None else module.eval_scores.detach().cpu())
+        scores.append(module.eval_scores.detach().cpu() if module.keep_scores and module.eval_scores is not None else None)
         labels.append(module.eval_labels.detach().cpu().clone())
         item_embs.append(module.item_embeddings.detach().cpu().clone())
         user_embs.append(module.eval_user_embeddings.detach().cpu().clone())
@@ -150,7 +150,32 @@ def test_model_on_dataloaders(module: RecModule, item_dataloaders: Sequence[Iter
         metric_dict.update({f"test/dataset_{i}/{k}": v for k, v in metric[0].items()})
     save_predictions(data_names, item_embs, item_embeddings_path, labels, metrics, metrics_path, predictions_path, scores,
                      user_embs, user_embeddings_path)
+    if predictions_path is None:  # the reference returns every domain's (users, items) matrix (utils.py:113): produced on first access
+        scores = LazyScores(user_embs, item_embs, module.device)
     return metric_dict, metrics, scores, labels
+
+
+class LazyScores(Sequence):
+    """``test_model``'s third return value when no predictions file was asked for: a list-like over the domains whose element i is the
+    (users_i, items_i) fp32 score matrix, computed on first access by the scoring path's exact-fp32 product from the embeddings the
+    evaluation kept (the same bits the kernel ranked), then cached.  The reference materialises these matrices on the host for every
+    call; here a caller that never looks pays nothing."""
+
+    def __init__(self, user_embs, item_embs, device):
+        self._u, self._e, self._dev = list(user_embs), list(item_embs), device
+        self._cache = [None] * len(self._u)
+
+    def __len__(self):
+        return len(self._u)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if self._cache[i] is None:
+            from .module.recommender import score_matrix
+
+            self._cache[i] = score_matrix(self._u[i], self._e[i], self._dev)
+        return self._cache[i]
 
 
 class DistillTrainer:

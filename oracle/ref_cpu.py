@@ -217,6 +217,94 @@ def pcb_vectors(base: torch.Tensor, models: Sequence[torch.Tensor], density: flo
 # --------------------------------------------------------------------------------------------
 
 
+# --------------------------------------------------------------------------------------------
+# Training-graph dropout.  The reference trains under lightning.Trainer.fit, i.e. train() mode with torch's dropout at HF's sites
+# (transformers RobertaEmbeddings / RobertaSelfAttention / RobertaSelfOutput / RobertaOutput and their Longformer twins;
+# recformer/models.py:93,135) at HF's default rates 0.1 / 0.1 (merge_train.py:178-196).  torch's Philox stream cannot be restated outside
+# torch, so the BUILD defines its mask as a pure function of (seed, step, layer, site, row, column) -- mergerec_amd/csrc/dropout.h --
+# and this is its restatement: with the same plan the oracle's autograd step and the HIP step must agree to rounding.
+# --------------------------------------------------------------------------------------------
+DROP_SITE_EMBED, DROP_SITE_ATTN_PROBS, DROP_SITE_ATTN_OUT, DROP_SITE_FFN_OUT, DROP_SITE_GLOBAL_ROW = range(5)
+
+
+def _lowbias32(x):
+    """uint32 mixer (numpy uint64 arithmetic masked to 32 bits)."""
+    import numpy as np
+
+    m = np.uint64(0xFFFFFFFF)
+    x = np.asarray(x, dtype=np.uint64) & m
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & m
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & m
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def dropout_site_key(seed: int, step: int, layer: int, site: int) -> int:
+    return int(_lowbias32(int(_lowbias32(int(_lowbias32(seed)) + step)) + layer * 8 + site))
+
+
+def dropout_keep(key: int, rows: torch.Tensor, cols: torch.Tensor, p: float) -> torch.Tensor:
+    """keep[...] = lowbias32(row * 0x9E3779B1 + col * 0x85EBCA77 + key) >= floor(p * 2^32); rows / cols broadcast against each other."""
+    import numpy as np
+
+    m = np.uint64(0xFFFFFFFF)
+    r = rows.to(torch.int64).numpy().astype(np.uint64)
+    c = cols.to(torch.int64).numpy().astype(np.uint64)
+    x = ((r * np.uint64(0x9E3779B1)) & m) + ((c * np.uint64(0x85EBCA77)) & m) + np.uint64(key)
+    thresh = min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF)
+    return torch.from_numpy(_lowbias32(x & m) >= np.uint64(thresh))
+
+
+def dropout_scale(p: float) -> torch.Tensor:
+    """1 / (1 - p) in fp32, as the kernels compute it."""
+    return torch.tensor(1.0, dtype=torch.float32) / (torch.tensor(1.0, dtype=torch.float32) - torch.tensor(p, dtype=torch.float32))
+
+
+@dataclass
+class DropoutPlan:
+    """One training forward's dropout (== mergerec_amd.engine_train.Dropout).  ``tok`` (B, L) int64 = packed token index of every
+    padded position (cumulative lengths + position), set by the encoders from the attention mask."""
+
+    p_hidden: float = 0.1
+    p_attn: float = 0.1
+    seed: int = 0
+    step: int = 0
+    tok: Optional[torch.Tensor] = None
+
+    def bind(self, attention_mask: torch.Tensor) -> "DropoutPlan":
+        lens = attention_mask.ne(0).sum(1)
+        start = torch.cumsum(lens, 0) - lens
+        self.tok = start[:, None] + torch.arange(attention_mask.shape[1])[None, :]
+        return self
+
+    def hidden(self, x: torch.Tensor, layer: int, site: int) -> torch.Tensor:
+        """x (B, L, d): row = packed token, col = feature."""
+        if self.p_hidden <= 0.0:
+            return x
+        keep = dropout_keep(dropout_site_key(self.seed, self.step, layer, site), self.tok[:, :, None], torch.arange(x.shape[-1])[None, None, :], self.p_hidden)
+        return x * (keep.to(x.dtype) * dropout_scale(self.p_hidden))
+
+    def probs(self, pr: torch.Tensor, layer: int) -> torch.Tensor:
+        """pr (B, H, L, L): row = packed query token * H + head, col = key position."""
+        if self.p_attn <= 0.0:
+            return pr
+        B, H, L, _ = pr.shape
+        rows = self.tok[:, None, :, None] * H + torch.arange(H)[None, :, None, None]
+        keep = dropout_keep(dropout_site_key(self.seed, self.step, layer, DROP_SITE_ATTN_PROBS), rows, torch.arange(L)[None, None, None, :], self.p_attn)
+        return pr * (keep.to(pr.dtype) * dropout_scale(self.p_attn))
+
+    def global_probs(self, pr: torch.Tensor, layer: int) -> torch.Tensor:
+        """pr (B, H, L, L) of the Longformer global projections (only the global query rows are used): row = sequence * H + head."""
+        if self.p_attn <= 0.0:
+            return pr
+        B, H, L, _ = pr.shape
+        rows = (torch.arange(B)[:, None, None, None] * H + torch.arange(H)[None, :, None, None]).expand(B, H, L, 1)
+        keep = dropout_keep(dropout_site_key(self.seed, self.step, layer, DROP_SITE_GLOBAL_ROW), rows, torch.arange(L)[None, None, None, :], self.p_attn)
+        return pr * (keep.to(pr.dtype) * dropout_scale(self.p_attn))
+
+
 @dataclass
 class EncoderConfig:
     hidden: int = 768
@@ -253,17 +341,21 @@ def roberta_embeddings(p: StateDict, input_ids: torch.Tensor, cfg: EncoderConfig
     return _ln(e, p[prefix + "embeddings.LayerNorm.weight"], p[prefix + "embeddings.LayerNorm.bias"], cfg.ln_eps)
 
 
-def _ffn_block(p: StateDict, lp: str, attn_ctx: torch.Tensor, x: torch.Tensor, cfg: EncoderConfig) -> torch.Tensor:
+def _ffn_block(p: StateDict, lp: str, attn_ctx: torch.Tensor, x: torch.Tensor, cfg: EncoderConfig, drop=None, layer: int = 0) -> torch.Tensor:
     """BertSelfOutput + BertIntermediate + BertOutput (shared by RoBERTa and Longformer layers):
-    ``h = LN(x + ctx W_o^T + b_o)``; ``y = LN(h + gelu_erf(h W_i^T + b_i) W_o2^T + b_o2)``."""
+    ``h = LN(x + dropout(ctx W_o^T + b_o))``; ``y = LN(h + dropout(gelu_erf(h W_i^T + b_i) W_o2^T + b_o2))`` (dropout: train() only)."""
     h = F.linear(attn_ctx, p[lp + "attention.output.dense.weight"], p[lp + "attention.output.dense.bias"])
+    if drop is not None:
+        h = drop.hidden(h, layer, DROP_SITE_ATTN_OUT)
     h = _ln(h + x, p[lp + "attention.output.LayerNorm.weight"], p[lp + "attention.output.LayerNorm.bias"], cfg.ln_eps)
     i = F.gelu(F.linear(h, p[lp + "intermediate.dense.weight"], p[lp + "intermediate.dense.bias"]))
     o = F.linear(i, p[lp + "output.dense.weight"], p[lp + "output.dense.bias"])
+    if drop is not None:
+        o = drop.hidden(o, layer, DROP_SITE_FFN_OUT)
     return _ln(o + h, p[lp + "output.LayerNorm.weight"], p[lp + "output.LayerNorm.bias"], cfg.ln_eps)
 
 
-def roberta_layer(p: StateDict, lp: str, x: torch.Tensor, attention_mask: torch.Tensor, cfg: EncoderConfig) -> torch.Tensor:
+def roberta_layer(p: StateDict, lp: str, x: torch.Tensor, attention_mask: torch.Tensor, cfg: EncoderConfig, drop=None, layer: int = 0) -> torch.Tensor:
     """transformers RobertaLayer: softmax(QK^T/sqrt(dh) + (1-mask)*finfo.min) V, 12 heads."""
     B, L, d = x.shape
     H, dh = cfg.heads, d // cfg.heads
@@ -272,19 +364,26 @@ def roberta_layer(p: StateDict, lp: str, x: torch.Tensor, attention_mask: torch.
     v = F.linear(x, p[lp + "attention.self.value.weight"], p[lp + "attention.self.value.bias"]).view(B, L, H, dh).transpose(1, 2)
     s = (q @ k.transpose(-1, -2)) * (dh**-0.5)
     s = s + ((1.0 - attention_mask.to(s.dtype)) * torch.finfo(s.dtype).min)[:, None, None, :]
-    ctx = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, d)
-    return _ffn_block(p, lp, ctx, x, cfg)
+    pr = torch.softmax(s, dim=-1)
+    if drop is not None:
+        pr = drop.probs(pr, layer)
+    ctx = (pr @ v).transpose(1, 2).reshape(B, L, d)
+    return _ffn_block(p, lp, ctx, x, cfg, drop, layer)
 
 
 def roberta_encode(
     p: StateDict, input_ids: torch.Tensor, attention_mask: torch.Tensor, cfg: EncoderConfig, prefix: str = "",
-    return_hidden: bool = False,
+    return_hidden: bool = False, dropout: Optional[DropoutPlan] = None,
 ):
-    """encoder/_base.py:32-49 -- ``self.model(**batch)`` then CLS pooling ``last_hidden_state[:, 0]``."""
+    """encoder/_base.py:32-49 -- ``self.model(**batch)`` then CLS pooling ``last_hidden_state[:, 0]``.  ``dropout``: the train()-mode
+    forward (mask = the build's counter-based function, see DropoutPlan)."""
     x = roberta_embeddings(p, input_ids, cfg, prefix)
+    drop = dropout.bind(attention_mask) if dropout is not None else None
+    if drop is not None:
+        x = drop.hidden(x, 0, DROP_SITE_EMBED)
     hidden = [x]
     for l in range(cfg.layers):
-        x = roberta_layer(p, f"{prefix}encoder.layer.{l}.", x, attention_mask, cfg)
+        x = roberta_layer(p, f"{prefix}encoder.layer.{l}.", x, attention_mask, cfg, drop, l)
         hidden.append(x)
     cls = x[:, 0, :]
     return (cls, hidden) if return_hidden else cls
@@ -307,7 +406,7 @@ def recformer_embeddings(
     return _ln(e, p[prefix + "embeddings.LayerNorm.weight"], p[prefix + "embeddings.LayerNorm.bias"], cfg.ln_eps)
 
 
-def longformer_layer(p: StateDict, lp: str, x: torch.Tensor, mask012: torch.Tensor, cfg: EncoderConfig) -> torch.Tensor:
+def longformer_layer(p: StateDict, lp: str, x: torch.Tensor, mask012: torch.Tensor, cfg: EncoderConfig, drop=None, layer: int = 0) -> torch.Tensor:
     """transformers LongformerSelfAttention (reached via recformer/models.py:189,340-348), restated
     densely.  mask012: 0 = no attention, 1 = local, 2 = global (recformer/models.py:261-271).
 
@@ -340,6 +439,8 @@ def longformer_layer(p: StateDict, lp: str, x: torch.Tensor, mask012: torch.Tens
     pr = torch.softmax(s.float(), dim=-1)
     pr = torch.nan_to_num(pr, nan=0.0)
     pr = pr.masked_fill(is_masked[:, None, :, None], 0.0)
+    if drop is not None:
+        pr = drop.probs(pr, layer)
     ctx = pr @ v  # (B,H,L,dh)
     # global rows
     if is_global.any():
@@ -348,24 +449,30 @@ def longformer_layer(p: StateDict, lp: str, x: torch.Tensor, mask012: torch.Tens
         vg = proj("value_global", x)
         sg = qg @ kg.transpose(-1, -2)
         sg = sg.masked_fill(is_masked[:, None, None, :], torch.finfo(sg.dtype).min)
-        cg = torch.softmax(sg.float(), dim=-1) @ vg
+        pg = torch.softmax(sg.float(), dim=-1)
+        if drop is not None:
+            pg = drop.global_probs(pg, layer)
+        cg = pg @ vg
         ctx = torch.where(is_global[:, None, :, None], cg, ctx)
     ctx = ctx.transpose(1, 2).reshape(B, L, d)
-    return _ffn_block(p, lp, ctx, x, cfg)
+    return _ffn_block(p, lp, ctx, x, cfg, drop, layer)
 
 
 def recformer_encode(
     p: StateDict, input_ids, attention_mask, global_attention_mask, token_type_ids, item_position_ids,
-    cfg: EncoderConfig, prefix: str = "", return_hidden: bool = False,
+    cfg: EncoderConfig, prefix: str = "", return_hidden: bool = False, dropout: Optional[DropoutPlan] = None,
 ):
     """recformer/interface.py:67-84 -> recformer/models.py:273-361.  Window padding
     (models.py:209-259) only appends masked positions, which never influence a non-masked row in
     the dense restatement, so it is not materialised; CLS pooling per encoder/_base.py:44-45."""
     mask012 = attention_mask * (global_attention_mask + 1)  # models.py:261-271
     x = recformer_embeddings(p, input_ids, token_type_ids, item_position_ids, cfg, prefix)
+    drop = dropout.bind(attention_mask) if dropout is not None else None
+    if drop is not None:
+        x = drop.hidden(x, 0, DROP_SITE_EMBED)
     hidden = [x]
     for l in range(cfg.layers):
-        x = longformer_layer(p, f"{prefix}encoder.layer.{l}.", x, mask012, cfg)
+        x = longformer_layer(p, f"{prefix}encoder.layer.{l}.", x, mask012, cfg, drop, l)
         hidden.append(x)
     cls = x[:, 0, :]
     return (cls, hidden) if return_hidden else cls

@@ -82,7 +82,9 @@ def test_scoring_contract(lib):
             assert call(u=None) == MR_EINVAL and call(e=None) == MR_EINVAL and call(m=0) == MR_EINVAL and call(dd=0) == MR_EINVAL
             assert call(n=-1) == MR_EINVAL and call(w=None) == MR_EINVAL
             assert call(wb=need // 2) == MR_EWS, f"mode {mode}: half the workspace"
-            assert call(kk=65) in (MR_EUNSUPPORTED, MR_EWS) and call(kk=M + 1, m=M) in (MR_EUNSUPPORTED, MR_EWS), "k beyond 64 / beyond the catalog"
+            kmax = lib.mr_topk_max_k()
+            assert kmax == 1024
+            assert call(kk=kmax + 1) in (MR_EUNSUPPORTED, MR_EWS) and call(kk=M + 1, m=M) in (MR_EUNSUPPORTED, MR_EWS), "k beyond the limit / beyond the catalog"
             assert untouched(val) and bool((idx == 77).all())
             assert call() == MR_OK
             torch.cuda.synchronize()
@@ -97,7 +99,7 @@ def test_scoring_contract(lib):
     sel = lambda s=sc, ld=100, r=4, c=100, kk=10: lib.mr_topk_rows_f32(p(s), ld, r, c, kk, p(tv_), p(ti_), None, 1.0, None, None, None, None)
     assert sel(r=0) == MR_OK and untouched(tv_)
     assert sel(s=None) == MR_EINVAL and sel(r=-1) == MR_EINVAL and sel(c=0) == MR_EINVAL and sel(kk=0) == MR_EINVAL and sel(ld=99) == MR_EINVAL
-    assert sel(kk=65) == MR_EUNSUPPORTED and sel(c=5, ld=5, kk=10) == MR_EUNSUPPORTED and untouched(tv_)
+    assert sel(kk=1025) == MR_EUNSUPPORTED and sel(kk=101) == MR_EUNSUPPORTED and sel(c=5, ld=5, kk=10) == MR_EUNSUPPORTED and untouched(tv_)
 
 
 def test_encoder_kernels_contract(lib):

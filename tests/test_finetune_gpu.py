@@ -159,7 +159,7 @@ def test_whole_training_step_matches_reference_on_hf_roberta(mode):
     st = load_golden("g9_finetune.pt")["roberta_step"]
     c = st["cfg"]
     over = dict(hidden=c["hidden"], heads=c["heads"], layers=c["layers"], intermediate=c["intermediate"], vocab=c["vocab"], max_pos=c["max_pos"])
-    model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "spec_overrides": over, "device": DEV, "gemm_mode": "f32"})
+    model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "spec_overrides": over, "device": DEV, "gemm_mode": "f32", "hidden_dropout_prob": 0.0, "attention_probs_dropout_prob": 0.0})
     model.load_state_dict(st["state_dict"])
     model.train_mode = mode
     mod = RecModule(model=model, evaluator=Evaluator(["NDCG"], [1]), negative_sample=NegativeSampleConfig(in_batch=True), similarity="cosine",
@@ -253,7 +253,7 @@ def _tiny_blair(seed=3):
     from mergerec_amd.module import ModelType
 
     over = dict(hidden=128, heads=2, layers=2, intermediate=256, vocab=300, max_pos=130)
-    return ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": seed, "spec_overrides": over, "device": DEV, "gemm_mode": "f32"}), over
+    return ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": seed, "spec_overrides": over, "device": DEV, "gemm_mode": "f32", "hidden_dropout_prob": 0.0, "attention_probs_dropout_prob": 0.0}), over
 
 
 def _toy_tokens(B, L, vocab, g):

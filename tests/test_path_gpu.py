@@ -109,12 +109,17 @@ def test_recformer_encoder_matches_reference_golden(mode):
 
 
 # ------------------------------------------------------------------ merger behind load_merging_module
-def _tiny_model(cfgd, kind="BLAIR_BASE"):
+NO_DROPOUT = {"hidden_dropout_prob": 0.0, "attention_probs_dropout_prob": 0.0}  # the HF configs the golden generators used (oracle/gen_golden*.py)
+
+
+def _tiny_model(cfgd, kind="BLAIR_BASE", **extra):
+    """dropout off by default: every fixture was recorded from the reference with hidden / attention dropout 0 (pass the two keys to turn
+    it on for the training-graph dropout tests)"""
     from mergerec_amd.module import ModelType
 
     over = dict(hidden=cfgd["hidden"], heads=cfgd["heads"], layers=cfgd["layers"], intermediate=cfgd["intermediate"], vocab=cfgd["vocab"],
                 max_pos=cfgd["max_pos"])
-    return ModelType[kind].value(model_kwargs={"init_seed": 1, "spec_overrides": over, "device": DEV})
+    return ModelType[kind].value(model_kwargs={"init_seed": 1, "spec_overrides": over, "device": DEV, **NO_DROPOUT, **extra})
 
 
 def test_load_merging_module_matches_reference_golden():
@@ -257,6 +262,11 @@ def test_end_to_end_merge_encode_score_evaluate(kind):
     dom = make_domain("Toy", n_items=333, n_users=150, batch_size=32, vocab=over["vocab"], seed=9,
                       kind="recformer" if rec else "roberta", max_seq_len=160, item_len_scale=0.3)
     metric_dict, metrics, scores, labels = test_model(module, [dom.item_batches], [dom.sequence_batches], ["Toy"])
+    # the (users, items) matrix is always available, as upstream (utils.py:113, module.py:344-352): produced on first access here
+    assert len(scores) == 1 and scores[0].shape == (dom.labels.numel(), module.item_embeddings.shape[0])
+    assert torch.equal(scores[0], module.eval_scores) and not module.keep_scores
+    assert torch.equal(scores[0], CO.gemm_nt(module.eval_user_embeddings, module.item_embeddings.detach().cpu()))   # the bits the kernel ranked
+    assert torch.equal(torch.gather(scores[0], 1, module.eval_topk_indices[:, :1]).squeeze(1), scores[0].max(1).values)
 
     # ---- oracle: same arithmetic on CPU
     base, shape_dict = O.flatten_model(pre)
