@@ -725,7 +725,8 @@ def test_encoder_backward_with_dropout_matches_oracle_autograd(kind):
         o2 = encode_with_grad(EncoderTrainGraph(spec, layout, dropout=Dropout(**dict(plan, step=4))), f2, pb)
         assert torch.equal(o0, o1) and not torch.allclose(o2, out, atol=1e-3)
         o0.sum().backward(); o1.sum().backward()
-        assert torch.equal(f0.grad, f1.grad)
+        # (the embedding-table gradients are scatter-added with float atomics: equal up to their summation order)
+        assert torch.allclose(f0.grad, f1.grad, rtol=1e-5, atol=1e-6 * float(f0.grad.abs().max()))
 
 
 def test_models_apply_dropout_in_train_mode_only_with_hf_default_rates():
