@@ -82,7 +82,7 @@ class DeviceSampler(threading.Thread):
         super().__init__(daemon=True)
         self.period = period_s
         self.stop_flag = threading.Event()
-        self.sclk, self.power = [], []
+        self.sclk, self.power, self.t = [], [], []
         self.dir, self.cap_w, self.note = None, None, None
         cands = []
         if pci_bus_id:
@@ -119,6 +119,7 @@ class DeviceSampler(threading.Thread):
         if self.dir is None:
             return
         while not self.stop_flag.is_set():
+            self.t.append(time.perf_counter())
             if self.f_sclk:
                 v = self._read(self.f_sclk)
                 if v:
@@ -131,7 +132,14 @@ class DeviceSampler(threading.Thread):
 
     def summary(self):
         mean = lambda xs: (sum(xs) / len(xs)) if xs else None
-        return dict(sclk_mhz_mean=mean(self.sclk), sclk_mhz_min=min(self.sclk) if self.sclk else None, power_w_mean=mean(self.power),
+        series = None
+        if self.t and self.t[-1] - self.t[0] >= 2.0 and len(self.sclk) == len(self.t) == len(self.power):
+            # runs of two seconds or more: the clock / power series per second (does the rate hold once the burst is over?)
+            t0, buckets = self.t[0], {}
+            for ti, c, w in zip(self.t, self.sclk, self.power):
+                buckets.setdefault(int(ti - t0), []).append((c, w))
+            series = [dict(second=k, sclk_mhz=round(mean([c for c, _ in v])), power_w=round(mean([w for _, w in v]))) for k, v in sorted(buckets.items())]
+        return dict(per_second=series, sclk_mhz_mean=mean(self.sclk), sclk_mhz_min=min(self.sclk) if self.sclk else None, power_w_mean=mean(self.power),
                     power_w_max=max(self.power) if self.power else None, power_cap_w=self.cap_w, samples=max(len(self.sclk), len(self.power)),
                     source=(self.dir or self.note))
 
@@ -317,11 +325,13 @@ def _main(real_stdout):
             return None
         merged_model.load_weights(force=True)
         e_all = ItemEncoderMixin.encode_items(passes, module)
-        c, n = state["cursor"], e_all.shape[0]
-        if c + n > M:
-            c = 0
-        module.item_embeddings.data[c : c + n] = e_all  # refresh those rows before scoring
-        state["cursor"] = c + n
+        c, n, off = state["cursor"], e_all.shape[0], 0
+        while off < n:  # refresh those rows before scoring (a long run re-encodes more rows than the catalog holds: wrap around)
+            c = 0 if c >= M else c
+            take = min(n - off, M - c)
+            module.item_embeddings.data[c : c + take] = e_all[off : off + take]
+            c, off = c + take, off + take
+        state["cursor"] = c
         module.on_test_epoch_start()
         for i in range(lo, hi):
             step(i)
