@@ -14,7 +14,7 @@ import collections, csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernel-name substring -> (family name used by bench.py's LaunchProfiler, launches per encoder pass (None: one per step))
 FAMILIES = {"gemm_nt_bf16x6_kernel": ("gemm_nt_bf16x", 49), "gemm_nt_kernel": ("gemm_nt", 49), "attn_kernel": ("attention", 11),
-            "attn_split_kernel": ("attention_bf16x", 11), "merge_nway_kernel": ("merge_nway", 1), "split_weights_kblock_kernel": ("split_weights", 1),
+            "attn_split_kernel": ("attention_bf16x", 11), "attn_split_work_kernel": ("attention_bf16x", 11), "topk_rows_reg_kernel": ("topk_rows", None), "merge_nway_kernel": ("merge_nway", 1), "split_weights_kblock_kernel": ("split_weights", 1),
             "embed_gather_ln_kernel": ("embed_gather_ln", 1), "layernorm_kernel": ("layernorm", 24), "topk_rows_kernel": ("topk_rows", None)}
 
 
