@@ -36,11 +36,15 @@ def run(lens, label):
     return ms
 
 
-for L in (32, 64, 96, 128, 160, 192, 256, 320, 384, 448, 512):
+quick = os.environ.get("AB_QUICK", "0") == "1"
+for L in ((256, 512) if quick else (32, 64, 96, 128, 160, 192, 256, 320, 384, 448, 512)):
     run(torch.full((65536 // L,), L), f"uniform L={L}")
 g = torch.Generator().manual_seed(1234)
 lens = blair_sequence_lengths(256, g)
 run(lens, "ragged users (bench)")
+if quick:
+    run(torch.cat([lens] * 4), "ragged users x 4 (tail amortised)")
+    sys.exit(0)
 run(lens[lens >= 384], "ragged, L >= 384 only")
 run(lens[(lens >= 128) & (lens < 384)], "ragged, 128 <= L < 384")
 run(lens[lens < 128], "ragged, L < 128")
