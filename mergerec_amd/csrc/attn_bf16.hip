@@ -435,9 +435,11 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
         for (int r = 0; r < 16; ++r) { o[j][0][r] = 0.f; o[j][1][r] = 0.f; }
     }
 
+    MR_PH_DECL
     gload(tile_base(0));
     lstore(lds);
     __syncthreads();
+    MR_PH(0)
 
     for (int it = 0; it < ntiles; ++it) {
         const unsigned char* buf = lds + (it & 1) * BUFB;
@@ -488,6 +490,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                     s[QT - 1] = mfma_split<NP>(ka, qp[QT - 1][st], s[QT - 1]);
                 }
             }
+            MR_PH(1)
             // ---- mask + online softmax (base 2) per query tile; s[r] is key kb + (r&3) + 8*(r>>2) + 4*lh for query q0 + lr
             u32x4 pp[QT][2][NP];
             auto softmax = [&](auto J) {
@@ -546,6 +549,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
             };
             if (rel[0]) softmax(QIdx<0>{});
             if (QT == 2 && rel[QT - 1]) softmax(QIdx<QT - 1>{});
+            MR_PH(2)
             // ---- O^T += V^T P^T: A operand element j of k-step st is V[kb + (j & 3) + 8 (2 st + (j >> 2)) + 4 lh][d]
             const unsigned char* vbase = buf + NP * KPIECE;
             auto vfrag = [&](int dt, int st, u32x4 (&va)[NP]) {
@@ -589,10 +593,14 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                     }
             }
         }
+        MR_PH(3)
         __builtin_amdgcn_sched_barrier(0);
         lstore(lds + ((it + 1) & 1) * BUFB);
+        MR_PH(4)
         __syncthreads();
+        MR_PH(5)
     }
+    MR_PH_FLUSH(blockIdx.x)
 
 #pragma unroll
     for (int j = 0; j < QT; ++j) {

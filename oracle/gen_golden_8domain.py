@@ -26,9 +26,29 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "oracle"))
 
 N_USERS, U_KEEP, E_STRIDE = 1024, 256, 64
+# r03: with 1,024 users ONE label crossing a Recall cut-off through a verified 2e-6 near-tie moves that metric by 9.8e-4 -- the whole 1e-3 bound.
+# The five domains where that happened are evaluated on 4,096 users (2.4e-4 per user); `python oracle/gen_golden_8domain.py <names>` regenerates
+# a subset into g13_partial.pt and `--merge` folds it into the fixture.
+N_USERS_WIDE = {"Beauty": 4096, "Sports": 4096, "Instruments": 4096, "Office": 4096, "Scientific": 4096}
 SEED_PRE, SEED_FT = 2000, tuple(range(2001, 2009))
 ALPHAS = (0.30, 0.10, 0.20, 0.15, 0.05, 0.25, 0.10, 0.20)
 SEED_DOMAIN0 = 31000
+
+
+def merge_partial():
+    import torch
+
+    full_p, part_p = ROOT / "tests" / "golden" / "g13_8domain_blair_base.pt", ROOT / "tests" / "golden" / "g13_partial.pt"
+    full, part = torch.load(full_p, weights_only=False), torch.load(part_p, weights_only=False)
+    for key in ("seed_pre", "seed_ft", "alphas", "ft_std", "ks", "key_order", "pre_checksum", "merged_checksum"):
+        assert full[key] == part[key], key
+    for name, d in part["domains"].items():
+        full["domains"][name] = d
+    for name, d in full["domains"].items():
+        d.setdefault("n_users", full["n_users"])
+    torch.save(full, full_p)
+    part_p.unlink()
+    print("merged", list(part["domains"]), "->", full_p, full_p.stat().st_size)
 
 
 def main():
@@ -37,7 +57,7 @@ def main():
 
     import gen_golden as GG
 
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(__import__("os").environ.get("GEN_THREADS", "8")))
     GG.install_reference_importer()
     from oracle import ref_cpu as O
     from mergerec_amd.synthetic import CATALOG_SIZES, make_domain
@@ -92,6 +112,7 @@ def main():
         if only and name not in only:
             continue
         seed = SEED_DOMAIN0 + d
+        N_USERS = N_USERS_WIDE.get(name, 1024)
         dom = make_domain(name, M, N_USERS, 32, cfg.vocab, seed)
         E = encode(dom.item_batches, "items", name)
         U = encode(dom.sequence_batches, "sequence", name)
@@ -108,13 +129,13 @@ def main():
         win = label_rank.long()[:, None] + torch.arange(-3, 4)[None, :]                    # sorted positions rank - 3 .. rank + 3
         label_window = torch.where((win >= 0) & (win < M), srt.gather(1, win.clamp(0, M - 1)), torch.full(win.shape, float("nan")))
         rows = torch.arange(0, M, E_STRIDE)
-        domains[name] = dict(n_items=M, seed=seed, U=U[:U_KEEP].clone(), E_rows=rows.to(torch.int32), E_sample=E[rows].clone(),
+        domains[name] = dict(n_items=M, n_users=N_USERS, seed=seed, U=U[:U_KEEP].clone(), E_rows=rows.to(torch.int32), E_sample=E[rows].clone(),
                              E_checksum=float(E.double().sum()), labels=labels, ref_top52_idx=top.indices[:, :52].to(torch.int32).clone(),
                              ref_top52_val=top.values[:, :52].clone(), label_rank=label_rank, label_score=lab_score.clone(), label_window=label_window,
                              metrics={k: float(v) for k, v in metrics.items()}, loss=loss)
         print(f"{name}: M={M} NDCG@10={metrics['test/NDCG@10']:.4f} loss={loss:.4f}  {time.time() - t0:.0f}s", flush=True)
 
-    out = dict(n_users=N_USERS, u_keep=U_KEEP, e_stride=E_STRIDE, seed_pre=SEED_PRE, seed_ft=list(SEED_FT), alphas=list(ALPHAS), ft_std=1e-3, ks=ks,
+    out = dict(n_users=1024, u_keep=U_KEEP, e_stride=E_STRIDE, seed_pre=SEED_PRE, seed_ft=list(SEED_FT), alphas=list(ALPHAS), ft_std=1e-3, ks=ks,
                key_order=list(pre.keys()), pre_checksum=float(sum(v.double().sum() for v in pre.values())),
                merged_checksum=float(sum(v.double().sum() for v in merged.values())), domains=domains,
                versions=dict(torch=str(torch.__version__), transformers=str(__import__("transformers").__version__)))
@@ -124,4 +145,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    merge_partial() if "--merge" in sys.argv else main()

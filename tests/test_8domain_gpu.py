@@ -57,9 +57,9 @@ def test_all_eight_domains_match_the_reference(merged, tmp_path):
     assert list(fx["domains"]) == list(CATALOG_SIZES), "the fixture covers every domain"
     module = RecModule(model=model, evaluator=Evaluator(["NDCG", "RECALL"], fx["ks"]), similarity="cosine")
     worst = dict(logit=0.0, ndcg10=0.0, any_metric=0.0)
-    n_users = fx["n_users"]
-    ar = torch.arange(n_users)
     for name, d in fx["domains"].items():
+        n_users = d.get("n_users", fx["n_users"])  # r03: 4,096 on the domains where one near-tie move used up the whole bound at 1,024
+        ar = torch.arange(n_users)
         dom = make_domain(name, d["n_items"], n_users, 32, cfg.vocab, d["seed"])
         seqs, at = [], 0
         for b in dom.sequence_batches:  # the fixture's labels (the reference's rank-derived items) replace the generator's random ones
@@ -103,6 +103,7 @@ def test_all_eight_domains_match_the_reference(merged, tmp_path):
         pos = lambda lists: torch.where((lists == labels[0][:, None]).any(1), (lists == labels[0][:, None]).float().argmax(1), torch.full((n_users,), 50))
         ties = (d["label_window"][:, 2] == d["label_score"]) | (d["label_window"][:, 4] == d["label_score"])  # exact ties in the reference
         must, slack = O.metrics_after_rank_moves(d["metrics"], pos(ref_idx[:, :50]), pos(idx), fx["ks"], tie_users=ties)
+        dom_worst = max((abs(metrics[0][k] - v), k) for k, v in d["metrics"].items())
         for k, v in d["metrics"].items():
             worst["any_metric"] = max(worst["any_metric"], abs(metrics[0][k] - v))
             assert abs(metrics[0][k] - must[k]) < 5e-6 + slack[k], (name, k, metrics[0][k], must[k], slack[k])
@@ -111,5 +112,6 @@ def test_all_eight_domains_match_the_reference(merged, tmp_path):
         dn = abs(metrics[0]["test/NDCG@10"] - d["metrics"]["test/NDCG@10"])
         worst["logit"], worst["ndcg10"] = max(worst["logit"], logit_err), max(worst["ndcg10"], dn)
         print(f"[{name}] M={d['n_items']} logit max err {logit_err:.2e}; top-50 positions differing (all near-ties) {int(diff.sum())}; "
-              f"labels moved {int((my_rank != ref_rank).sum())}; NDCG@10 {metrics[0]['test/NDCG@10']:.4f} (reference {d['metrics']['test/NDCG@10']:.4f}, |d| {dn:.1e})")
+              f"labels moved {int((my_rank != ref_rank).sum())}; NDCG@10 {metrics[0]['test/NDCG@10']:.4f} (reference {d['metrics']['test/NDCG@10']:.4f}, |d| {dn:.1e}); "
+              f"largest metric difference {dom_worst[0]:.1e} ({dom_worst[1]})")
     print(f"[8 domains] worst logit err {worst['logit']:.2e}, worst |dNDCG@10| {worst['ndcg10']:.1e}, worst |d metric| {worst['any_metric']:.1e}")
