@@ -2,13 +2,21 @@
 // Each workgroup's wave 0 accumulates s_memtime deltas: 0 prologue, 1 compute (LDS fragment reads + MFMA issue),
 // 2 split + LDS store + global prefetch issue, 3 barrier wait, 4 epilogue issue.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imergerec_amd/csrc -o exp/gemm_phases exp/gemm_phases.hip
+//        ... -DPH_CLOCK_ONLY -o exp/gemm_clock ...   (in-kernel clock of the unperturbed kernel: profiles/r03_inkernel_clock.txt)
 #include <hip/hip_runtime.h>
 __device__ unsigned long long g_ph[16384 * 8];
 __device__ unsigned long long g_rt[16384 * 2];
 #define MR_PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long ph_t0 = ph_t; const unsigned long long ph_r0 = __builtin_amdgcn_s_memrealtime();
+#ifdef PH_CLOCK_ONLY  /* r03: no phase stamps -- only the workgroup's first / last s_memtime + s_memrealtime: the UNPERTURBED library kernel's clock */
+#define MR_PH(i)
+#define MR_PH_WAITLOADS(i)
+#define MR_PH_LAST ph_t = __builtin_amdgcn_s_memtime();
+#else
+#define MR_PH_LAST
 #define MR_PH(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += n_ - ph_t; ph_t = n_; }
 #define MR_PH_WAITLOADS(i) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); MR_PH(i) }  /* NT=4, NP=2: the newer stage's 6 loads stay in flight */
-#define MR_PH_FLUSH(pid) if (threadIdx.x == 0 && (pid) < 16384) { for (int z = 0; z < 6; ++z) g_ph[(pid) * 8 + z] = ph_acc[z]; g_ph[(pid) * 8 + 6] = ph_t0; g_ph[(pid) * 8 + 7] = ph_t; g_rt[(pid) * 2] = ph_r0; g_rt[(pid) * 2 + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#define MR_PH_FLUSH(pid) MR_PH_LAST if (threadIdx.x == 0 && (pid) < 16384) { for (int z = 0; z < 6; ++z) g_ph[(pid) * 8 + z] = ph_acc[z]; g_ph[(pid) * 8 + 6] = ph_t0; g_ph[(pid) * 8 + 7] = ph_t; g_rt[(pid) * 2] = ph_r0; g_rt[(pid) * 2 + 1] = __builtin_amdgcn_s_memrealtime(); }
 #include "../mergerec_amd/csrc/gemm_bf16.hip"
 #include "../mergerec_amd/csrc/capi.hip"
 #include <stdio.h>
