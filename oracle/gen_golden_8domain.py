@@ -29,6 +29,7 @@ N_USERS, U_KEEP, E_STRIDE = 1024, 256, 64
 # r03: with 1,024 users ONE label crossing a Recall cut-off through a verified 2e-6 near-tie moves that metric by 9.8e-4 -- the whole 1e-3 bound.
 # The five domains where that happened are evaluated on 4,096 users (2.4e-4 per user); `python oracle/gen_golden_8domain.py <names>` regenerates
 # a subset into g13_partial.pt and `--merge` folds it into the fixture.
+LABEL_WIN = 8  # reference scores kept either side of the label's rank (r02: 3; a 4,096-user domain holds a label that moves 4 places through near-ties)
 N_USERS_WIDE = {"Beauty": 4096, "Sports": 4096, "Instruments": 4096, "Office": 4096, "Scientific": 4096}
 SEED_PRE, SEED_FT = 2000, tuple(range(2001, 2009))
 ALPHAS = (0.30, 0.10, 0.20, 0.15, 0.05, 0.25, 0.10, 0.20)
@@ -126,7 +127,7 @@ def main():
         lab_score = scores[torch.arange(N_USERS), labels]
         label_rank = (scores > lab_score[:, None]).sum(1).to(torch.int32)
         srt = torch.sort(scores, dim=1, descending=True).values
-        win = label_rank.long()[:, None] + torch.arange(-3, 4)[None, :]                    # sorted positions rank - 3 .. rank + 3
+        win = label_rank.long()[:, None] + torch.arange(-LABEL_WIN, LABEL_WIN + 1)[None, :]  # sorted positions rank - w .. rank + w
         label_window = torch.where((win >= 0) & (win < M), srt.gather(1, win.clamp(0, M - 1)), torch.full(win.shape, float("nan")))
         rows = torch.arange(0, M, E_STRIDE)
         domains[name] = dict(n_items=M, n_users=N_USERS, seed=seed, U=U[:U_KEEP].clone(), E_rows=rows.to(torch.int32), E_sample=E[rows].clone(),
