@@ -304,6 +304,9 @@ int mr_attn_global_row_train_f32(const float* qg, const float* kvg, const int32_
 int mr_attn_bwd_train_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H,
                           int dh, int max_len, float scale, int window, float drop_p, uint32_t drop_key, float* rowstat, float* dqkv,
                           mr_stream_t stream);
+/* mr_attn_bwd_train_f32 on the work-list grid of mr_attn_split_work_f32 (work from mr_attn_work_plan with q_rows = 128): same results. */
+int mr_attn_bwd_work_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H,
+                         int dh, float scale, int window, float drop_p, uint32_t drop_key, float* rowstat, float* dqkv, mr_stream_t stream);
 int mr_attn_global_row_bwd_train_f32(const float* qg, const float* kvg, const float* ctx_cls, const float* dctx_cls, const int32_t* cu_seqlens,
                                      int B, int H, int dh, float scale, float drop_p, uint32_t drop_key, float* dqg, float* dkvg,
                                      mr_stream_t stream);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "mr_attn_split_work_train_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_i, c_f, c_u32, c_p, c_p]),
     "mr_attn_global_row_train_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u32, c_p, c_i, c_p]),
     "mr_attn_bwd_train_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p, c_p]),
+    "mr_attn_bwd_work_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p, c_p]),
     "mr_attn_global_row_bwd_train_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_u32, c_p, c_p, c_p]),
     "mr_attn_global_row_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "mr_cls_pool_normalize_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_p, c_p]),

@@ -146,14 +146,23 @@ __global__ __launch_bounds__(64 * NW, (STATS ? 4 : 3)) void attn_bwd_q_kernel(co
                                                                 const float* __restrict__ dctx, const int32_t* __restrict__ cu,
                                                                 const int32_t* __restrict__ order, int H, float scale, int window,
                                                                 float* __restrict__ rowstat, float* __restrict__ dqkv,
-                                                                uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u) {
+                                                                uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u,
+                                                                const int32_t* __restrict__ work = nullptr) {
     // drop_thresh != 0: the forward dropped attention probabilities (mask = mr::dropout_keep(key, query token * H + head, key position)):
     // dP = (dO . v) * mask / (1 - p); delta = dO . O already holds the dropped forward
     __shared__ float ks[kTile], vs[STATS ? 1 : kTile];
-    const int b = order ? order[blockIdx.z] : blockIdx.z, h = blockIdx.y;  // longest sequences first when the caller passes the order
-    const int t0 = cu[b], len = cu[b + 1] - t0;
     constexpr int kRows = 32 * NW;  // rows owned by this workgroup
-    const int Q0 = blockIdx.x * kRows;
+    // work != NULL: the 1-D work-list grid of mr_attn_split_work_f32 (csrc/attn_bf16.hip: only the (sequence, 128-row block) pairs that
+    // exist, dealt over the XCD queues); else the (blocks, H, B) box with the longest sequences first when the caller passes the order
+    int b, h, Q0;
+    if (work) {
+        const int slot = blockIdx.x >> 3, e = slot / H, ent = work[e * 8 + (blockIdx.x & 7)];
+        if (ent < 0) return;
+        h = slot - e * H; b = ent & 0xffffff; Q0 = (ent >> 24) * kRows;
+    } else {
+        b = order ? order[blockIdx.z] : blockIdx.z; h = blockIdx.y; Q0 = blockIdx.x * kRows;
+    }
+    const int t0 = cu[b], len = cu[b + 1] - t0;
     if (Q0 >= len) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
@@ -284,12 +293,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_kernel(const float* __
                                                                  const float* __restrict__ rowstat, const int32_t* __restrict__ cu,
                                                                  const int32_t* __restrict__ order, int H, float scale, int window,
                                                                  float* __restrict__ dqkv, uint32_t drop_thresh = 0u, float drop_inv = 1.f,
-                                                                 uint32_t drop_key = 0u) {
+                                                                 uint32_t drop_key = 0u, const int32_t* __restrict__ work = nullptr) {
     __shared__ float qs[kTile], gs[kTile], stat[32][2];
-    const int b = order ? order[blockIdx.z] : blockIdx.z, h = blockIdx.y;
-    const int t0 = cu[b], len = cu[b + 1] - t0;
     constexpr int kRows = 32 * NW;
-    const int K0 = blockIdx.x * kRows;
+    int b, h, K0;
+    if (work) {  // as in attn_bwd_q_kernel: a key block of 128 rows per list entry
+        const int slot = blockIdx.x >> 3, e = slot / H, ent = work[e * 8 + (blockIdx.x & 7)];
+        if (ent < 0) return;
+        h = slot - e * H; b = ent & 0xffffff; K0 = (ent >> 24) * kRows;
+    } else {
+        b = order ? order[blockIdx.z] : blockIdx.z; h = blockIdx.y; K0 = blockIdx.x * kRows;
+    }
+    const int t0 = cu[b], len = cu[b + 1] - t0;
     if (K0 >= len) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const int64_t ld = (int64_t)3 * H * kDh, ldc = (int64_t)H * kDh;
@@ -391,6 +406,31 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_kernel(const float* __
 static int attn_bwd_launch(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H,
                            int dh, int max_len, float scale, int window, float* rowstat, float* dqkv, uint32_t thresh, float inv, uint32_t key,
                            mr_stream_t stream);
+
+// work-list launch of the three backward kernels (work / n_slots from mr_attn_work_plan(lens, B, 128, ...)): no empty workgroups on ragged
+// batches; same results as mr_attn_bwd_train_f32 bit for bit (every output element has one owner and a fixed order in both)
+extern "C" int mr_attn_bwd_work_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* work,
+                                    int64_t n_slots, int H, int dh, float scale, int window, float drop_p, uint32_t drop_key, float* rowstat,
+                                    float* dqkv, mr_stream_t stream) {
+    uint32_t thresh;
+    float inv;
+    if (!mr::dropout_params(drop_p, &thresh, &inv)) return MR_EINVAL;
+    if (!qkv || !ctx || !dctx || !cu_seqlens || !rowstat || !dqkv || n_slots < 0 || H < 1 || (n_slots > 0 && !work)) return MR_EINVAL;
+    if (dh != kDh) return MR_EUNSUPPORTED;
+    if (!mr::aligned16(qkv) || !mr::aligned16(ctx) || !mr::aligned16(dctx)) return MR_EALIGN;
+    if (n_slots == 0) return MR_OK;
+    if (n_slots * 8 * (int64_t)H > 0x7fffffff) return MR_EINVAL;
+    const dim3 grid((unsigned)(n_slots * 8 * H));
+    hipStream_t st = (hipStream_t)stream;
+    if (!thresh) inv = 1.f;
+    hipLaunchKernelGGL((attn_bwd_q_kernel<true, 4>), grid, dim3(256), 0, st, qkv, ctx, dctx, cu_seqlens, nullptr, H, scale, window, rowstat, dqkv, thresh,
+                       inv, drop_key, work);
+    hipLaunchKernelGGL((attn_bwd_q_kernel<false, 4>), grid, dim3(256), 0, st, qkv, ctx, dctx, cu_seqlens, nullptr, H, scale, window, rowstat, dqkv, thresh,
+                       inv, drop_key, work);
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<4>), grid, dim3(256), 0, st, qkv, dctx, rowstat, cu_seqlens, nullptr, H, scale, window, dqkv, thresh, inv, drop_key,
+                       work);
+    return mr::check_launch();
+}
 
 extern "C" int mr_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order, int B,
                                int H, int dh, int max_len, float scale, int window, float* rowstat, float* dqkv, mr_stream_t stream) {

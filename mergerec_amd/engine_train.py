@@ -272,7 +272,7 @@ class EncoderTrainGraph:
             self._wgrad(da_t, self._xt(s["ctx"]), g[lp + "attention.output.dense.weight"])
             dctx = self._dgrad(dad, w, l, "attention.output.dense")
             dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window, max_len=pb.max_len, seq_order=pb.seq_order,
-                                     drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_ATTN_PROBS) if pa > 0.0 else 0)
+                                     drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_ATTN_PROBS) if pa > 0.0 else 0, work=pb.attn_work)
             xt = self._xt(s["x"])
             if self.rec:
                 dqg, dkvg = ops.attention_global_row_bwd(s["qg"], s["kvg"], ops.gather_rows(s["ctx"], pb.cls_rows), ops.gather_rows(dctx, pb.cls_rows),

@@ -646,7 +646,8 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
 
 
 def attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, scale: Optional[float] = None,
-                  window: int = -1, max_len: Optional[int] = None, seq_order: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_key: int = 0):
+                  window: int = -1, max_len: Optional[int] = None, seq_order: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_key: int = 0,
+                  work=None):
     _dev(qkv, "qkv", torch.float32), _dev(ctx, "ctx", torch.float32), _dev(dctx, "dctx", torch.float32)
     T = qkv.shape[0]
     if not (qkv.is_contiguous() and ctx.is_contiguous() and dctx.is_contiguous()) or qkv.shape[1] != 3 * H * 64:
@@ -656,7 +657,11 @@ def attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, cu_s
     if max_len is None:  # (one small D2H sync; the training graph passes the packed batch's own maximum)
         max_len = int((cu_seqlens[1:] - cu_seqlens[:-1]).max()) if B else 0
     ev = PROF.begin(qkv.device)
-    if drop_p > 0.0:
+    wl = work.get(128) if work else None
+    if wl is not None and os.environ.get("MR_ATTN_WORKLIST", "1") != "0":  # the (sequence, 128-row block) pairs that exist: no empty workgroups
+        check(_lib.load().mr_attn_bwd_work_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, 64, 0.125 if scale is None else scale,
+                                               window, float(drop_p), drop_key, ptr(rowstat), ptr(dqkv), _stream(qkv)), "mr_attn_bwd_work_f32")
+    elif drop_p > 0.0:
         check(_lib.load().mr_attn_bwd_train_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), ptr(seq_order), B, H, 64, max_len,
                                                 0.125 if scale is None else scale, window, drop_p, drop_key, ptr(rowstat), ptr(dqkv), _stream(qkv)),
               "mr_attn_bwd_train_f32")

@@ -75,6 +75,13 @@ def test_attention_backward_matches_torch(lens):
     assert torch.allclose(ctx_dev.cpu(), ctx.detach(), atol=2e-5)
     got = ops.attention_bwd(qkv.to(DEV), ctx_dev, dctx.to(DEV), cu.to(DEV), len(lens), H).cpu()
     assert torch.allclose(got, q.grad, atol=3e-5, rtol=1e-4), (got - q.grad).abs().max()
+    # the work-list launch (only the (sequence, 128-row block) pairs that exist) gives the same bits, with and without dropout, full and banded
+    work = {128: (lambda w, n: (w.to(DEV), n))(*ops.attn_work_plan(torch.tensor(lens), 128))}
+    for window, p_drop in ((-1, 0.0), (-1, 0.1), (4, 0.0), (4, 0.1)):
+        kw = dict(window=window, max_len=max(lens), drop_p=p_drop, drop_key=77)
+        box = ops.attention_bwd(qkv.to(DEV), ctx_dev, dctx.to(DEV), cu.to(DEV), len(lens), H, **kw)
+        lst = ops.attention_bwd(qkv.to(DEV), ctx_dev, dctx.to(DEV), cu.to(DEV), len(lens), H, work=work, **kw)
+        assert torch.equal(box, lst), (window, p_drop)
 
 
 def test_encoder_backward_matches_oracle_autograd():
