@@ -254,6 +254,9 @@ int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t
  * dealt over the 8 queues in snake order.  It returns n_slots; with work == NULL or capacity < n_slots * 8 nothing is written (size query).
  * replaces: the same reference code as mr_attn_f32 (transformers RobertaSelfAttention / LongformerSelfAttention). */
 int mr_attn_split_q_rows(int window, int products);
+/* mr_attn_f32 (exact fp32) on the same kind of work list (q_rows = 128); drop_p > 0: the training-graph dropout of mr_attn_train_f32. */
+int mr_attn_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale, int window,
+                     float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream);
 int64_t mr_attn_work_plan(const int64_t* lens_host, int B, int q_rows, int32_t* work_host, int64_t capacity);
 int mr_attn_split_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale,
                            int window, int products, float* ctx, mr_stream_t stream);

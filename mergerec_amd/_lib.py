@@ -77,6 +77,7 @@ SIGNATURES = {
     "mr_attn_split_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p]),
     "mr_attn_split_q_rows": (c_i, [c_i, c_i]),
     "mr_attn_work_plan": (c_i64, [c_p, c_i, c_i, c_p, c_i64]),
+    "mr_attn_work_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p]),
     "mr_attn_split_work_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_i, c_p, c_p]),
     "mr_dropout_site_key": (c_i, [c_u32, c_u32, c_u32, c_u32, c_p]),
     "mr_dropout_rows_f32": (c_i, [c_p, c_i64, c_i, c_i, c_f, c_u32, c_p, c_i64, c_p, c_i64, c_p]),

@@ -409,24 +409,29 @@ def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_l
     dh = qkv.shape[1] // (3 * H)
     out = torch.empty(T, H * dh, dtype=torch.float32, device=qkv.device) if out is None else out
     ev = PROF.begin(qkv.device)
-    if drop_p > 0.0:
-        wl = work.get(attn_q_rows(window, products)) if (work and products == 3) else None
-        if wl is not None:
-            check(_lib.load().mr_attn_split_work_train_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, products, drop_p,
-                                                           drop_key, ptr(out), _stream(qkv)), "mr_attn_split_work_train_f32")
-        else:  # exact-fp32 kernel (also the bf16x3 graph's route when a batch carries no work list)
-            check(_lib.load().mr_attn_train_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, drop_p, drop_key,
-                                                ptr(out), _stream(qkv)), "mr_attn_train_f32")
-    elif products:
-        wl = work.get(attn_q_rows(window, products)) if work else None
-        if wl is not None and os.environ.get("MR_ATTN_WORKLIST", "1") != "0":
-            check(_lib.load().mr_attn_split_work_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, products,
-                                                     ptr(out), _stream(qkv)), "mr_attn_split_work_f32")
+    use_list = bool(work) and os.environ.get("MR_ATTN_WORKLIST", "1") != "0"
+    lib = _lib.load()
+    if products and use_list and (drop_p == 0.0 or products == 3) and work.get(attn_q_rows(window, products)) is not None:
+        wl = work[attn_q_rows(window, products)]
+        if drop_p > 0.0:
+            check(lib.mr_attn_split_work_train_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, products, drop_p, drop_key,
+                                                   ptr(out), _stream(qkv)), "mr_attn_split_work_train_f32")
         else:
-            check(_lib.load().mr_attn_split_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, products,
-                                                ptr(out), _stream(qkv)), "mr_attn_split_f32")
+            check(lib.mr_attn_split_work_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, products, ptr(out), _stream(qkv)),
+                  "mr_attn_split_work_f32")
+    elif (not products or drop_p > 0.0) and use_list and work.get(128) is not None:
+        # exact-fp32 kernel on the work list (also the route of a dropout launch in the six-product mode, which has no dropout variant)
+        wl = work[128]
+        check(lib.mr_attn_work_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, float(drop_p), drop_key, ptr(out), _stream(qkv)),
+              "mr_attn_work_f32")
+    elif drop_p > 0.0:
+        check(lib.mr_attn_train_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, drop_p, drop_key, ptr(out), _stream(qkv)),
+              "mr_attn_train_f32")
+    elif products:
+        check(lib.mr_attn_split_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, products, ptr(out), _stream(qkv)),
+              "mr_attn_split_f32")
     else:
-        check(_lib.load().mr_attn_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, ptr(out), _stream(qkv)), "mr_attn_f32")
+        check(lib.mr_attn_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, ptr(out), _stream(qkv)), "mr_attn_f32")
     PROF.end(ev, qkv.device, "attention" if not products else f"attention_bf16x{products}", flops=ATTN_FLOPS_HINT[0], nbytes=4.0 * T * 4 * H * dh)
     ATTN_FLOPS_HINT[0] = 0.0
     return out

@@ -269,10 +269,10 @@ def test_attention_split_precision(ops, products, tol, window):
     assert torch.allclose(got[keep], want[keep], atol=tol, rtol=tol), (got[keep] - want[keep]).abs().max()
 
 
-@pytest.mark.parametrize("products", [3, 6])
+@pytest.mark.parametrize("products", [0, 3, 6])
 @pytest.mark.parametrize("window", [-1, 4, 32])
 def test_attention_work_list_is_bit_identical_to_the_box_grid(ops, products, window):
-    """mr_attn_split_work_f32 (host-built (sequence, query block) list, 256-row blocks with two query tiles per wave for full attention in
+    """mr_attn_work_f32 (products = 0: the exact-fp32 kernel) / mr_attn_split_work_f32 (host-built (sequence, query block) list, 256-row blocks with two query tiles per wave for full attention in
     bf16x3) against mr_attn_split_f32 on a ragged batch that exercises every tile-count case of a block (1..8 query tiles, partial
     tiles, one-token sequences): the same bits, rows that belong to the global-row kernel untouched, and within tolerance of fp64."""
     g = _g(300 + products + window)
