@@ -407,16 +407,24 @@ class EncoderRunner:
             if ops.PROF.enabled:
                 w_ = sp.one_sided_window
                 ops.ATTN_FLOPS_HINT[0] = 4.0 * sp.hidden * (pb.sum_len_sq if not rec else pb.T * (2 * w_ + 2))
+            chain = ops.PROF.chain if (self.fuse_qkv and not rec) else (lambda: None)  # back-to-back launches: shared event stamps
+            chain()
             ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=sp.one_sided_window if rec else -1,
                                 seq_order=pb.seq_order, products={"f32": 0, "bf16x6": 6, "bf16x3": 3}[w.mode], work=pb.attn_work)
             if rec:
                 qg = self._proj(w, lp, ("query_global",), ops.gather_rows(x, pb.cls_rows))
                 kvg = self._proj(w, lp, ("key_global", "value_global"), x)
                 ops.attention_global_row(qg, kvg, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx)
+        chain = ops.PROF.chain if (not cls_only and not rec and self.fuse_qkv) else (lambda: None)
+        chain()
         h = self._linear(w, ctx, [lp + "attention.output.dense.weight"], [lp + "attention.output.dense.bias"], residual=x)
+        chain()
         h = ops.layernorm(h, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps, out=h)
+        chain()
         i = self._linear(w, h, [lp + "intermediate.dense.weight"], [lp + "intermediate.dense.bias"], act=ops.ACT_GELU)
+        chain()
         o = self._linear(w, i, [lp + "output.dense.weight"], [lp + "output.dense.bias"], residual=h)
+        chain()
         return ops.layernorm(o, w[lp + "output.LayerNorm.weight"], w[lp + "output.LayerNorm.bias"], sp.ln_eps, out=o)
 
     def forward_packed(self, w, pb: PackedBatch, normalize: bool, return_hidden: bool = False):
@@ -432,6 +440,8 @@ class EncoderRunner:
         L = self.spec.layers
         for l in range(L):
             last = l == L - 1
+            if l and not (last and not return_hidden):
+                ops.PROF.chain()  # a full layer's first launch follows the previous layer's LayerNorm directly
             x = self.layer(w, l, x, pb, cls_only=last and not return_hidden)
             if return_hidden:
                 hidden.append(x)
