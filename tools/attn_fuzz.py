@@ -1,5 +1,6 @@
 """Randomised differential test of the attention kernels (fp32 / bf16x6 / bf16x3, full and Longformer-windowed, backward kernels)
-on ragged batches against a float64 torch reference.  Exit code 1 on any mismatch."""
+on ragged batches against a float64 torch reference, through BOTH launch forms: the work list the engine builds while packing (the
+product's route) and the (blocks, H, B) box grid -- which must also agree with each other bit for bit.  Exit code 1 on any mismatch."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -34,8 +35,14 @@ for it in range(int(os.environ.get("FZ_N", 24))):
     rows = torch.ones(T, dtype=torch.bool)
     if window >= 0:
         rows[cu[:-1].long()] = False  # row 0 of every sequence belongs to the global-row kernel
+    work = {q: (lambda w, n: (w.to(dev), n))(*ops.attn_work_plan(torch.tensor(lens), q)) for q in (128, 256)}
     for products, tol in ((0, 3e-6), (6, 3e-6), (3, 2e-4)):
-        got = ops.attention(qkv.to(dev), cu.to(dev), B, H, max(lens), window=window, products=products).cpu().double()
+        box = ops.attention(qkv.to(dev), cu.to(dev), B, H, max(lens), window=window, products=products)
+        lst = ops.attention(qkv.to(dev), cu.to(dev), B, H, max(lens), window=window, products=products, work=work)
+        if not torch.equal(box[rows.to(dev)], lst[rows.to(dev)]):
+            bad += 1
+            print(f"MISMATCH work list vs box grid it={it} products={products} H={H} lens={lens} window={window}")
+        got = lst.cpu().double()
         err = float((got[rows] - ref.detach()[rows]).abs().max()) if rows.any() else 0.0
         if not err <= tol:
             bad += 1
@@ -44,7 +51,12 @@ for it in range(int(os.environ.get("FZ_N", 24))):
     dd = dctx.clone(); dd[~rows] = 0
     (ref * dd.double()).sum().backward()
     ctx_dev = ops.attention(qkv.to(dev), cu.to(dev), B, H, max(lens), window=window, products=0)
-    gq = ops.attention_bwd(qkv.to(dev), ctx_dev, dd.to(dev), cu.to(dev), B, H, window=window).cpu().double()
+    gq_box = ops.attention_bwd(qkv.to(dev), ctx_dev, dd.to(dev), cu.to(dev), B, H, window=window, max_len=max(lens))
+    gq_dev = ops.attention_bwd(qkv.to(dev), ctx_dev, dd.to(dev), cu.to(dev), B, H, window=window, max_len=max(lens), work=work)
+    if not torch.equal(gq_box, gq_dev):
+        bad += 1
+        print(f"MISMATCH bwd work list vs box grid it={it} H={H} lens={lens} window={window}")
+    gq = gq_dev.cpu().double()
     err = float((gq - q.grad).abs().max()) / (float(q.grad.abs().max()) + 1e-9)
     if not err <= 2e-5:
         bad += 1
