@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kRegThreads) void topk_rows_reg_kernel(const float*
                                                                    const int64_t* __restrict__ labels, float inv_temp,
                                                                    float* __restrict__ row_lse, float* __restrict__ row_lab,
                                                                    int32_t* __restrict__ label_rank) {
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist4[4][256];  // one histogram per radix pass, all zeroed once (no zero-and-barrier inside the pass loop)
     __shared__ unsigned s_prefix, s_remaining, s_ngt, s_neq, s_eqtotal, s_rank;
     __shared__ unsigned wcnt[kRegWaves];
     __shared__ float red[kRegWaves];
@@ -241,11 +241,12 @@ __global__ __launch_bounds__(kRegThreads) void topk_rows_reg_kernel(const float*
 
     if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)k; s_ngt = 0u; s_neq = 0u; s_eqtotal = 0u; s_rank = 0xffffffffu; }
     for (int i = tid; i < KCAP; i += kRegThreads) cand[i] = 0ull;
+    (&hist4[0][0])[tid] = 0u;  // 4 x 256 words, one per thread
+    __syncthreads();
     unsigned mask = 0u;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0u;
-        __syncthreads();
+        unsigned* hist = hist4[pass];
         const unsigned prefix = s_prefix, rem = s_remaining;
         // run-length pre-aggregation per thread (cosine scores share sign, exponent and the top mantissa bits: one atomic per run)
         unsigned run_b = 0xffffffffu, run_n = 0u;
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(kRegThreads) void topk_rows_reg_kernel(const float*
         float acc = 0.f;
 #pragma unroll
         for (int e = 0; e < NV * 4; ++e)
-            if (key[e] != 0u) acc += expf(key_value(key[e]) * inv_temp - mx);
+            if (key[e] != 0u) acc += __expf(key_value(key[e]) * inv_temp - mx);  // arguments <= 0: v_exp_f32 on x * log2(e) is within 2 ulp
         acc = mr::wave_sum(acc);
         if (lane == 0) red[wave] = acc;
         __syncthreads();
