@@ -12,6 +12,13 @@
 #include <stdlib.h>
 #include <atomic>
 
+// phase-timing hooks: empty in the library; exp/topk_phases.hip defines them (s_memtime deltas of thread 0)
+#ifndef MR_TK_DECL
+#define MR_TK_DECL
+#define MR_TK(i)
+#define MR_TK_FLUSH(row)
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(kThreads) void topk_rows_kernel(const float* __rest
 // a serial walk over 256 LDS words.  Same canonical result as topk_rows_kernel (score desc, index asc; NaN first; -0 == +0), also
 // for k up to 1024 (the candidates are then sorted by the whole workgroup).  Covers ncols <= 4096 * NV (NV <= 12: 49,152 columns; longer rows take topk_rows_kernel).
 constexpr int kRegThreads = 1024;
+constexpr int kFastBins = 2048, kFastCand = 2048;
 constexpr int kRegWaves = kRegThreads / MR_WAVE;
 
 __device__ __forceinline__ float key_value(unsigned key) {  // inverse of ord_key up to the sign of zero and the NaN payload
@@ -216,10 +224,16 @@ __global__ __launch_bounds__(kRegThreads) void topk_rows_reg_kernel(const float*
     __shared__ unsigned wcnt[kRegWaves];
     __shared__ float red[kRegWaves];
     __shared__ unsigned long long cand[KCAP];
+    // fast path (below): one 2048-bin histogram over the row's own key range, candidate lists
+    __shared__ unsigned h2[kFastBins];
+    __shared__ unsigned long long c2[kFastCand], c3[kFastCand];
+    __shared__ unsigned wlo[kRegWaves], whi[kRegWaves], wsum[kRegWaves];
+    __shared__ unsigned s_nc, s_bstar, s_nctot;
 
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ g = scores + (int64_t)row * ld;
     // element (j, c) of this thread is column (j * 1024 + tid) * 4 + c; columns past ncols carry key 0 (below every real key)
+    MR_TK_DECL
     unsigned key[NV * 4];
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15u) == 0);
 #pragma unroll
@@ -239,10 +253,89 @@ __global__ __launch_bounds__(kRegThreads) void topk_rows_reg_kernel(const float*
         key[e] = i < ncols ? ord_key(__uint_as_float(key[e])) : 0u;
     }
 
-    if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)k; s_ngt = 0u; s_neq = 0u; s_eqtotal = 0u; s_rank = 0xffffffffu; }
+    MR_TK(0)
+    if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)k; s_ngt = 0u; s_neq = 0u; s_eqtotal = 0u; s_rank = 0xffffffffu; s_nc = 0u; s_nctot = 0xffffffffu; }
     for (int i = tid; i < KCAP; i += kRegThreads) cand[i] = 0ull;
     (&hist4[0][0])[tid] = 0u;  // 4 x 256 words, one per thread
-    __syncthreads();
+    h2[tid] = 0u;
+    h2[tid + kRegThreads] = 0u;
+    // ---- fast path: ONE histogram pass.  The keys of a row of cosine scores share their sign, exponent and leading mantissa bits, so a
+    // fixed-digit radix pass spends its first two sweeps on bits that do not separate anything.  Instead the 2048 bins are laid over the
+    // row's own key range [kmin, kmax] (bin = (key - kmin) >> sh): the bin that holds the k-th largest key and every bin above it then
+    // contain k plus a few keys -- those go to a candidate list that is rank-sorted directly ((key, index) pairs are unique; ties at the
+    // threshold share a bin, so the canonical order falls out).  Rows whose range is blown up by an outlier (NaN, inf) or that hold
+    // thousands of equal keys put more than kFastCand keys into the list: they take the exact four-pass radix select below.
+    constexpr bool kTryFast = NV >= 4;  // short rows (<= 8,192 columns): the fixed cost of this path exceeds what the radix passes cost there
+    bool fast = false;
+    if (kTryFast) {
+        unsigned klo = 0xffffffffu, khi = 0u;
+#pragma unroll
+        for (int e = 0; e < NV * 4; ++e)
+            if (key[e]) { klo = key[e] < klo ? key[e] : klo; khi = key[e] > khi ? key[e] : khi; }  // key 0 = padding (no real key is 0)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned a = __shfl_xor(klo, o, 64), c = __shfl_xor(khi, o, 64);
+            klo = a < klo ? a : klo;
+            khi = c > khi ? c : khi;
+        }
+        if (lane == 0) { wlo[wave] = klo; whi[wave] = khi; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < kRegWaves; ++w) { klo = wlo[w] < klo ? wlo[w] : klo; khi = whi[w] > khi ? whi[w] : khi; }
+        const unsigned range = khi - klo;
+        const int sh = range ? ((32 - __clz(range) - 11) > 0 ? (32 - __clz(range) - 11) : 0) : 0;  // (range >> sh) < 2048
+#pragma unroll
+        for (int e = 0; e < NV * 4; ++e)
+            if (key[e]) atomicAdd(&h2[(key[e] - klo) >> sh], 1u);
+        __syncthreads();
+        {
+            // thread t owns bins 2 t, 2 t + 1; `above` = keys in higher bins (suffix sum over the lanes above, then the waves above)
+            const unsigned a0 = h2[2 * tid], a1 = h2[2 * tid + 1], loc = a0 + a1;
+            unsigned incl = loc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_down(incl, o, 64);
+                if (lane + o < 64) incl += t;
+            }
+            if (lane == 0) wsum[wave] = incl;
+            __syncthreads();
+            unsigned above = incl - loc;
+#pragma unroll
+            for (int w = 0; w < kRegWaves; ++w)
+                if (w > wave) above += wsum[w];
+            if (above < (unsigned)k && (unsigned)k <= above + loc) {  // exactly one thread: its bins hold the k-th largest key
+                if (above + a1 >= (unsigned)k) { s_bstar = 2u * tid + 1u; s_nctot = above + a1; }
+                else { s_bstar = 2u * tid; s_nctot = above + loc; }
+            }
+        }
+        __syncthreads();
+        fast = s_nctot <= (unsigned)kFastCand;  // block-uniform
+        if (fast) {
+            const unsigned bstar = s_bstar, nc = s_nctot;
+#pragma unroll
+            for (int e = 0; e < NV * 4; ++e) {
+                if (key[e] && ((key[e] - klo) >> sh) >= bstar) {
+                    const unsigned slot = atomicAdd(&s_nc, 1u);
+                    const unsigned i = (unsigned)(((e >> 2) * kRegThreads + tid) * 4 + (e & 3));
+                    c2[slot] = ((unsigned long long)key[e] << 32) | (unsigned long long)(0xffffffffu - i);
+                }
+            }
+            __syncthreads();
+            for (unsigned t = tid; t < nc; t += kRegThreads) {  // rank sort, descending by (key, -index): the pairs are unique
+                const unsigned long long v = c2[t];
+                unsigned r = 0u;
+                for (unsigned j = 0; j < nc; ++j) r += c2[j] > v ? 1u : 0u;
+                c3[r] = v;
+            }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
+    MR_TK(1)
+    const unsigned long long* __restrict__ sorted = fast ? c3 : cand;
+    const int64_t lab = labels ? labels[row] : -1;
+    if (!fast) {
     unsigned mask = 0u;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
@@ -352,8 +445,8 @@ __global__ __launch_bounds__(kRegThreads) void topk_rows_reg_kernel(const float*
     }
     __syncthreads();
 
+    MR_TK(2)
     // sort the candidates descending by (key, -index); unused slots are 0 and sink
-    const int64_t lab = labels ? labels[row] : -1;
     if (KCAP == 64) {
         if (wave == 0) {
             unsigned long long v = cand[lane];
@@ -384,8 +477,9 @@ __global__ __launch_bounds__(kRegThreads) void topk_rows_reg_kernel(const float*
         }
     }
     __syncthreads();
+    }  // !fast
     for (int t = tid; t < k; t += kRegThreads) {
-        unsigned idx = 0xffffffffu - (unsigned)(cand[t] & 0xffffffffull);
+        unsigned idx = 0xffffffffu - (unsigned)(sorted[t] & 0xffffffffull);
         if (idx >= (unsigned)ncols) idx = 0u;  // cannot happen for ncols >= k; never read out of bounds
         top_idx[(int64_t)row * k + t] = (int64_t)idx;
         top_val[(int64_t)row * k + t] = g[idx];
@@ -396,9 +490,10 @@ __global__ __launch_bounds__(kRegThreads) void topk_rows_reg_kernel(const float*
         if (tid == 0 && label_rank) label_rank[row] = s_rank == 0xffffffffu ? -1 : (int32_t)s_rank;
     }
 
+    MR_TK(3)
     if (labels && row_lse) {
         // row max = best candidate's score (NaN rows propagate NaN like torch.cross_entropy)
-        unsigned best = 0xffffffffu - (unsigned)(cand[0] & 0xffffffffull);
+        unsigned best = 0xffffffffu - (unsigned)(sorted[0] & 0xffffffffull);
         if (best >= (unsigned)ncols) best = 0u;
         const float mx = g[best] * inv_temp;
         float acc = 0.f;
@@ -416,6 +511,8 @@ __global__ __launch_bounds__(kRegThreads) void topk_rows_reg_kernel(const float*
             if (row_lab) row_lab[row] = (lab >= 0 && lab < ncols) ? g[lab] * inv_temp : NAN;
         }
     }
+    MR_TK(4)
+    MR_TK_FLUSH(row)
 }
 
 }  // namespace
