@@ -84,6 +84,8 @@ class Evaluator:
             raise ValueError("Evaluator expects GPU score tensors (top-k runs in the HIP kernel; no CPU fallback)")
         from .. import ops
 
+        if self._max_k > scores.shape[1]:  # torch.topk(scores, self._max_k, dim=1) (evaluator/evaluator.py:43)
+            raise RuntimeError(f"selected index k out of range (max(ks) = {self._max_k}, {scores.shape[1]} score columns)")
         _, _, _, _, rank = ops.topk_rows(scores.contiguous(), self._max_k, labels.to(scores.device, torch.int64).contiguous())
         return self.from_ranks(rank, metric_prefix)
 

@@ -202,7 +202,9 @@ class RecModule(_Base):
     def _eval_step(self, batch: BatchSequence):
         user = self._encode(batch.sequence)
         labels = batch.labels.to(user.device, torch.int64).contiguous()
-        k = min(self.evaluator._max_k, self.item_embeddings.shape[0])
+        k = self.evaluator._max_k
+        if k > self.item_embeddings.shape[0]:  # torch.topk(scores, max(ks)) upstream (evaluator/evaluator.py:43) raises the same way
+            raise RuntimeError(f"selected index k out of range (max(ks) = {k}, catalog of {self.item_embeddings.shape[0]} items)")
         _, idx, lse, lab, rank, scores = ops.score_topk(user, self.item_embeddings.data, k, labels, 1.0 / self.temperature,
                                                         return_scores=self.keep_scores)
         self._ranks.append(rank)
@@ -225,7 +227,7 @@ class RecModule(_Base):
         cat = lambda xs, empty: torch.cat(xs, dim=0) if xs else empty
         dev = self.device
         d = self.item_embeddings.shape[1] if self.item_embeddings is not None else 0
-        k = min(self.evaluator._max_k, self.item_embeddings.shape[0]) if self.item_embeddings is not None else 0
+        k = self.evaluator._max_k if self.item_embeddings is not None else 0
         labels = cat(self.eval_labels, torch.empty(0, dtype=torch.int64, device=dev))
         users = cat(self.eval_user_embeddings, torch.empty(0, d, device=dev))
         topk = cat(self.eval_topk_indices, torch.empty(0, k, dtype=torch.int64, device=dev))
@@ -245,6 +247,12 @@ class RecModule(_Base):
                 parts = [shard.gather_rows(local[:, c0:c0 + 4096].to(dev)) for c0 in range(0, M, 4096)]
                 scores = torch.cat([p_.cpu() for p_ in parts], dim=1) if shard.rank == 0 else None
         self.eval_labels, self.eval_user_embeddings, self.eval_topk_indices = labels.cpu(), users.cpu(), topk.cpu()
+        if self.item_embeddings is not None and self.eval_labels.numel():
+            # F.cross_entropy(scores / T, labels) upstream (module.py:356) raises for a class index outside the catalog; the scoring kernel
+            # reads no memory for such a label (its logit is NaN, its rank -1), so the check waits for the epoch's labels on the host
+            bad = (self.eval_labels < 0) | (self.eval_labels >= self.item_embeddings.shape[0])
+            if bool(bad.any()):
+                raise IndexError(f"Target {int(self.eval_labels[bad][0])} is out of bounds.")
         self.eval_scores = scores
         if scores is None and self.item_embeddings is not None and (shard is None or shard.world == 1 or shard.rank == 0):
             self._eval_scores_lazy = (self.eval_user_embeddings, self.item_embeddings.data)  # materialised on first access

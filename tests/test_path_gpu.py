@@ -512,6 +512,56 @@ def test_load_merging_module_ties_lns(merge_type):
     assert torch.equal(merged, O.merge_task_wise(base, want_tv, torch.full((3,), 0.4)))
 
 
+def test_scoring_edge_cases_behave_like_the_reference():
+    """The evaluation loop on degenerate shapes, and the two errors upstream raises from torch: ``torch.topk(scores, max(ks))`` on a catalog
+    smaller than max(ks) (evaluator/evaluator.py:43: RuntimeError) and ``F.cross_entropy`` on a label outside the catalog (module.py:356:
+    IndexError "Target ... is out of bounds.") -- the scoring kernel itself reads no memory for such a label."""
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.module import ModelType, RecModule
+    from mergerec_amd.synthetic import make_domain
+    from mergerec_amd.utils import test_model_on_dataloaders as test_model
+
+    over = dict(hidden=128, heads=2, layers=1, intermediate=128, vocab=300, max_pos=200)
+
+    def run(ks, n_items, n_users, bs=32, mutate=None, module=None):
+        mod = module or RecModule(model=ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 3, "spec_overrides": over, "device": DEV}),
+                                  evaluator=Evaluator(["NDCG", "RECALL"], ks), similarity="cosine")
+        dom = make_domain("Toy", n_items=n_items, n_users=n_users, batch_size=bs, vocab=300, seed=5, max_seq_len=120, item_len_scale=0.3)
+        if mutate:
+            mutate(dom)
+        return mod, dom, test_model(mod, [dom.item_batches], [dom.sequence_batches], ["Toy"])[1][0]
+
+    with pytest.raises(RuntimeError, match="selected index k out of range"):
+        run([1, 5, 10, 50], 30, 40)
+    with pytest.raises(RuntimeError, match="selected index k out of range"):
+        Evaluator(["NDCG"], [50])(torch.randn(4, 30, device=DEV), torch.zeros(4, dtype=torch.int64, device=DEV))
+    _, _, m = run([1, 5, 10], 30, 40)  # k up to the catalog size is fine
+    assert m["test/Recall@10"] >= m["test/Recall@5"] >= m["test/Recall@1"]
+    _, _, m = run([1], 1, 5)  # a one-item catalog: every label is item 0, cosine scores, loss = log(1) = 0
+    assert m == {"test/NDCG@1": 1.0, "test/Recall@1": 1.0, "test/loss": 0.0}
+    _, dom1, one = run([1, 5], 64, 1)
+    assert set(one) == {"test/NDCG@1", "test/NDCG@5", "test/Recall@1", "test/Recall@5", "test/loss"} and one["test/loss"] == one["test/loss"]
+    _, _, a = run([1, 5], 64, 7, bs=1)  # one-row batches all the way through
+    assert a["test/loss"] == a["test/loss"] and 0.0 <= a["test/Recall@5"] <= 1.0
+    # metric keys keep the order of --ks as given (evaluator.py:12-15 builds them metric-major in that order)
+    _, _, m = run([10, 5, 1], 64, 40)
+    assert list(m) == ["test/NDCG@10", "test/NDCG@5", "test/NDCG@1", "test/Recall@10", "test/Recall@5", "test/Recall@1", "test/loss"]
+    # a module evaluated twice starts from clean state
+    mod, dom, first = run([1, 10], 64, 40)
+    assert test_model(mod, [dom.item_batches], [dom.sequence_batches], ["Toy"])[1][0] == first
+
+    def bad_label(value):
+        def f(dom):
+            dom.sequence_batches[0].labels = dom.sequence_batches[0].labels.clone()
+            dom.sequence_batches[0].labels[0] = value
+        return f
+
+    with pytest.raises(IndexError, match="Target 10000 is out of bounds"):
+        run([1, 10], 64, 40, mutate=bad_label(10_000))
+    with pytest.raises(IndexError, match="Target -1 is out of bounds"):
+        run([1, 10], 64, 40, mutate=bad_label(-1))
+
+
 def test_coalesced_batches_give_identical_results():
     """Macro-batching of the dataloader stream (padding-invariant kernels) must not change any per-sequence result."""
     from mergerec_amd.data import coalesce_batches
