@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/mergerec_hip.h"
 
 #define MR_WAVE 64
@@ -19,6 +20,25 @@ inline int check_launch() {
     }
     return MR_OK;
 }
+
+// Dynamic-LDS ceiling of one kernel (hipFuncAttributeMaxDynamicSharedMemorySize), raised once per device and per kernel: declare one
+// `static mr::DynLdsCeiling` beside the launch of each instantiation.  The return code is checked (a failed call would otherwise surface
+// as an opaque launch error, or only on the second device of a process); racing first calls both set the same value.
+struct DynLdsCeiling {
+    static constexpr int kMaxDevices = 64;
+    std::atomic<size_t> set[kMaxDevices] = {};
+    int ensure(const void* kernel, size_t bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return MR_ELAUNCH;
+        if (set[dev].load(std::memory_order_acquire) >= bytes) return MR_OK;
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            set_last_hip_error(hipGetErrorString(hipGetLastError()));
+            return MR_EUNSUPPORTED;
+        }
+        set[dev].store(bytes, std::memory_order_release);
+        return MR_OK;
+    }
+};
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -235,7 +235,10 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __re
     for (int c = lane * 4; c < d; c += MR_WAVE * 4) *reinterpret_cast<float4*>(out + (int64_t)i * ldo + c) = ld4(r + c);
 }
 
-// any width / alignment (teacher-score rows have the catalog's length): one dword per lane, still coalesced
+// any width / alignment (teacher-score rows have the catalog's length): one dword per lane, still coalesced.  A wave copies one
+// kScalarChunk-column piece of a row (blockIdx.y = piece): the alpha-learning step gathers a handful of catalog-length rows, which one
+// wave per row turns into a few hundred dependent loads
+constexpr int kScalarChunk = 2048;
 __global__ __launch_bounds__(kThreads) void gather_rows_scalar_kernel(const float* __restrict__ xin, int64_t ldx,
                                                                      const int32_t* __restrict__ idx, int n, int d,
                                                                      float* __restrict__ out, int64_t ldo) {
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(kThreads) void gather_rows_scalar_kernel(const floa
     const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (i >= n) return;
     const float* r = xin + (int64_t)idx[i] * ldx;
-    for (int c = lane; c < d; c += MR_WAVE) out[(int64_t)i * ldo + c] = r[c];
+    const int c0 = blockIdx.y * kScalarChunk, c1 = (c0 + kScalarChunk < d) ? c0 + kScalarChunk : d;
+    for (int c = c0 + lane; c < c1; c += MR_WAVE) out[(int64_t)i * ldo + c] = r[c];
 }
 
 #define MR_DISPATCH_NV(d, CALL)                                  \
@@ -335,8 +339,8 @@ extern "C" int mr_gather_rows_f32(const float* x, int64_t ldx, const int32_t* ro
     if (n == 0) return MR_OK;
     const unsigned blocks = (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock);
     if ((d & 3) || (ldx & 3) || (ldo & 3) || !mr::aligned16(x) || !mr::aligned16(out)) {
-        hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, row_idx, n, d, out,
-                           ldo);
+        hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3(blocks, (unsigned)((d + kScalarChunk - 1) / kScalarChunk)), dim3(kThreads), 0,
+                           (hipStream_t)stream, x, ldx, row_idx, n, d, out, ldo);
         return mr::check_launch();
     }
     hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, row_idx, n, d, out, ldo);

@@ -531,12 +531,10 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
     const bool pf2 = ((K / BK) % 2 == 0) && !(wide && products == 6);
 #define MR_GEMM_LAUNCH5(ACT_, HASR_, PF2_, NP_, NT_)                                                                                  \
     do {                                                                                                                              \
-        static bool attr_done = false;                                                                                                \
-        if (!attr_done) {                                                                                                             \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_>),                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * PIECE + 3 * (NT_ / 2) * PIECE) + shm_pad);                  \
-            attr_done = true;                                                                                                         \
-        }                                                                                                                             \
+        static mr::DynLdsCeiling lds_ceiling;                                                                                         \
+        if (const int e_ = lds_ceiling.ensure(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_>),     \
+                                              2 * (3 * PIECE + 3 * (NT_ / 2) * PIECE) + shm_pad))                                     \
+            return e_;                                                                                                                \
         hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_>), dim3(nwg), dim3(kThreads), shm, st, A, lda, w_hi,     \
                            w_mid, w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg, group_n,  \
                            tiles_m);                                                                                                  \
@@ -601,12 +599,10 @@ extern "C" int mr_gemm_nt_bf16x3_splitk_f32(const float* A, int64_t lda, const u
     hipStream_t st = (hipStream_t)stream;
 #define MR_SK_LAUNCH(PF2_, NT_)                                                                                                          \
     do {                                                                                                                                 \
-        static bool attr_done = false;                                                                                                   \
-        if (!attr_done) {                                                                                                                \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<MR_ACT_NONE, false, PF2_, 2, NT_, true>),           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * PIECE + 3 * (NT_ / 2) * PIECE));                    \
-            attr_done = true;                                                                                                            \
-        }                                                                                                                                \
+        static mr::DynLdsCeiling lds_ceiling;                                                                                            \
+        if (const int e_ = lds_ceiling.ensure(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<MR_ACT_NONE, false, PF2_, 2, NT_, true>), \
+                                              2 * (3 * PIECE + 3 * (NT_ / 2) * PIECE)))                                                  \
+            return e_;                                                                                                                   \
         hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<MR_ACT_NONE, false, PF2_, 2, NT_, true>), dim3(nwg, nsplit), dim3(kThreads),            \
                            2 * (size_t)(3 * PIECE + 3 * (BN / 128) * PIECE), st, A, lda, w_hi, w_mid, w_hi, off, 0, 0, nullptr, nullptr,  \
                            nullptr, M, N, K, nullptr, 0, part, (int64_t)N, tiles_n, tiles_n, nwg, tiles_n, tiles_m, kchunk, stride);      \

@@ -79,7 +79,13 @@ def _dev(t: torch.Tensor, name: str, dtype=None):
     return t
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the handle without building a torch.cuda.Stream object per launch
+
+
 def _stream(t: torch.Tensor):
+    """HIP stream handle of torch's current stream on ``t``'s device (every kernel is launched on it)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -578,8 +584,33 @@ def _pad16(n: int) -> int:
     return (n + 15) // 16 * 16
 
 
+def splitk_plan(M: int, N: int, K: int, has_residual: bool = False) -> int:
+    """Number of k slices for the exact-fp32 training product (M, K) x (N, K)^T: the argmin of a launch model fitted to
+    ``tools/splitk_sweep.py`` on an MI355X (it ranks every measured shape's candidates in the measured order).  These products are
+    latency-bound -- one workgroup per CU runs a 128 x 128 x 16 tile step in ~1.2 us, 2.3 x the matrix pipe's time -- so a launch costs
+    (rounds of 256 workgroups) x (tile steps per workgroup), and cutting k pays until the partial sums' traffic (s x M x N x 4 B written
+    and read again) and the second launch outweigh it.  One slice goes through the plain kernel, which halves the tile height when that
+    fills the chip better (no residual).  A pure function of the shape: the same slices, hence the same bits, on every rank and run."""
+    nk = max(K // 16, 1)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    step_us, launch_us, bytes_per_us = 1.2, 6.0, 8.0e6  # the partial sums are re-read out of L2 / Infinity Cache
+    half_tiles = ((M + 63) // 64) * ((N + 127) // 128)
+    if not has_residual and -(-half_tiles // 256) * 0.5 * 1.05 < -(-tiles // 256):  # csrc/gemm.hip's own rule
+        best, best_cost = 1, -(-half_tiles // 256) * nk * 0.5 * step_us
+    else:
+        best, best_cost = 1, -(-tiles // 256) * nk * step_us
+    for sp in range(2, min(nk, 16) + 1):
+        chunk = -(-nk // sp)
+        if -(-nk // chunk) != sp:  # the library rounds slices to whole k tiles: this count collapses to a smaller one
+            continue
+        cost = -(-tiles * sp // 256) * chunk * step_us + launch_us + sp * M * N * 8.0 / bytes_per_us
+        if cost < best_cost:
+            best, best_cost = sp, cost
+    return best
+
+
 def gemm_nt_train(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, splits: Optional[int] = None) -> torch.Tensor:
     """A @ W.T (+ bias) (+ residual) for the training graph: split-K when the output has too few tiles to fill the chip."""
     if not (A.is_cuda and W.is_cuda and A.dtype == torch.float32 and W.dtype == torch.float32):
         raise ValueError("A and W must be fp32 GPU tensors (the HIP path has no CPU fallback)")
@@ -589,7 +620,8 @@ def gemm_nt_train(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
         raise ValueError("A (M, K) with unit inner stride and contiguous W (N, K) expected")
     out = torch.empty(M, N, dtype=torch.float32, device=A.device) if out is None else out
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    splits = max(1, min(K // 16, 16, 512 // max(tiles, 1)))
+    if splits is None:
+        splits = splitk_plan(M, N, K, residual is not None)
     lib = _lib.load()
     nbytes = lib.mr_gemm_nt_splitk_ws_bytes(M, N, splits)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=A.device) if splits > 1 else None

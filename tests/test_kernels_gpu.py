@@ -219,6 +219,8 @@ def test_layernorm_and_cls_pool(ops, d):
     assert torch.equal(ops.gather_rows(x.to(DEV), idx.to(DEV)).cpu(), x[idx.long()])
     y = torch.randn(9, 333)  # unaligned width: scalar path
     assert torch.equal(ops.gather_rows(y.to(DEV), idx.to(DEV) % 9).cpu(), y[(idx % 9).long()])
+    z = torch.randn(5, 4 * 2048 + 77)  # catalog-length rows (teacher scores): several column pieces per row, ragged last piece
+    assert torch.equal(ops.gather_rows(z.to(DEV), idx.to(DEV) % 5).cpu(), z[(idx % 5).long()])
 
 
 # ------------------------------------------------------------------ K4 attention

@@ -76,6 +76,17 @@ print(f"{MODEL} {learn} [{mm.train_mode}]: N={N} domains, B={B} sequences ({int(
       f"({1e3/ms:.1f} steps/s, {B*1e3/ms:.0f} sequences/s); loss {loss.item():.4f}")
 print(f"  parameter-sized streams per step: merge fwd {(N+2)*P*4/1e9:.2f} GB + alpha-gradient {(N+1)*P*4/1e9:.2f} GB "
       f"-> {((2*N+3)*P*4/1e9)/(ms/1e3)/1e3:.2f} TB/s of the step if nothing else moved")
+if os.environ.get("TB_HOSTPROF", "0") == "1":  # where the host thread spends a step (cProfile inflates Python frames; read the shares)
+    import cProfile, pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+
 if os.environ.get("TB_CPU", "0") == "1" and not REC:
     # the same step through the CPU oracle (merge + encoder + loss restatements) with torch autograd, 16 threads
     from oracle import ref_cpu as O
@@ -106,5 +117,5 @@ if os.environ.get("TB_PROFILE", "1") == "1":
     rows = sorted(((e.key, e.device_time_total / 3e3, e.count // 3) for e in prof.key_averages() if e.device_time_total > 0), key=lambda r: -r[1])
     tot = sum(r[1] for r in rows)
     print(f"  device time per step {tot:.2f} ms over {sum(r[2] for r in rows)} launches:")
-    for k, t, c in rows[:14]:
+    for k, t, c in rows[: int(os.environ.get("TB_ROWS", 14))]:
         print(f"    {t:7.3f} ms  x{c:<4d} {k[:110]}")

@@ -2,6 +2,8 @@
 # Regenerates profiles/<round>_* on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh [modes...]'      (default mode list: bf16x3)
 # Everything large stays in /tmp; only the reduced summaries are written under gpurun_out/profiles/ (copy them to profiles/).
+# Order per mode: kernel trace + stats, traffic / clock counter passes, SQ passes (bf16x3; SQ=0 skips), then the plain bench, whose
+# line quotes the counter files just produced.
 set -o pipefail
 RND=r03
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,9 +12,6 @@ mkdir -p $OUT
 MODES=${@:-bf16x3}
 cd /tmp && export TMPDIR=/tmp
 for m in $MODES; do
-  extra="--no-cpu-baseline"; [ $m = bf16x3 ] && extra=""
-  timeout -k 10 400 python3 $R/bench.py --steps 10 --warmup 2 --gemm-mode $m $extra > $OUT/${RND}_bench_$m.json 2> /tmp/bench_$m.err || { tail -5 /tmp/bench_$m.err; exit 1; }
-  echo "bench $m done"
   rm -rf /tmp/prof_$m
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$m -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --gemm-mode $m > $OUT/${RND}_bench_under_rocprof_$m.json 2> /tmp/prof_$m.err || { tail -5 /tmp/prof_$m.err; exit 1; }
   cp $(ls /tmp/prof_$m/*/*kernel_stats.csv | head -1) $OUT/${RND}_kernel_stats_$m.csv
@@ -31,5 +30,12 @@ for m in $MODES; do
   python3 $R/tools/pmc_clock.py /tmp/pmcc_$m $OUT/${RND}_pmc_clock_$m.json > /dev/null
   echo "pmc $m done"
   rm -rf /tmp/prof_$m /tmp/pmcf_$m /tmp/pmcw_$m /tmp/pmcl_$m /tmp/pmcc_$m
+  # SQ passes (matrix-pipe busy) for the headline mode, then the plain bench LAST: its line reads the counter files of THIS source
+  # tree from profiles/ (roofline.traffic, roofline.mfma_busy; a hash of csrc/ flags them stale otherwise)
+  if [ $m = bf16x3 ] && [ "${SQ:-1}" = 1 ]; then bash $R/tools/sq_pass.sh $m > /tmp/sq_$m.log 2>&1 || { tail -8 /tmp/sq_$m.log; exit 1; }; echo "sq $m done"; fi
+  cp $OUT/${RND}_pmc_*_$m.json $R/profiles/
+  extra="--no-cpu-baseline"; [ $m = bf16x3 ] && extra=""
+  timeout -k 10 400 python3 $R/bench.py --steps 10 --warmup 2 --gemm-mode $m $extra > $OUT/${RND}_bench_$m.json 2> /tmp/bench_$m.err || { tail -5 /tmp/bench_$m.err; exit 1; }
+  echo "bench $m done"
 done
 ls -la $OUT

@@ -1,0 +1,40 @@
+"""Split-K sweep of the exact-fp32 training GEMM (ops.gemm_nt_train) at the alpha-learning step's shapes: device time per call
+(product + partial-sum launch) for each split count beside the heuristic's choice.   PYTHONPATH=. python tools/splitk_sweep.py [tokens]"""
+import sys
+import torch
+from mergerec_amd import ops
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 602
+Tp = (T + 15) // 16 * 16
+dev = torch.device("cuda:0")
+shapes = [("fwd q/k/v/out", T, 768, 768), ("fwd up", T, 3072, 768), ("fwd down", T, 768, 3072), ("dgrad qkv", T, 768, 2304),
+          ("dgrad up", T, 768, 3072), ("dgrad down", T, 3072, 768), ("wgrad 768x768", 768, 768, Tp), ("wgrad up", 3072, 768, Tp),
+          ("wgrad down", 768, 3072, Tp)]
+
+
+def timed(fn, n=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+for name, M, N, K in shapes:
+    A, W = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+    out = torch.empty(M, N, device=dev)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    auto = max(1, min(K // 16, 16, 512 // max(tiles, 1)))
+    res = {}
+    for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+        if s > K // 16:
+            continue
+        res[s] = timed(lambda: ops.gemm_nt_train(A, W, out=out, splits=s))
+    best = min(res, key=res.get)
+    print(f"{name:16s} M={M:5d} N={N:5d} K={K:5d} tiles={tiles:3d} auto={auto:2d} ({timed(lambda: ops.gemm_nt_train(A, W, out=out)):6.1f} us)  best={best:2d} "
+          f"({res[best]:6.1f} us)  " + " ".join(f"{s}:{t:.1f}" for s, t in res.items()), flush=True)
