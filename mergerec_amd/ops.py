@@ -6,6 +6,8 @@ tensors and the shared library must be present, otherwise MergeRecHipError / Val
 """
 from __future__ import annotations
 
+import functools
+
 import os
 from typing import Optional, Sequence, Tuple
 
@@ -584,6 +586,7 @@ def _pad16(n: int) -> int:
     return (n + 15) // 16 * 16
 
 
+@functools.lru_cache(maxsize=4096)
 def splitk_plan(M: int, N: int, K: int, has_residual: bool = False) -> int:
     """Number of k slices for the exact-fp32 training product (M, K) x (N, K)^T: the argmin of a launch model fitted to
     ``tools/splitk_sweep.py`` on an MI355X (it ranks every measured shape's candidates in the measured order).  These products are

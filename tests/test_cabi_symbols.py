@@ -90,3 +90,23 @@ def test_ops_refuse_cpu_tensors():
 
     with pytest.raises(ValueError):
         ops.merge_nway(torch.zeros(8), torch.zeros(2, 8), torch.zeros(2))
+
+
+def test_split_plan_of_the_training_product_is_a_pure_function_of_the_shape():
+    """ops.splitk_plan (host logic): slice counts the launch model picks for the alpha-learning step's shapes -- the measured optima of
+    tools/splitk_sweep.py -- and its invariants: 1 <= s <= min(16, k tiles), no slice count the library would collapse."""
+    from mergerec_amd.ops import splitk_plan
+
+    T, Tp = 602, 608
+    shapes = [(T, 768, 768, False), (T, 3072, 768, False), (T, 768, 3072, True), (T, 768, 2304, True), (T, 768, 3072, True),
+              (T, 3072, 768, False), (768, 768, Tp, False), (3072, 768, Tp, False), (768, 3072, Tp, False)]
+    assert [splitk_plan(*s) for s in shapes] == [8, 1, 8, 8, 8, 1, 7, 3, 3]
+    for M in (1, 16, 130, 602, 5000, 70000):
+        for N in (64, 768, 3072):
+            for K in (16, 64, 768, 3072):
+                s = splitk_plan(M, N, K)
+                nk = K // 16
+                assert 1 <= s <= min(16, nk)
+                chunk = -(-nk // s)
+                assert -(-nk // chunk) == s  # the library's rounding to whole k tiles keeps this many slices
+    assert splitk_plan(70000, 768, 768) == 1  # a grid that fills the chip is not cut
