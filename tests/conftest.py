@@ -44,6 +44,15 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
                                     "this run does not cover BLaIR-large / Recformer-large", red=True, bold=True)
 
 
+# ---- background regeneration of the seed-defined inputs of the real-dimension checks: tests/_prefetch.py (ONE module object, whichever
+# name this file is imported under -- pytest loads it as `conftest`, the test modules as `tests.conftest`)
+from tests._prefetch import prefetched, register_prefetch, seeded_state_dicts, start_prefetch  # noqa: E402,F401
+
+
+def pytest_collection_finish(session):
+    start_prefetch(session)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

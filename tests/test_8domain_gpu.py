@@ -6,7 +6,6 @@ Fixture: tests/golden/g13_8domain_blair_base.pt, produced in the build container
 seeds here.  Checked per domain, in the product's default arithmetic (bf16x3) through the drop-in evaluation loop: user embeddings, sampled
 item rows and their logits within 1e-4; the ranked top-50 equal to the reference's up to its own near-ties (2e-6); label ranks equal up to
 near-ties; every Recall / NDCG value within 1e-3; the loss within 1e-3."""
-from collections import OrderedDict
 
 import os
 
@@ -14,7 +13,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu as O
-from tests.conftest import load_golden
+from tests.conftest import load_golden, prefetched, register_prefetch, seeded_state_dicts
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -25,17 +24,24 @@ NEAR_TIE = 2.5e-6      # two items whose REFERENCE scores are this close may swa
 NDCG_TOL = 1e-3        # north_star
 
 
+def _build_state_dicts():
+    """host-only: the fixture and its pretrained + 8 fine-tuned BLaIR-base state dicts (the order the reference's wrapper yielded:
+    perturbations are drawn along it)"""
+    fx = load_golden("g13_8domain_blair_base.pt")
+    cfg = O.EncoderConfig()
+    pre, fts = seeded_state_dicts(O.roberta_param_shapes(cfg), fx["key_order"], fx["seed_pre"], 0.02, fx["pre_checksum"], fx["seed_ft"], fx["ft_std"])
+    return fx, cfg, pre, fts
+
+
+register_prefetch("g13", _build_state_dicts, match=("test_8domain_gpu.py",))
+
+
 @pytest.fixture(scope="module")
 def merged():
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
     from mergerec_amd.module import ModelType
 
-    fx = load_golden("g13_8domain_blair_base.pt")
-    cfg = O.EncoderConfig()
-    pre0 = O.random_state_dict(O.roberta_param_shapes(cfg), seed=fx["seed_pre"], std=0.02)
-    pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])  # the order the reference's wrapper yielded (perturbations are drawn along it)
-    assert abs(float(sum(v.double().sum() for v in pre.values())) - fx["pre_checksum"]) < 1e-6 * abs(fx["pre_checksum"]) + 1e-9
-    fts = [O.perturbed_state_dict(pre, seed=s, std=fx["ft_std"]) for s in fx["seed_ft"]]
+    fx, cfg, pre, fts = prefetched("g13")  # host-only part, drawn in the background (tests/_prefetch.py)
     model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "device": DEV})
     model.load_state_dict(pre)
     mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, pre, fts, set(), disable_softmax=True)  # merge_test.py:35-71

@@ -5,20 +5,31 @@ Fixture: tests/golden/g12_realscale_blair_base.pt, produced in the build contain
 reference itself -- its load_merging_module / get_state_dict (2-domain merge, alpha = 0.5: BASELINE configs[1]), transformers'
 RobertaModel at BLaIR-base true dimensions (12 x 768, 124.6 M parameters), user @ item.T and its Evaluator -- on a Pantry-sized
 synthetic domain (4,968 items, 2,048 users).  Inputs are regenerated from seeds here; the fixture holds outputs and the labels."""
-from collections import OrderedDict
 from pathlib import Path
 
 import pytest
 import torch
 
 from oracle import ref_cpu as O
-from tests.conftest import load_golden
+from tests.conftest import load_golden, prefetched, register_prefetch, seeded_state_dicts
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 LOGIT_TOL = 1e-4       # north_star
 NEAR_TIE = 2e-6        # two items whose REFERENCE scores are this close may swap places (fp32 summation order)
 NDCG_TOL = 1e-3        # north_star
+
+
+def _build_state_dicts():
+    """host-only: the fixture and its pretrained + 2 fine-tuned state dicts (the order the reference's wrapper yielded: perturbations are
+    drawn along it)"""
+    fx = load_golden("g12_realscale_blair_base.pt")
+    cfg = O.EncoderConfig()
+    pre, fts = seeded_state_dicts(O.roberta_param_shapes(cfg), fx["key_order"], fx["seed_pre"], 0.02, fx["pre_checksum"], fx["seed_ft"], fx["ft_std"])
+    return fx, cfg, pre, fts
+
+
+register_prefetch("g12", _build_state_dicts, match=("test_realscale_gpu.py",))
 
 
 @pytest.fixture(scope="module")
@@ -28,12 +39,7 @@ def setup():
     from mergerec_amd.module import ModelType
     from mergerec_amd.synthetic import make_domain
 
-    fx = load_golden("g12_realscale_blair_base.pt")
-    cfg = O.EncoderConfig()
-    pre0 = O.random_state_dict(O.roberta_param_shapes(cfg), seed=fx["seed_pre"], std=0.02)
-    pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])  # the order the reference's wrapper yielded (perturbations are drawn along it)
-    assert abs(float(sum(v.double().sum() for v in pre.values())) - fx["pre_checksum"]) < 1e-6 * abs(fx["pre_checksum"]) + 1e-9
-    fts = [O.perturbed_state_dict(pre, seed=s, std=fx["ft_std"]) for s in fx["seed_ft"]]
+    fx, cfg, pre, fts = prefetched("g12")  # host-only part, drawn in the background (tests/_prefetch.py)
     model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "device": DEV})
     model.load_state_dict(pre)
     mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, pre, fts, set(), disable_softmax=True)

@@ -8,13 +8,12 @@ Fixture: tests/golden/g14_realscale_recformer_base.pt, produced in the build con
 reference itself (its load_merging_module / get_state_dict, its RecformerModel driving transformers' LongformerEncoder, user @ item.T, its
 Evaluator; CPU, fp32).  Inputs are regenerated from seeds here.  Checked through the drop-in evaluation loop: embeddings and sampled logits
 within 1e-4, the ranked top-50 equal up to the reference's own near-ties (2e-6), label ranks equal up to near-ties, every metric within 1e-3."""
-from collections import OrderedDict
 
 import pytest
 import torch
 
 from oracle import ref_cpu as O
-from tests.conftest import heavy, load_golden
+from tests.conftest import heavy, load_golden, prefetched, register_prefetch, seeded_state_dicts
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -27,6 +26,23 @@ SIZES = {"recformer_base": ("g14_realscale_recformer_base.pt", "RECFORMER_BASE")
          "blair_large": ("g16_realscale_blair_large.pt", "BLAIR_LARGE")}   # (BLaIR-base: tests/test_realscale_gpu.py, tests/test_8domain_gpu.py)
 
 
+def _build_state_dicts(size):
+    """host-only: the fixture and the pretrained / fine-tuned state dicts it names by seed (the reference model's key order: perturbations
+    are drawn along it)"""
+    fixture_name, model_type = SIZES[size]
+    fx = load_golden(fixture_name)
+    enc = fx.get("encoder", {})
+    rec = model_type.startswith("RECFORMER")
+    cfg = O.EncoderConfig(max_pos=4098, token_type_size=4, max_item_embeddings=51, one_sided_window=32, **enc) if rec else O.EncoderConfig(**enc)
+    pre, fts = seeded_state_dicts(O.recformer_param_shapes(cfg) if rec else O.roberta_param_shapes(cfg), fx["key_order"], fx["seed_pre"], 0.02,
+                                  fx["pre_checksum"], fx["seed_ft"], fx["ft_std"])
+    return fx, cfg, rec, pre, fts
+
+
+for _size in SIZES:
+    register_prefetch(f"realscale:{_size}", (lambda s=_size: _build_state_dicts(s)), match=("test_realscale_recformer_gpu.py", f"[{_size}-"))
+
+
 @pytest.fixture(scope="module", params=["recformer_base", pytest.param("recformer_large", marks=heavy), pytest.param("blair_large", marks=heavy)])
 def setup(request):
     from mergerec_amd.merger import LearnType, MergeType, load_merging_module
@@ -34,16 +50,9 @@ def setup(request):
     from mergerec_amd.module import ModelType
     from mergerec_amd.synthetic import make_domain
 
-    fixture_name, model_type = SIZES[request.param]
-    fx = load_golden(fixture_name)
-    enc = fx.get("encoder", {})
-    rec = model_type.startswith("RECFORMER")
-    cfg = O.EncoderConfig(max_pos=4098, token_type_size=4, max_item_embeddings=51, one_sided_window=32, **enc) if rec else O.EncoderConfig(**enc)
-    pre0 = O.random_state_dict(O.recformer_param_shapes(cfg) if rec else O.roberta_param_shapes(cfg), seed=fx["seed_pre"], std=0.02)
-    pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])  # the reference model's key order (perturbations are drawn along it)
+    model_type = SIZES[request.param][1]
+    fx, cfg, rec, pre, fts = prefetched(f"realscale:{request.param}")  # host-only part, drawn in the background (tests/_prefetch.py)
     fsum = lambda sd: float(sum(v.double().sum() for v in sd.values() if v.is_floating_point()))
-    assert abs(fsum(pre) - fx["pre_checksum"]) < 1e-6 * abs(fx["pre_checksum"]) + 1e-9
-    fts = [O.perturbed_state_dict(pre, seed=s, std=fx["ft_std"]) for s in fx["seed_ft"]]
     model = ModelType[model_type].value(model_kwargs={"init_seed": 0, "device": DEV})
     model.load_state_dict(pre)
     mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, pre, fts, set(), disable_softmax=True)  # merge_test.py:35-71

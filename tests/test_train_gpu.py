@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu as O
-from tests.conftest import heavy, load_golden
+from tests.conftest import heavy, load_golden, prefetched, register_prefetch, seeded_state_dicts
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -440,16 +440,12 @@ def test_whole_merge_train_step_matches_reference(case):
             assert float((got - want).abs().max()) <= 5e-3 * scale, (name, k, got, want)
 
 
-@pytest.fixture(scope="module")
-def g19_inputs():
-    """the regenerated inputs of fixture g19 (pretrained + 8 fine-tuned state dicts, item matrices, teacher scores), once for both cases"""
+def _build_g19():
+    """host-only: the regenerated inputs of fixture g19 (pretrained + 8 fine-tuned state dicts, item matrices, teacher scores)"""
     fx = load_golden("g19_merge_train_step_realscale.pt")
     cfg = O.EncoderConfig()
-    pre0 = O.random_state_dict(O.roberta_param_shapes(cfg), seed=fx["pretrain_seed"], std=fx["pretrain_std"])
-    pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])
-    assert abs(float(sum(v.double().sum() for v in pre.values())) - fx["pretrain_checksum"]) < 1e-6 * abs(fx["pretrain_checksum"]) + 1e-9
-    fts = [O.perturbed_state_dict(pre, seed=s, std=fx["finetune_std"]) for s in fx["finetune_seeds"]]
-    assert abs(float(sum(v.double().sum() for ft in fts for v in ft.values())) - fx["finetune_checksum"]) < 1e-6 * abs(fx["finetune_checksum"]) + 1e-6
+    pre, fts = seeded_state_dicts(O.roberta_param_shapes(cfg), fx["key_order"], fx["pretrain_seed"], fx["pretrain_std"], fx["pretrain_checksum"],
+                                  fx["finetune_seeds"], fx["finetune_std"], fx["finetune_checksum"])
     # the generator's data stream: lengths, ids, then the item matrices, then the teacher scores (one generator)
     g = torch.Generator().manual_seed(fx["data_seed"])
     B, L = fx["batch"]
@@ -461,6 +457,15 @@ def g19_inputs():
     assert abs(float(sum(x.double().sum() for x in items)) - fx["item_checksum"]) < 1e-6 * abs(fx["item_checksum"]) + 1e-6
     assert abs(float(sum(x.double().sum() for x in teachers)) - fx["teacher_checksum"]) < 1e-6 * abs(fx["teacher_checksum"]) + 1e-6
     return fx, pre, fts, items, teachers
+
+
+register_prefetch("g19", _build_g19, match=("test_train_gpu.py", "test_whole_merge_train_step_at_real_dimensions"))
+
+
+@pytest.fixture(scope="module")
+def g19_inputs():
+    """built once for both cases (drawn in the background while earlier modules run: tests/_prefetch.py)"""
+    return prefetched("g19")
 
 
 @pytest.mark.parametrize("case", [0, 1])
@@ -498,18 +503,13 @@ def test_whole_merge_train_step_at_real_dimensions_matches_reference(g19_inputs,
           f"worst gradient deviation {worst:.1e} of the group's largest entry")
 
 
-@pytest.fixture(scope="module")
-def g20_inputs():
-    """the regenerated inputs of fixture g20 (Recformer-large: pretrained + 4 fine-tuned state dicts of 435 M parameters each, item
-    matrices, teacher scores), built ONCE for the four tests that use them (two reference cases, two 8-domain property cases)"""
+def _build_g20():
+    """host-only: the regenerated inputs of fixture g20 (Recformer-large: pretrained + 4 fine-tuned state dicts of 435 M parameters each,
+    item matrices, teacher scores)"""
     fx = load_golden("g20_merge_train_step_recformer_large.pt")
     cfg = O.EncoderConfig(**{k: v for k, v in fx["cfg"].items() if k in O.EncoderConfig.__dataclass_fields__})
-    pre0 = O.random_state_dict(O.recformer_param_shapes(cfg), seed=fx["pretrain_seed"], std=fx["pretrain_std"])
-    pre = OrderedDict((k, pre0[k]) for k in fx["key_order"])
-    fsum = lambda sds: float(sum(v.double().sum() for sd in sds for v in sd.values() if v.is_floating_point()))
-    assert abs(fsum([pre]) - fx["pretrain_checksum"]) < 1e-6 * abs(fx["pretrain_checksum"]) + 1e-9
-    fts = [O.perturbed_state_dict(pre, seed=s, std=fx["finetune_std"]) for s in fx["finetune_seeds"]]
-    assert abs(fsum(fts) - fx["finetune_checksum"]) < 1e-6 * abs(fx["finetune_checksum"]) + 1e-6
+    pre, fts = seeded_state_dicts(O.recformer_param_shapes(cfg), fx["key_order"], fx["pretrain_seed"], fx["pretrain_std"], fx["pretrain_checksum"],
+                                  fx["finetune_seeds"], fx["finetune_std"], fx["finetune_checksum"])
     g = torch.Generator().manual_seed(fx["data_seed"])
     B, L = fx["batch"]
     torch.randint(3, L + 1, (B,), generator=g)            # (the generator's stream: lengths, ids, items, teachers)
@@ -519,6 +519,16 @@ def g20_inputs():
     assert abs(float(sum(x.double().sum() for x in items)) - fx["item_checksum"]) < 1e-6 * abs(fx["item_checksum"]) + 1e-6
     assert abs(float(sum(x.double().sum() for x in teachers)) - fx["teacher_checksum"]) < 1e-6 * abs(fx["teacher_checksum"]) + 1e-6
     return fx, pre, fts, items, teachers
+
+
+register_prefetch("g20", _build_g20, match=("test_train_gpu.py", "recformer_large"))
+
+
+@pytest.fixture(scope="module")
+def g20_inputs():
+    """built ONCE for the four tests that use them (two reference cases, two 8-domain property cases), in the background while earlier
+    modules run (tests/_prefetch.py)"""
+    return prefetched("g20")
 
 
 def _g20_step(g20_inputs, case, copies, per_weight):
