@@ -23,7 +23,7 @@ def prefetched(name):
 
 
 def start_prefetch(session):
-    if os.environ.get("MERGEREC_PREFETCH", "1") != "1" or not _PREFETCH:
+    if os.environ.get("MERGEREC_PREFETCH", "1") != "1" or not _PREFETCH or session.config.getoption("collectonly", False):
         return
     heavy_off = os.environ.get("MERGEREC_HEAVY_TESTS", "") == "0"
     order = []
@@ -61,3 +61,10 @@ def seeded_state_dicts(shapes, key_order, seed_pre, std_pre, pre_checksum, ft_se
     if ft_checksum is not None:
         assert abs(fsum(fts) - ft_checksum) < 1e-6 * abs(ft_checksum) + 1e-6
     return pre, fts
+
+
+def stop_prefetch(session):
+    """session end: builders that have not started are dropped (a run that stopped early must not keep drawing gigabytes nobody reads)"""
+    pool = getattr(session.config, "_mergerec_prefetch_pool", None)
+    if pool is not None:
+        pool.shutdown(wait=False, cancel_futures=True)

@@ -46,11 +46,15 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
 
 # ---- background regeneration of the seed-defined inputs of the real-dimension checks: tests/_prefetch.py (ONE module object, whichever
 # name this file is imported under -- pytest loads it as `conftest`, the test modules as `tests.conftest`)
-from tests._prefetch import prefetched, register_prefetch, seeded_state_dicts, start_prefetch  # noqa: E402,F401
+from tests._prefetch import prefetched, register_prefetch, seeded_state_dicts, start_prefetch, stop_prefetch  # noqa: E402,F401
 
 
 def pytest_collection_finish(session):
     start_prefetch(session)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    stop_prefetch(session)
 
 
 @pytest.fixture(scope="session")
