@@ -37,6 +37,9 @@ def init_from_env(verbose: bool = True) -> Tuple[int, int]:
         return world()
     local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
     backend = os.environ.get("MERGEREC_DIST_BACKEND", "nccl")
+    # RCCL's (and torch's) cross-process buffer sharing needs dmabuf IPC on this driver stack; the runtime reads the variable when it
+    # initialises, which nothing has done yet (device_count() below does not): a launcher that did not export it still gets a working group
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = torch.cuda.device_count()
     if backend == "nccl" and ws > ndev and int(os.environ.get("LOCAL_WORLD_SIZE", ws)) > ndev:
         raise SystemExit(f"{ws} ranks need {ws} GPUs, {ndev} visible (set MERGEREC_DIST_BACKEND=gloo to share GPUs in a rehearsal)")
