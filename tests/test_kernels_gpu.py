@@ -110,9 +110,11 @@ def test_gemm_segments_gelu_residual(ops):
     assert torch.allclose(got, want, atol=2e-6, rtol=1e-6)
 
 
-@pytest.mark.parametrize("M,N,K", [(130, 768, 768), (257, 200, 3072), (64, 333, 16)])
+@pytest.mark.parametrize("M,N,K", [(130, 768, 768), (257, 200, 3072), (64, 333, 16), (300, 896, 64), (6656, 2560, 32)])
 def test_gemm_bf16x6_split_precision(ops, M, N, K):
-    """6 bf16 products per fp32 product: fp32-grade accuracy (not bit-exact); weights addressed inside split arenas."""
+    """6 bf16 products per fp32 product: fp32-grade accuracy (not bit-exact); weights addressed inside split arenas.  The last two shapes
+    put a narrower last group into the kernel's column-group tile order: 7 narrow column tiles = groups of 6 + 1, and (52 row tiles x 10
+    wide column tiles >= 512 workgroups: the 128 x 256 tile kernel) groups of 3 + 3 + 3 + 1."""
     g = _g(M * 3 + N + K)
     A, b = torch.randn(M, K, generator=g), torch.randn(N, generator=g)
     arena = torch.zeros(64 * 5 + N * K + 64)  # the matrix sits at a non-zero, 64-aligned offset of a bigger arena
