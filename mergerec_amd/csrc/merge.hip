@@ -4,6 +4,7 @@
 // Arithmetic contract (bit-exact with torch CPU, see include/mergerec_hip.h): products are rounded
 // separately (no FMA contraction), summed sequentially from 0 in task order, then added to base.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -192,6 +193,55 @@ __global__ __launch_bounds__(kThreads) void merge_bwd_stage1(const float* __rest
     }
 }
 
+// The same sums for N <= 8 with every stream of a chunk in flight at once: one pass over the chunk, g read once, N running sums per thread
+// (each the SAME fmaf chain over the same elements in the same order as the loop above, and the same wave / workgroup combine -- results are
+// bit-identical), one barrier instead of 2 N.  The per-vector loop above leaves only four 16-byte loads per thread in flight between barriers:
+// 4.1 TB/s at N = 8 against the forward merge's 5.3 TB/s over the same streams.
+template <int NN>
+__global__ __launch_bounds__(kThreads) void merge_bwd_stage1_n(const float* __restrict__ tv, int64_t tv_stride, const float* __restrict__ g,
+                                                              const int64_t* __restrict__ seg_off, int S, int64_t P,
+                                                              const int64_t* __restrict__ chunk_first, float* __restrict__ partial) {
+    const int64_t c = blockIdx.x;
+    int lo = 0, hi = S - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (chunk_first[mid] <= c) lo = mid; else hi = mid - 1;
+    }
+    const int s = lo;
+    const int64_t seg_b = seg_off ? seg_off[s] : 0, seg_e = seg_off ? seg_off[s + 1] : P;
+    const int64_t b = seg_b + (c - chunk_first[s]) * kBwdChunk;
+    int64_t e = b + kBwdChunk;
+    if (e > seg_e) e = seg_e;
+    __shared__ float red[NN][kThreads / MR_WAVE];
+    float acc[NN];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int it = 0; it < kBwdChunk / (kThreads * 4); ++it) {
+        const int64_t p = b + (int64_t)threadIdx.x * 4 + (int64_t)it * kThreads * 4;
+        if (p < e) {
+            const float4 y = ld4(g + p);
+            float4 x[NN];
+#pragma unroll
+            for (int i = 0; i < NN; ++i) x[i] = ld4(tv + (int64_t)i * tv_stride + p);
+#pragma unroll
+            for (int i = 0; i < NN; ++i) {
+                acc[i] = fmaf(x[i].x, y.x, acc[i]);
+                acc[i] = fmaf(x[i].y, y.y, acc[i]);
+                acc[i] = fmaf(x[i].z, y.z, acc[i]);
+                acc[i] = fmaf(x[i].w, y.w, acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NN; ++i) {
+        const float w = mr::wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < NN) partial[c * NN + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
 __global__ void merge_bwd_prologue(const int64_t* __restrict__ seg_off, int S, int64_t P,
                                    int64_t* __restrict__ chunk_first) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -339,7 +389,21 @@ extern "C" int mr_merge_bwd_alpha_f32(const float* tv, int64_t tv_stride, const 
     const int64_t nchunk = host_chunk_upper_bound(S, P);  // grid upper bound; surplus blocks map to the last segment's empty tail
     hipLaunchKernelGGL(merge_bwd_prologue, dim3(1), dim3(64), 0, st, seg_off, S, P, chunk_first);
     // exact chunk count is only known on device; launch the upper bound and let surplus blocks write zeros
-    hipLaunchKernelGGL(merge_bwd_stage1, dim3((unsigned)nchunk), dim3(kThreads), 0, st, tv, tv_stride, g, seg_off, N, S, P, chunk_first, partial);
+#define MR_BWD1(NN_) hipLaunchKernelGGL(merge_bwd_stage1_n<NN_>, dim3((unsigned)nchunk), dim3(kThreads), 0, st, tv, tv_stride, g, seg_off, S, P, chunk_first, partial)
+    const char* generic = getenv("MR_MERGE_BWD_GENERIC");  // A/B and the bit-identity test: the per-vector loop for every N (read per call)
+    switch ((generic && generic[0] == '1') ? 0 : N) {
+        case 1: MR_BWD1(1); break;
+        case 2: MR_BWD1(2); break;
+        case 3: MR_BWD1(3); break;
+        case 4: MR_BWD1(4); break;
+        case 5: MR_BWD1(5); break;
+        case 6: MR_BWD1(6); break;
+        case 7: MR_BWD1(7); break;
+        case 8: MR_BWD1(8); break;
+        default:
+            hipLaunchKernelGGL(merge_bwd_stage1, dim3((unsigned)nchunk), dim3(kThreads), 0, st, tv, tv_stride, g, seg_off, N, S, P, chunk_first, partial);
+    }
+#undef MR_BWD1
     hipLaunchKernelGGL(merge_bwd_stage2, dim3((unsigned)(S * N)), dim3(MR_WAVE), 0, st, partial, chunk_first, N, dalpha);
     return mr::check_launch();
 }

@@ -80,6 +80,19 @@ def test_merge_bwd_alpha(ops):
         assert torch.allclose(got[s], want, rtol=1e-4, atol=1e-2 * math.sqrt((b - a) / 1e6)), (got[s], want)
     one = ops.merge_bwd_alpha(tv.to(DEV), gr.to(DEV)).cpu()
     assert torch.allclose(one[0], O.merge_bwd_alpha(tv, gr), rtol=1e-4, atol=2e-2)
+    # the single-pass kernel (N <= 8: every stream of a chunk in flight at once) keeps each sum's operation order: equal, bit for bit, to
+    # the per-vector loop that larger N still use -- for every N, with segments whose last chunk is ragged and shorter than a chunk
+    import os
+
+    for n in (1, 2, 3, 5, 8):
+        tvn = torch.randn(n, P, generator=g).to(DEV)
+        fast = ops.merge_bwd_alpha(tvn, gr.to(DEV), seg_off.to(DEV)).cpu()
+        os.environ["MR_MERGE_BWD_GENERIC"] = "1"
+        try:
+            slow = ops.merge_bwd_alpha(tvn, gr.to(DEV), seg_off.to(DEV)).cpu()
+        finally:
+            del os.environ["MR_MERGE_BWD_GENERIC"]
+        assert torch.equal(fast, slow), n
 
 
 # ------------------------------------------------------------------ K3 GEMM (bit-exact vs k-ordered fmaf chain)
