@@ -44,6 +44,18 @@ def test_backward_kernels_match_torch():
     dx = ops.layernorm_bwd(xx.detach().to(DEV), dy.to(DEV), gam.detach().to(DEV), 1e-5, dg, db).cpu()
     assert torch.allclose(dx, xx.grad, atol=2e-5, rtol=1e-4)
     assert torch.allclose(dg.cpu(), gam.grad, atol=2e-4, rtol=1e-4) and torch.allclose(db.cpu(), bet.grad, atol=2e-4, rtol=1e-4)
+    # hidden sizes that are whole multiples of 256 take the register-resident rows kernel (each element read once, 16-byte loads);
+    # 18,000 rows = 71 row chunks through the eight-lane chunk combine
+    for d, T in ((768, 300), (1024, 257), (256, 18000), (512, 40)):
+        xx = (torch.randn(T, d, generator=g) * 3 + 1).requires_grad_(True)
+        gam, bet = torch.randn(d, generator=g).requires_grad_(True), torch.randn(d, generator=g).requires_grad_(True)
+        dy = torch.randn(T, d, generator=g)
+        torch.nn.functional.layer_norm(xx, (d,), gam, bet, 1e-5).backward(dy)
+        dg, db = torch.empty(d, device=DEV), torch.empty(d, device=DEV)
+        dx = ops.layernorm_bwd(xx.detach().to(DEV), dy.to(DEV), gam.detach().to(DEV), 1e-5, dg, db).cpu()
+        assert torch.allclose(dx, xx.grad, atol=3e-5, rtol=1e-4), (d, T)
+        tol = 2e-4 * max(1.0, (T / 777) ** 0.5)
+        assert torch.allclose(dg.cpu(), gam.grad, atol=tol, rtol=1e-4) and torch.allclose(db.cpu(), bet.grad, atol=tol, rtol=1e-4), (d, T)
     # scatter-add with repeated rows
     tab = torch.zeros(10, 64, device=DEV)
     idx = torch.tensor([3, 3, 9, 0, 3], dtype=torch.int32)
