@@ -41,6 +41,32 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const float* __rest
     }
 }
 
+// the same on 64 x 64 tiles with 16-byte global accesses on both sides (C, ldi, ldo, R_pad multiples of 4, 16-byte aligned bases): a
+// thread loads four float4 of the tile's rows, scatters them into a 65-float-pitch LDS tile, gathers four elements of an LDS column
+// (conflict-free both ways) and stores them as one float4 of an output row.  The 32 x 32 form above moves 4 bytes per lane and access.
+__global__ __launch_bounds__(kThreads) void transpose_vec_kernel(const float* __restrict__ in, int64_t ldi, int R, int C,
+                                                                float* __restrict__ out, int64_t ldo, int R_pad) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 float4 columns x 16 rows per pass
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 16 * k, c = c0 + 4 * tx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R && c < C) v = *reinterpret_cast<const float4*>(in + (int64_t)r * ldi + c);
+        float* t = &tile[ty + 16 * k][4 * tx];
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 16 * k, r = r0 + 4 * tx;
+        if (c < C && r < R_pad)
+            *reinterpret_cast<float4*>(out + (int64_t)c * ldo + r) =
+                make_float4(tile[4 * tx][ty + 16 * k], tile[4 * tx + 1][ty + 16 * k], tile[4 * tx + 2][ty + 16 * k], tile[4 * tx + 3][ty + 16 * k]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ column sums
 // out[c] = sum_r x[r][c].  Workgroup = 32 columns x 8 row lanes over one chunk of kRowsPerChunk rows (rows r = lane, lane + 8, ...),
 // partials combined in a fixed order through LDS.  Tall matrices (token-sized: fine-tuning batches) are cut into row chunks whose
@@ -371,6 +397,11 @@ __global__ __launch_bounds__(kThreads) void scatter_add_rows_kernel(const float*
 extern "C" int mr_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int64_t ldo, int R_pad, mr_stream_t stream) {
     if (!in || !out || R < 0 || C < 0 || R_pad < R || ldi < C || ldo < R_pad) return MR_EINVAL;
     if (R_pad == 0 || C == 0) return MR_OK;
+    if (!((C | R_pad) & 3) && !((ldi | ldo) & 3) && mr::aligned16(in) && mr::aligned16(out)) {
+        const dim3 grid((C + 63) / 64, (R_pad + 63) / 64);
+        hipLaunchKernelGGL(transpose_vec_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, in, ldi, R, C, out, ldo, R_pad);
+        return mr::check_launch();
+    }
     const dim3 grid((C + 31) / 32, (R_pad + 31) / 32);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, in, ldi, R, C, out, ldo, R_pad);
     return mr::check_launch();

@@ -19,6 +19,15 @@ def test_backward_kernels_match_torch():
     x = torch.randn(37, 100, generator=g)
     t = ops.transpose_pad(x.to(DEV)).cpu()
     assert t.shape == (100, 48) and torch.equal(t[:, :37], x.T) and torch.count_nonzero(t[:, 37:]) == 0
+    # 64 x 64 float4 tiles when the widths allow 16-byte accesses, the 32 x 32 scalar form otherwise; output into a column slice
+    for R, C, pad in ((1000, 768, 32), (602, 3072, 16), (37, 99, 16), (130, 4, 16), (5, 260, 32)):
+        xr = torch.randn(R, C, generator=g)
+        got = ops.transpose_pad(xr.to(DEV), pad=pad).cpu()
+        Rp = (R + pad - 1) // pad * pad
+        assert got.shape == (C, Rp) and torch.equal(got[:, :R], xr[:, :C].T) and torch.count_nonzero(got[:, R:]) == 0, (R, C)
+        wide = torch.full((C, Rp + 8), 7.0, device=DEV)
+        ops.transpose_pad(xr.to(DEV), out=wide[:, :Rp], pad=pad)
+        assert torch.equal(wide[:, :R].cpu(), xr[:, :C].T) and bool((wide[:, Rp:] == 7.0).all()), (R, C)
     assert torch.allclose(ops.colsum(x.to(DEV)).cpu(), x.sum(0), atol=1e-5)
     u, dh = torch.randn(50, 64, generator=g) * 2, torch.randn(50, 64, generator=g)
     uu = u.clone().requires_grad_(True)
