@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if pat in r["Kernel_Name"] and r["Counter_Name"] == c:
                 name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-                key = (name[name.index(pat):].split("(")[0], r["Grid_Size"] if "Grid_Size" in r else "")
+                key = (name.split("(")[0].strip() or name[:60], r["Grid_Size"] if "Grid_Size" in r else "")
                 res[key][c].append(float(r["Counter_Value"]))
 for key, d in sorted(res.items()):
     f, w = d.get("FETCH_SIZE", [0]), d.get("WRITE_SIZE", [0])
