@@ -7,9 +7,12 @@ from mergerec_amd import ops
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 602
 Tp = (T + 15) // 16 * 16
 dev = torch.device("cuda:0")
-shapes = [("fwd q/k/v/out", T, 768, 768), ("fwd up", T, 3072, 768), ("fwd down", T, 768, 3072), ("dgrad qkv", T, 768, 2304),
-          ("dgrad up", T, 768, 3072), ("dgrad down", T, 3072, 768), ("wgrad 768x768", 768, 768, Tp), ("wgrad up", 3072, 768, Tp),
-          ("wgrad down", 768, 3072, Tp)]
+import os
+
+H = int(os.environ.get("SW_HIDDEN", 768))  # SW_HIDDEN=1024: the large models' shapes
+shapes = [("fwd q/k/v/out", T, H, H), ("fwd up", T, 4 * H, H), ("fwd down", T, H, 4 * H), ("dgrad qkv", T, H, 3 * H),
+          ("dgrad up", T, H, 4 * H), ("dgrad down", T, 4 * H, H), ("wgrad d x d", H, H, Tp), ("wgrad up", 4 * H, H, Tp),
+          ("wgrad down", H, 4 * H, Tp)]
 
 
 def timed(fn, n=30):
@@ -29,9 +32,9 @@ for name, M, N, K in ([] if (len(sys.argv) > 2 and sys.argv[2] == "bf16x3") else
     A, W = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
     out = torch.empty(M, N, device=dev)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    auto = max(1, min(K // 16, 16, 512 // max(tiles, 1)))
+    auto = ops.splitk_plan(M, N, K, False)
     res = {}
-    for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+    for s in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 24, 32):
         if s > K // 16:
             continue
         res[s] = timed(lambda: ops.gemm_nt_train(A, W, out=out, splits=s))
