@@ -101,6 +101,10 @@ def test_split_plan_of_the_training_product_is_a_pure_function_of_the_shape():
     shapes = [(T, 768, 768, False), (T, 3072, 768, False), (T, 768, 3072, True), (T, 768, 2304, True), (T, 768, 3072, True),
               (T, 3072, 768, False), (768, 768, Tp, False), (3072, 768, Tp, False), (768, 3072, Tp, False)]
     assert [splitk_plan(*s) for s in shapes] == [8, 1, 8, 8, 8, 1, 7, 3, 3]
+    # the 1,024-wide models' shapes were not used for the fit; the sweep (SW_HIDDEN=1024) measured exactly these as the optima
+    T, Tp, H = 603, 608, 1024
+    large = [(T, H, H), (T, 4 * H, H), (T, H, 4 * H), (T, H, 3 * H), (T, H, 4 * H), (T, 4 * H, H), (H, H, Tp), (4 * H, H, Tp), (H, 4 * H, Tp)]
+    assert [splitk_plan(*s) for s in large] == [6, 3, 6, 6, 6, 3, 4, 1, 1]
     for M in (1, 16, 130, 602, 5000, 70000):
         for N in (64, 768, 3072):
             for K in (16, 64, 768, 3072):
