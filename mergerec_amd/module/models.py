@@ -4,9 +4,11 @@ encoder/blair.py, encoder/recformer/interface.py): ``ModelType[NAME].value(...)`
 ``'model.<hf-key>'``.  The arithmetic of transformers' RobertaModel / the reference's RecformerModel is
 re-implemented as HIP kernels (mergerec_amd/engine.py); weights live in one device arena.
 
-No network: pretrained weights come from a LOCAL file (``model_name_or_path`` = a torch-saved state_dict,
-with or without the 'model.' prefix) or are randomly initialised when ``model_kwargs['init_seed']`` is
-given (synthetic benchmarks).  Hub names fail loudly.
+No network: pretrained weights come from a LOCAL source, as ``from_pretrained`` accepts one upstream (models/_base.py:56-58):
+``model_name_or_path`` = a Hugging Face snapshot DIRECTORY (``config.json`` + ``model.safetensors`` / ``pytorch_model.bin``, sharded or
+not), a bare ``.safetensors`` file or a torch-saved state_dict, with or without the ``roberta.`` / ``model.`` prefixes
+(mergerec_amd/checkpoint.py) -- or are randomly initialised when ``model_kwargs['init_seed']`` is given (synthetic benchmarks).  A snapshot's
+``config.json`` decides the architecture, as it does upstream.  Hub names fail loudly.
 """
 from __future__ import annotations
 
@@ -47,6 +49,21 @@ class BaseEncoderModel(nn.Module):
         self.model_name_or_path = model_name_or_path
         self.pooling_method = pooling_method
         spec = self.SPEC()
+        ckpt_path = model_kwargs.pop("ckpt_path", None)  # Recformer (interface.py:38-41)
+        # the architecture: the wrapper class's family, then the snapshot's config.json (AutoModel.from_pretrained /
+        # RecformerConfig.from_pretrained(model_path), interface.py:17-25: the file decides), then explicit overrides
+        pretrained_sd, cfg_json = None, None
+        if model_name_or_path is not None and os.path.exists(str(model_name_or_path)):
+            from .. import checkpoint
+
+            if os.path.isdir(str(model_name_or_path)):
+                cfg_json = checkpoint.read_config(str(model_name_or_path))
+                if cfg_json is not None:
+                    checkpoint.apply_config(spec, cfg_json, str(model_name_or_path))
+                elif ckpt_path is None:
+                    raise FileNotFoundError(f"{model_name_or_path}: a snapshot directory needs a config.json")
+            if ckpt_path is None:  # Recformer takes only the CONFIG from model_name_or_path; its weights are ckpt_path (interface.py:56-62)
+                pretrained_sd = checkpoint.normalize_keys(checkpoint.read_model_source(str(model_name_or_path))[0], spec.kind)
         overrides = dict(model_kwargs.pop("spec_overrides", {}))
         for k in [k for k in model_kwargs if k.startswith("spec.")]:  # CLI form: --model_kwargs spec.layers 2 spec.hidden 128 ...
             overrides[k[len("spec."):]] = model_kwargs.pop(k)
@@ -63,14 +80,14 @@ class BaseEncoderModel(nn.Module):
         self._weights = WeightSet(self.layout, self._flat, self.gemm_mode)
         self._views: Dict[str, torch.Tensor] = self._weights.views
         self.tokenizer = self._load_tokenizer(tokenizer_name_or_path, tokenizer_kwargs or {})
-        ckpt_path = model_kwargs.pop("ckpt_path", None)  # Recformer (interface.py:38-41)
         init_seed = model_kwargs.pop("init_seed", None)
         # HF config overrides the reference forwards to from_pretrained.  Dropout never changes inference; the training graph
         # (merge_train / finetune_train under train()) applies it at HF's sites with HF's default rates (RobertaConfig / LongformerConfig:
         # hidden_dropout_prob = attention_probs_dropout_prob = 0.1), mask = the counter-based function of csrc/dropout.h keyed by
         # (dropout_seed, training-forward counter)
-        self.hidden_dropout_prob = float(model_kwargs.pop("hidden_dropout_prob", 0.1))
-        self.attention_probs_dropout_prob = float(model_kwargs.pop("attention_probs_dropout_prob", 0.1))
+        hf = cfg_json or {}  # a snapshot's config.json carries the rates from_pretrained would use; model_kwargs override them as upstream
+        self.hidden_dropout_prob = float(model_kwargs.pop("hidden_dropout_prob", hf.get("hidden_dropout_prob", 0.1)))
+        self.attention_probs_dropout_prob = float(model_kwargs.pop("attention_probs_dropout_prob", hf.get("attention_probs_dropout_prob", 0.1)))
         self.dropout_seed = int(model_kwargs.pop("dropout_seed", 0))
         self._dropout_step = 0
         for rate in (self.hidden_dropout_prob, self.attention_probs_dropout_prob):
@@ -79,17 +96,31 @@ class BaseEncoderModel(nn.Module):
         model_kwargs.pop("classifier_dropout", None)  # no classifier head on this path
         if model_kwargs:
             print(f"note: model_kwargs {sorted(model_kwargs)} are not used by the HIP encoder")
-        src = ckpt_path or model_name_or_path
-        if src is not None and os.path.isfile(str(src)):
-            sd = torch.load(str(src), map_location="cpu")
-            sd = {(k if k.startswith("model.") else "model." + k): v for k, v in sd.items()}
-            self.load_state_dict(sd, strict=ckpt_path is None)
+        if ckpt_path is not None and os.path.exists(str(ckpt_path)):
+            from .. import checkpoint
+
+            # interface.py:61-62: ``self.model.load_state_dict(torch.load(ckpt_path), strict=False)`` and print the key report
+            sd = checkpoint.normalize_keys(checkpoint.read_model_source(str(ckpt_path))[0], spec.kind)
+            print("Loading model state from checkpoint:", ckpt_path)
+            missing, unexpected = self.load_state_dict(sd, strict=False)
+            print(f"<missing keys: {missing}, unexpected keys: {unexpected}>")
+        elif pretrained_sd is not None:
+            # AutoModel.from_pretrained: heads were dropped by normalize_keys; an encoder tensor the file lacks, or carries in
+            # another shape, is an error here (upstream would initialise it randomly and warn -- never what a user of this path wants)
+            missing, unexpected = self.load_state_dict(pretrained_sd, strict=False)
+            pooler = [k for k in missing if k.startswith("model.pooler.")]  # a snapshot saved with add_pooling_layer=False
+            missing = [k for k in missing if k not in pooler]
+            if missing:
+                raise RuntimeError(f"{model_name_or_path}: the checkpoint lacks encoder tensors {missing[:4]}{' ...' if len(missing) > 4 else ''}")
+            if unexpected:
+                print(f"note: {len(unexpected)} tensors of {model_name_or_path} are not part of the encoder and were ignored: {unexpected[:4]}")
         elif init_seed is not None:
             self.load_state_dict(random_init_state_dict(spec, int(init_seed)))
         else:
             raise FileNotFoundError(
-                f"pretrained weights '{src}' are not a local file and the container is offline; pass a local state_dict "
-                "path or model_kwargs={'init_seed': <int>} for synthetic weights"
+                f"pretrained weights '{ckpt_path or model_name_or_path}' are not a local snapshot directory / .safetensors / state_dict "
+                "file and the container is offline (hub names cannot be fetched); pass a local path or "
+                "model_kwargs={'init_seed': <int>} for synthetic weights"
             )
 
     @staticmethod

@@ -672,6 +672,87 @@ def random_state_dict(shapes, seed: int, std: float = 0.02) -> StateDict:
     return sd
 
 
+# Per-layer query / key gains of the trained-like statistics below, CALIBRATED ONCE in the build container (oracle/calibrate_trained_like.py:
+# one sequential pass over a 16-sequence batch, each layer's gain chosen so its pre-softmax logits have sigma = 4) and frozen here as
+# constants: the weights are a pure function of (shapes, seed, these numbers), never of a forward pass, so they regenerate bit for bit
+# on any host.
+TRAINED_LIKE_QK_GAIN = {
+    "roberta-base": (0.997, 1.021, 1.103, 0.909, 0.706, 0.685, 0.902, 0.742, 0.64, 1.3, 0.886, 0.965),
+    "recformer-base": (0.99, 1.315, 0.866, 0.448, 1.127, 0.88, 1.131, 0.864, 0.913, 0.72, 0.7, 0.811),
+}
+
+
+def trained_like_state_dict(shapes, seed: int, cfg: "EncoderConfig", qk_layer_gain: Sequence[float], *, word_std: float = 0.06,
+                            qk_gain: float = 3.0, head_sigma: float = 0.35, vo_gain: float = 4.0, ffn_gain: float = 1.5, n_outlier: int = 3,
+                            outlier_gain: float = 5.0, massive: float = 20.0, last_damp: float = 0.1) -> StateDict:
+    """Weights with the statistics of a TRAINED encoder instead of HF's init (fixture g22; VERDICT r03 'Missing #2'): what a fine-tuned
+    checkpoint (merge_test.py:21-34) stresses and N(0, 0.02^2) never does.
+
+    * query / key projections ``qk_gain`` x wider with a log-normal per-head sharpness and the calibrated per-layer gain: pre-softmax
+      logits with sigma ~ 4 and a heavy tail (|max| 20-45, kurtosis 3-14) -- peaky softmax rows, the online-softmax rescale path taken,
+      product errors amplified by exp();
+    * LayerNorm gamma log-normal (sigma 0.3) with ``n_outlier`` persistent outlier dimensions (x ``outlier_gain``, their beta ~ N(0, 1))
+      shared by every LayerNorm, like RoBERTa's dimensions 77 / 588; beta ~ N(0, 0.05^2) elsewhere;
+    * three 'massive-activation' hidden dimensions fed by the FFN output bias (+-``massive``, log-normal);
+    * the columns of W_q / W_k that read those six dimensions shrunk by 2 / outlier_gain (a trained model's logits stay finite there);
+    * word-embedding rows with log-normal norms (sigma 0.5); value / attention-output projections ``vo_gain`` x wider so a token's
+      context outweighs its residual: CLS vectors become content-dependent and cosines spread over ~0.2-0.96 instead of crowding 1.0;
+    * the last layer's two LayerNorms carry the outlier / massive dimensions at gamma x ``last_damp`` with no outlier beta (contrastive
+      fine-tuning flattens uninformative directions of the embedding that is scored).
+    """
+    g = torch.Generator().manual_seed(seed)
+    d, H = cfg.hidden, cfg.heads
+    dh = d // H
+    perm = torch.randperm(d, generator=g)
+    out_dims, mass_dims = perm[:n_outlier], perm[n_outlier:n_outlier + 3]
+    hot = torch.cat([out_dims, mass_dims])
+    last_tag = f"encoder.layer.{cfg.layers - 1}."
+    sd = OrderedDict()
+    for k, shp in shapes.items():
+        last = last_tag in k
+        if k.endswith("position_ids"):
+            sd[k] = torch.arange(shp[-1], dtype=torch.int64).expand(shp).clone()
+        elif "LayerNorm.weight" in k:
+            w = torch.exp(0.3 * torch.randn(shp, generator=g))
+            spread = torch.exp(0.3 * torch.randn(n_outlier, generator=g))
+            if last:
+                w[hot] *= last_damp
+            else:
+                w[out_dims] *= outlier_gain * spread
+            sd[k] = w
+        elif "LayerNorm.bias" in k:
+            b = 0.05 * torch.randn(shp, generator=g)
+            ob = torch.randn(n_outlier, generator=g)
+            if not last:
+                b[out_dims] += ob
+            sd[k] = b
+        elif "word_embeddings" in k:
+            rows = torch.exp(0.5 * torch.randn(shp[0], 1, generator=g))
+            sd[k] = word_std * rows * torch.randn(shp, generator=g)
+        elif "embeddings.weight" in k:  # position / token-type / item-position tables
+            sd[k] = 0.02 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            b = 0.02 * torch.randn(shp, generator=g)
+            if ".output.dense.bias" in k and "attention" not in k:
+                b[mass_dims] += massive * torch.sign(torch.randn(3, generator=g)) * torch.exp(0.3 * torch.randn(3, generator=g))
+            if ".query" in k or ".key" in k:  # covers query_global / key_global
+                b = b * qk_layer_gain[int(k.split("encoder.layer.")[1].split(".")[0])]
+            sd[k] = b
+        else:
+            w = 0.02 * torch.randn(shp, generator=g)
+            if ".query" in k or ".key" in k:
+                layer = int(k.split("encoder.layer.")[1].split(".")[0])
+                hg = qk_gain * qk_layer_gain[layer] * torch.exp(head_sigma * torch.randn(H, generator=g))
+                w = (w.view(H, dh, d) * hg[:, None, None]).reshape(shp).clone()
+                w[:, hot] *= 2.0 / outlier_gain
+            elif ".value" in k or "attention.output.dense.weight" in k:
+                w = w * vo_gain
+            elif "intermediate.dense.weight" in k or "output.dense.weight" in k:
+                w = w * ffn_gain
+            sd[k] = w
+    return sd
+
+
 def perturbed_state_dict(base: StateDict, seed: int, std: float = 1e-3) -> StateDict:
     """A synthetic 'fine-tuned' checkpoint: theta_i = theta_pre + tau_i, tau ~ N(0, std^2)."""
     g = torch.Generator().manual_seed(seed)
