@@ -29,9 +29,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dq, h.size() * 4)); CK(hipMalloc(&dc, (size_t)T * H * 64 * 4)); CK(hipMalloc(&dcu, (B + 1) * 4)); CK(hipMalloc(&dw, work.size() * 4));
     CK(hipMemcpy(dq, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dcu, cu.data(), (B + 1) * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dw, work.data(), work.size() * 4, hipMemcpyHostToDevice));
-    for (int rep = 0; rep < 3; ++rep) if (mr_attn_split_work_f32(dq, dcu, dw, ns, H, 64, 0.125f, -1, 3, dc, 0)) { printf("rc\n"); return 1; }
+    for (int rep = 0; rep < 3; ++rep) if (mr_attn_split_work_f32(dq, dcu, dw, ns, B, 256, H, 64, 0.125f, -1, 3, dc, 0)) { printf("rc\n"); return 1; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    CK(hipEventRecord(e0, 0)); mr_attn_split_work_f32(dq, dcu, dw, ns, H, 64, 0.125f, -1, 3, dc, 0); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    CK(hipEventRecord(e0, 0)); mr_attn_split_work_f32(dq, dcu, dw, ns, B, 256, H, 64, 0.125f, -1, 3, dc, 0); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const int nwg = (int)(ns * 8 * H), n = nwg < 65536 ? nwg : 65536;
     std::vector<unsigned long long> ph((size_t)65536 * 8), rt((size_t)65536 * 4);

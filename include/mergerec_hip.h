@@ -39,6 +39,12 @@ extern "C" {
 
 #define MR_ACT_NONE 0
 #define MR_ACT_GELU_ERF 1
+/* `products` of the split-precision entry points: 3 = two bf16 pieces per operand (hi*hi + hi*lo + lo*hi, ~2^-16 per product), 6 = three
+ * bf16 pieces (six products, ~2^-24), MR_PRODUCTS_F16X3 = two FP16 pieces per operand and the same three products (~2^-21 per product at
+ * the cost of bf16x3; operands must stay inside fp16's range: |x| < 65504, weights |w| < 255.9 -- see mr_split_weights_kblock_f16_f32). */
+#define MR_PRODUCTS_BF16X3 3
+#define MR_PRODUCTS_BF16X6 6
+#define MR_PRODUCTS_F16X3 35
 
 #define MR_EMBED_ROBERTA 0   /* LN((word + type) + pos)            -- transformers RobertaEmbeddings */
 #define MR_EMBED_RECFORMER 1 /* LN(((word + pos) + type) + itempos) -- recformer/models.py:130-133   */
@@ -217,6 +223,13 @@ int mr_split_bf16x3_f32(const float* x, int64_t n, uint16_t* hi, uint16_t* mid, 
  * lo may be NULL: only the hi / mid pieces are written (all the "products = 3" GEMMs read). */
 int mr_split_weights_kblock_f32(const float* arena, const int64_t* table, const int64_t* unit_prefix, int n_mat,
                                 int64_t total_units, uint16_t* hi, uint16_t* mid, uint16_t* lo, mr_stream_t stream);
+/* The FP16 pieces of the same matrices for products = MR_PRODUCTS_F16X3: hi = fp16(256 w), lo = fp16(256 w - hi) in the same k-blocked
+ * layout (the 2^8 scale is exact, keeps the low piece of ordinary 0.01..0.1 weights a normal fp16 number, and is undone in the GEMM
+ * epilogue).  overflow (device int32, may be NULL; set to 1, never cleared): a scaled weight left fp16's range (|w| >= 255.9) or is NaN --
+ * the caller must then use the bf16 pieces.  Same reference lines as mr_split_weights_kblock_f32 (no counterpart upstream: the pieces are
+ * a derived form of the merged parameters of merger/weight_learning/utils.py:29-40). */
+int mr_split_weights_kblock_f16_f32(const float* arena, const int64_t* table, const int64_t* unit_prefix, int n_mat, int64_t total_units,
+                                    uint16_t* hi, uint16_t* lo, int32_t* overflow, mr_stream_t stream);
 
 /* out[t,:] = LayerNorm(x[t,:]) * gamma + beta   (x already holds dense(...) + residual).
  * replaces: the LayerNorm of transformers RobertaSelfOutput / RobertaOutput (post-LN blocks). */
@@ -252,14 +265,18 @@ int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t
  *   queue and the query blocks of one (sequence, head) -- which read the same K / V rows -- share one L2.
  * mr_attn_work_plan (HOST memory in and out, no GPU work) builds that list from the B sequence lengths: sequences by decreasing length,
  * dealt over the 8 queues in snake order.  It returns n_slots; with work == NULL or capacity < n_slots * 8 nothing is written (size query).
+ * An entry holds a BLOCK index, so a list only means something for the block height it was planned with: every work-list entry point takes
+ * the (B, q_rows) the list was planned for and returns MR_EINVAL unless q_rows is its kernel's block height (mr_attn_split_q_rows(window,
+ * products) here, 128 for mr_attn_work_f32 / mr_attn_bwd_work_f32); entries naming a sequence >= B are skipped by the kernel (cu_seqlens
+ * has B + 1 entries and is never read past them).
  * replaces: the same reference code as mr_attn_f32 (transformers RobertaSelfAttention / LongformerSelfAttention). */
 int mr_attn_split_q_rows(int window, int products);
 /* mr_attn_f32 (exact fp32) on the same kind of work list (q_rows = 128); drop_p > 0: the training-graph dropout of mr_attn_train_f32. */
-int mr_attn_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale, int window,
-                     float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream);
+int mr_attn_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int B, int q_rows, int H, int dh, float scale,
+                     int window, float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream);
 int64_t mr_attn_work_plan(const int64_t* lens_host, int B, int q_rows, int32_t* work_host, int64_t capacity);
-int mr_attn_split_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale,
-                           int window, int products, float* ctx, mr_stream_t stream);
+int mr_attn_split_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int B, int q_rows, int H, int dh,
+                           float scale, int window, int products, float* ctx, mr_stream_t stream);
 
 /* Global-token row of Longformer attention: for each sequence b, ctx[cu[b], :] =
  * softmax(qg_b kg^T * scale) vg over all tokens of b, where qg is (B, H*dh) (the global query of
@@ -300,16 +317,17 @@ int mr_dropout_rows_f32(const float* x, int64_t ldx, int T, int d, float drop_p,
  * probabilities (transformers RobertaSelfAttention / LongformerSelfAttention: nn.functional.dropout(attn_probs, p, training)). */
 int mr_attn_train_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh, int max_len, float scale,
                       int window, float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream);
-int mr_attn_split_work_train_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale,
-                                 int window, int products, float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream);
+int mr_attn_split_work_train_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int B, int q_rows, int H, int dh,
+                                 float scale, int window, int products, float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream);
 int mr_attn_global_row_train_f32(const float* qg, const float* kvg, const int32_t* cu_seqlens, int B, int H, int dh, int max_len, float scale,
                                  float drop_p, uint32_t drop_key, float* ctx, int compact, mr_stream_t stream);
 int mr_attn_bwd_train_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H,
                           int dh, int max_len, float scale, int window, float drop_p, uint32_t drop_key, float* rowstat, float* dqkv,
                           mr_stream_t stream);
 /* mr_attn_bwd_train_f32 on the work-list grid of mr_attn_split_work_f32 (work from mr_attn_work_plan with q_rows = 128): same results. */
-int mr_attn_bwd_work_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H,
-                         int dh, float scale, int window, float drop_p, uint32_t drop_key, float* rowstat, float* dqkv, mr_stream_t stream);
+int mr_attn_bwd_work_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int B,
+                         int q_rows, int H, int dh, float scale, int window, float drop_p, uint32_t drop_key, float* rowstat, float* dqkv,
+                         mr_stream_t stream);
 int mr_attn_global_row_bwd_train_f32(const float* qg, const float* kvg, const float* ctx_cls, const float* dctx_cls, const int32_t* cu_seqlens,
                                      int B, int H, int dh, float scale, float drop_p, uint32_t drop_key, float* dqg, float* dkvg,
                                      mr_stream_t stream);
@@ -346,6 +364,9 @@ int mr_topk_max_k(void);
 size_t mr_score_topk_ws_bytes(int64_t nU, int64_t M);
 size_t mr_score_topk_ws_bytes_ex(int64_t nU, int64_t M, int d, int k);
 int mr_score_fused_mode(int mode);
+/* test / A-B switch of mr_merge_bwd_alpha_f32: 1 = the per-vector loop for every N (bit-identical to the single-pass kernels), 0 = default;
+ * any other value only queries.  Returns the previous setting.  Initial value: MR_MERGE_BWD_GENERIC, read once when the library loads. */
+int mr_merge_bwd_generic(int on);
 int mr_score_topk_f32(const float* U, const float* E, int64_t nU, int64_t M, int d, int k, float* top_val,
                       int64_t* top_idx, float* scores_out, const int64_t* labels, float inv_temp, float* row_lse,
                       float* row_lab, int32_t* label_rank, void* ws, size_t ws_bytes, mr_stream_t stream);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mr_embed_gather_ln_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p]),
     "mr_gemm_nt_bias_act_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p]),
     "mr_gemm_nt_bf16x6_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_i, c_p]),
+    "mr_split_weights_kblock_f16_f32": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "mr_split_bf16x3_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     "mr_split_weights_kblock_f32": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "mr_layernorm_f32": (c_i, [c_p, c_i64, c_p, c_p, c_f, c_i, c_i, c_p, c_i64, c_p]),
@@ -77,15 +78,15 @@ SIGNATURES = {
     "mr_attn_split_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p]),
     "mr_attn_split_q_rows": (c_i, [c_i, c_i]),
     "mr_attn_work_plan": (c_i64, [c_p, c_i, c_i, c_p, c_i64]),
-    "mr_attn_work_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p]),
-    "mr_attn_split_work_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_i, c_p, c_p]),
+    "mr_attn_work_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p]),
+    "mr_attn_split_work_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p]),
     "mr_dropout_site_key": (c_i, [c_u32, c_u32, c_u32, c_u32, c_p]),
     "mr_dropout_rows_f32": (c_i, [c_p, c_i64, c_i, c_i, c_f, c_u32, c_p, c_i64, c_p, c_i64, c_p]),
     "mr_attn_train_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p]),
-    "mr_attn_split_work_train_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_i, c_f, c_u32, c_p, c_p]),
+    "mr_attn_split_work_train_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_f, c_u32, c_p, c_p]),
     "mr_attn_global_row_train_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u32, c_p, c_i, c_p]),
     "mr_attn_bwd_train_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p, c_p]),
-    "mr_attn_bwd_work_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p, c_p]),
+    "mr_attn_bwd_work_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u32, c_p, c_p, c_p]),
     "mr_attn_global_row_bwd_train_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_u32, c_p, c_p, c_p]),
     "mr_attn_global_row_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "mr_cls_pool_normalize_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_p, c_p]),
@@ -95,6 +96,7 @@ SIGNATURES = {
     "mr_score_topk_ws_bytes": (c_sz, [c_i64, c_i64]),
     "mr_score_topk_ws_bytes_ex": (c_sz, [c_i64, c_i64, c_i, c_i]),
     "mr_score_fused_mode": (c_i, [c_i]),
+    "mr_merge_bwd_generic": (c_i, [c_i]),
     "mr_score_topk_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p]),
 }
 

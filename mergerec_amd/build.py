@@ -18,8 +18,9 @@ OBJ = HERE / "lib" / "obj"
 LIB = HERE / "lib" / "libmergerec_hip.so"
 SOURCES = ["capi.hip", "merge.hip", "embed.hip", "gemm.hip", "gemm_bf16.hip", "attn.hip", "attn_bf16.hip", "score.hip", "score_fused.hip", "select.hip", "distill.hip", "backward.hip", "attn_bwd.hip", "optim.hip", "dropout.hip"]
 # merge.hip must not contract a*b+c into an FMA: the reference rounds the products separately.
-EXTRA = {"merge.hip": ["-ffp-contract=off"], "gemm_bf16.hip": os.environ.get("MR_GEMM_DEFS", "").split(),
-         "score_fused.hip": os.environ.get("MR_SCORE_DEFS", "").split()}
+# (no environment-supplied defines: an object built with a flag would be reused silently by the next plain build -- experiments compile
+# their own copies into /tmp, tools/ab_flag.sh)
+EXTRA = {"merge.hip": ["-ffp-contract=off"]}
 
 
 def hipcc() -> str:

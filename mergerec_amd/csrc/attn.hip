@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kThreads, 4) void attn_kernel(const float* __restri
                                                        const int32_t* __restrict__ seq_order, int H,
                                                        float scale_log2e, int window, float* __restrict__ ctx,
                                                        uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u,
-                                                       const int32_t* __restrict__ work = nullptr) {
+                                                       const int32_t* __restrict__ work = nullptr, int nseq = 0x7fffffff) {
     __shared__ __attribute__((aligned(16))) float lds[2][kTileFloats];
     // work != NULL: the 1-D work-list grid of mr_attn_split_work_f32 (csrc/attn_bf16.hip; 128-row blocks: only the (sequence, block) pairs
     // that exist, dealt over the XCD queues).  Else the (blocks, H, B) box; seq_order (optional) = sequence ids by decreasing length
@@ -42,6 +42,7 @@ __global__ __launch_bounds__(kThreads, 4) void attn_kernel(const float* __restri
         const int slot = blockIdx.x >> 3, e = slot / H, ent = work[e * 8 + (blockIdx.x & 7)];
         if (ent < 0) return;
         h = slot - e * H; b = ent & 0xffffff; q_base = (ent >> 24) * 128;
+        if (b >= nseq) return;  // a list planned for another batch: never index cu[] past its B + 1 entries
     } else {
         b = seq_order ? seq_order[blockIdx.z] : (int)blockIdx.z; h = blockIdx.y; q_base = blockIdx.x * 128;
     }
@@ -266,12 +267,13 @@ extern "C" int mr_attn_f32(const float* qkv, const int32_t* cu_seqlens, const in
 
 // exact-fp32 attention on the work-list grid (work / n_slots from mr_attn_work_plan(lens, B, 128, ...)); drop_p as mr_attn_train_f32.
 // Same results as mr_attn_f32 / mr_attn_train_f32 bit for bit.
-extern "C" int mr_attn_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale,
-                                int window, float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream) {
+extern "C" int mr_attn_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int B, int q_rows, int H, int dh,
+                                float scale, int window, float drop_p, uint32_t drop_key, float* ctx, mr_stream_t stream) {
     uint32_t thresh;
     float inv;
     if (!mr::dropout_params(drop_p, &thresh, &inv)) return MR_EINVAL;
-    if (!qkv || !cu_seqlens || !ctx || n_slots < 0 || H < 1 || (n_slots > 0 && !work)) return MR_EINVAL;
+    if (!qkv || !cu_seqlens || !ctx || n_slots < 0 || B < 0 || H < 1 || (n_slots > 0 && !work)) return MR_EINVAL;
+    if (q_rows != 128) return MR_EINVAL;  // this kernel's block height: a list planned with another one would skip or repeat rows
     if (dh != kDh) return MR_EUNSUPPORTED;
     if (!mr::aligned16(qkv) || !mr::aligned16(ctx)) return MR_EALIGN;
     if (n_slots == 0) return MR_OK;
@@ -280,7 +282,7 @@ extern "C" int mr_attn_work_f32(const float* qkv, const int32_t* cu_seqlens, con
     const float scale_log2e = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
 #define MR_ATTN_W(W_, D_) hipLaunchKernelGGL((attn_kernel<W_, D_>), grid, dim3(kThreads), 0, st, qkv, cu_seqlens, nullptr, H, scale_log2e, window, ctx, \
-                                             thresh, thresh ? inv : 1.f, drop_key, work)
+                                             thresh, thresh ? inv : 1.f, drop_key, work, B)
     if (window >= 0) { if (thresh) MR_ATTN_W(true, true); else MR_ATTN_W(true, false); }
     else { if (thresh) MR_ATTN_W(false, true); else MR_ATTN_W(false, false); }
 #undef MR_ATTN_W

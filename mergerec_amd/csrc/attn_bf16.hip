@@ -48,9 +48,29 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 }
 __device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+// FP16 pieces ("f16x3", see gemm_bf16.hip): q, k, v and the probabilities are activations -- unscaled, |x| < 65504; a probability's low piece
+// may be an fp16 subnormal, which the matrix pipe honours (absolute error 2^-25 on a value in [0, 1])
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float lo_h(uint32_t u) {
+    float r;
+    asm("v_cvt_f32_f16 %0, %1" : "=v"(r) : "v"(u));
+    return r;
+}
+__device__ __forceinline__ float hi_h(uint32_t u) {
+    float r;
+    asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(u));
+    return r;
+}
+template <bool F16> __device__ __forceinline__ uint32_t pk(float a, float b) { return F16 ? pack2h(a, b) : pack2(a, b); }
+template <bool F16> __device__ __forceinline__ float lo_v(uint32_t u) { return F16 ? lo_h(u) : lo_f(u); }
+template <bool F16> __device__ __forceinline__ float hi_v(uint32_t u) { return F16 ? hi_h(u) : hi_f(u); }
 
-// 8 fp32 -> NP pieces of 8 bf16 (4 dwords each); piece 0 = hi
-template <int NP>
+// 8 fp32 -> NP pieces of 8 bf16 / fp16 (4 dwords each); piece 0 = hi
+template <int NP, bool F16 = false>
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[NP]) {
     float r[8];
 #pragma unroll
@@ -59,11 +79,11 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[NP]) {
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t w = pack2(r[2 * j], r[2 * j + 1]);
+            const uint32_t w = pk<F16>(r[2 * j], r[2 * j + 1]);
             out[p][j] = w;
             if (p + 1 < NP) {
-                r[2 * j] -= lo_f(w);
-                r[2 * j + 1] -= hi_f(w);
+                r[2 * j] -= lo_v<F16>(w);
+                r[2 * j + 1] -= hi_v<F16>(w);
             }
         }
     }
@@ -76,8 +96,15 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
 }
 
 // acc += sum over the product set of piece pairs: NP = 2 -> (lo,hi) (hi,lo) (hi,hi); NP = 3 -> + (lo2,hi) (hi,lo2) (mid,mid)
-template <int NP>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NP, bool F16 = false>
 __device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[NP], const u32x4 (&b)[NP], f32x16 c) {
+    if (F16) {  // NP == 2
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+        return c;
+    }
     if (NP == 3) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[2]), as_bf16x8(b[0]), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[0]), as_bf16x8(b[2]), c, 0, 0, 0);
@@ -89,7 +116,7 @@ __device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[NP], const u32x4 (
     return c;
 }
 
-template <bool WINDOWED, int NP>
+template <bool WINDOWED, int NP, bool F16 = false>
 __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel(const float* __restrict__ qkv,
                                                                 const int32_t* __restrict__ cu,
                                                                 const int32_t* __restrict__ seq_order, int H,
@@ -122,7 +149,7 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
             const float4 x1 = *reinterpret_cast<const float4*>(qr + 16 * s + 4);
             const float x[8] = {x0.x * scale_log2e, x0.y * scale_log2e, x0.z * scale_log2e, x0.w * scale_log2e,
                                 x1.x * scale_log2e, x1.y * scale_log2e, x1.z * scale_log2e, x1.w * scale_log2e};
-            split8<NP>(x, qp[s]);
+            split8<NP, F16>(x, qp[s]);
         }
     }
 
@@ -157,9 +184,9 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
         float r0 = x.x, r1 = x.y, r2 = x.z, r3 = x.w;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const uint32_t w0 = pack2(r0, r1), w1 = pack2(r2, r3);
+            const uint32_t w0 = pk<F16>(r0, r1), w1 = pk<F16>(r2, r3);
             *reinterpret_cast<uint2*>(dst + p * KPIECE) = make_uint2(w0, w1);
-            if (p + 1 < NP) { r0 -= lo_f(w0); r1 -= hi_f(w0); r2 -= lo_f(w1); r3 -= hi_f(w1); }
+            if (p + 1 < NP) { r0 -= lo_v<F16>(w0); r1 -= hi_v<F16>(w0); r2 -= lo_v<F16>(w1); r3 -= hi_v<F16>(w1); }
         }
     };
     // V piece position of (row, 4-d group sc4): 16-B chunk (sc4 >> 1) ^ (4 * ((row >> 1) & 1)); rows sr and sr + 16 share the bit
@@ -214,7 +241,7 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
                     ka[p] = *reinterpret_cast<const u32x4*>(buf + p * KPIECE + lr * KROWB + (((2 * st + lh) ^ kswz) << 4));
-                s = mfma_split<NP>(ka, qp[st], s);
+                s = mfma_split<NP, F16>(ka, qp[st], s);
             }
             MR_PH(1)
             // ---- mask + online softmax (base 2); s[r] is key kb + (r&3) + 8*(r>>2) + 4*lh for query q0 + lr
@@ -259,7 +286,7 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
             for (int st = 0; st < 2; ++st) {
                 const float x[8] = {pv[8 * st], pv[8 * st + 1], pv[8 * st + 2], pv[8 * st + 3],
                                     pv[8 * st + 4], pv[8 * st + 5], pv[8 * st + 6], pv[8 * st + 7]};
-                split8<NP>(x, pp[st]);
+                split8<NP, F16>(x, pp[st]);
             }
             MR_PH(2)
             // ---- O^T += V^T P^T: A operand element j of k-step st is V[kb + (j & 3) + 8 (2 st + (j >> 2)) + 4 lh][d]
@@ -278,8 +305,8 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
                                                                        (__attribute__((address_space(3))) s16x4*)(a0 + 8 * KROWB)));
                         va[p][0] = lo.x; va[p][1] = lo.y; va[p][2] = hi.x; va[p][3] = hi.y;
                     }
-                    if (dt == 0) o0 = mfma_split<NP>(va, pp[st], o0);
-                    else o1 = mfma_split<NP>(va, pp[st], o1);
+                    if (dt == 0) o0 = mfma_split<NP, F16>(va, pp[st], o0);
+                    else o1 = mfma_split<NP, F16>(va, pp[st], o1);
                 }
             }
         }
@@ -320,10 +347,10 @@ struct QIdx { static constexpr int value = J; };
 
 // DROP (training graph only): probabilities masked by mr::dropout_keep(key, query token * H + head, key position), scaled by 1 / (1 - p),
 // after the row sum has taken the un-dropped values (softmax, then dropout).
-template <bool WINDOWED, int NP, int QT, bool DROP = false>
+template <bool WINDOWED, int NP, int QT, bool DROP = false, bool F16 = false>
 __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void attn_split_work_kernel(
     const float* __restrict__ qkv, const int32_t* __restrict__ cu, const int32_t* __restrict__ work, int H, float scale_log2e,
-    int window, float* __restrict__ ctx, uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u) {
+    int window, float* __restrict__ ctx, int nseq, uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u) {
     constexpr int BUFB = 2 * NP * KPIECE;  // K pieces, then V pieces
     constexpr int QROWS = 128 * QT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUFB
@@ -332,6 +359,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
     const int ent = __builtin_amdgcn_readfirstlane(work[e * 8 + (id & 7)]);
     if (ent < 0) return;  // padding entry of a shorter XCD queue: the whole workgroup leaves together, before any barrier
     const int b = ent & 0xffffff, q_base = (ent >> 24) * QROWS;
+    if (b >= nseq) return;  // an entry of a list planned for another batch: never index cu[] past its B + 1 entries
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 31, lh = lane >> 5;
     const int t0 = __builtin_amdgcn_readfirstlane(cu[b]), len = __builtin_amdgcn_readfirstlane(cu[b + 1]) - t0;
@@ -365,7 +393,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                 const float4 x1 = *reinterpret_cast<const float4*>(qr + 16 * s + 4);
                 const float x[8] = {x0.x * scale_log2e, x0.y * scale_log2e, x0.z * scale_log2e, x0.w * scale_log2e,
                                     x1.x * scale_log2e, x1.y * scale_log2e, x1.z * scale_log2e, x1.w * scale_log2e};
-                split8<NP>(x, qp[j][s]);
+                split8<NP, F16>(x, qp[j][s]);
             }
         }
     }
@@ -403,9 +431,9 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
         float r0 = __uint_as_float(xb[0]), r1 = __uint_as_float(xb[1]), r2 = __uint_as_float(xb[2]), r3 = __uint_as_float(xb[3]);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const uint32_t w0 = pack2(r0, r1), w1 = pack2(r2, r3);
+            const uint32_t w0 = pk<F16>(r0, r1), w1 = pk<F16>(r2, r3);
             *reinterpret_cast<uint2*>(dst + p * KPIECE) = make_uint2(w0, w1);
-            if (p + 1 < NP) { r0 -= lo_f(w0); r1 -= hi_f(w0); r2 -= lo_f(w1); r3 -= hi_f(w1); }
+            if (p + 1 < NP) { r0 -= lo_v<F16>(w0); r1 -= hi_v<F16>(w0); r2 -= lo_v<F16>(w1); r3 -= hi_v<F16>(w1); }
         }
     };
     const int vw0 = sr * KROWB + ((((sc4 >> 1) ^ (((sr >> 1) & 1) << 2)) << 4) | ((sc4 & 1) << 3));
@@ -472,22 +500,22 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                 for (int st = 0; st < 4; ++st) {
                     u32x4 ka[NP];
                     kfrag(st, ka);
-                    s[0] = mfma_split<NP>(ka, qp[0][st], s[0]);
-                    s[QT - 1] = mfma_split<NP>(ka, qp[QT - 1][st], s[QT - 1]);
+                    s[0] = mfma_split<NP, F16>(ka, qp[0][st], s[0]);
+                    s[QT - 1] = mfma_split<NP, F16>(ka, qp[QT - 1][st], s[QT - 1]);
                 }
             } else if (rel[0]) {
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     u32x4 ka[NP];
                     kfrag(st, ka);
-                    s[0] = mfma_split<NP>(ka, qp[0][st], s[0]);
+                    s[0] = mfma_split<NP, F16>(ka, qp[0][st], s[0]);
                 }
             } else {
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     u32x4 ka[NP];
                     kfrag(st, ka);
-                    s[QT - 1] = mfma_split<NP>(ka, qp[QT - 1][st], s[QT - 1]);
+                    s[QT - 1] = mfma_split<NP, F16>(ka, qp[QT - 1][st], s[QT - 1]);
                 }
             }
             MR_PH(1)
@@ -544,7 +572,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                 for (int st = 0; st < 2; ++st) {
                     const float x[8] = {pv[8 * st], pv[8 * st + 1], pv[8 * st + 2], pv[8 * st + 3],
                                         pv[8 * st + 4], pv[8 * st + 5], pv[8 * st + 6], pv[8 * st + 7]};
-                    split8<NP>(x, pp[j][st]);
+                    split8<NP, F16>(x, pp[j][st]);
                 }
             };
             if (rel[0]) softmax(QIdx<0>{});
@@ -570,8 +598,8 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                     for (int st = 0; st < 2; ++st) {
                         u32x4 va[NP];
                         vfrag(dt, st, va);
-                        o[0][dt] = mfma_split<NP>(va, pp[0][st], o[0][dt]);
-                        o[QT - 1][dt] = mfma_split<NP>(va, pp[QT - 1][st], o[QT - 1][dt]);
+                        o[0][dt] = mfma_split<NP, F16>(va, pp[0][st], o[0][dt]);
+                        o[QT - 1][dt] = mfma_split<NP, F16>(va, pp[QT - 1][st], o[QT - 1][dt]);
                     }
             } else if (rel[0]) {
 #pragma unroll
@@ -580,7 +608,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                     for (int st = 0; st < 2; ++st) {
                         u32x4 va[NP];
                         vfrag(dt, st, va);
-                        o[0][dt] = mfma_split<NP>(va, pp[0][st], o[0][dt]);
+                        o[0][dt] = mfma_split<NP, F16>(va, pp[0][st], o[0][dt]);
                     }
             } else {
 #pragma unroll
@@ -589,7 +617,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                     for (int st = 0; st < 2; ++st) {
                         u32x4 va[NP];
                         vfrag(dt, st, va);
-                        o[QT - 1][dt] = mfma_split<NP>(va, pp[QT - 1][st], o[QT - 1][dt]);
+                        o[QT - 1][dt] = mfma_split<NP, F16>(va, pp[QT - 1][st], o[QT - 1][dt]);
                     }
             }
         }
@@ -624,19 +652,19 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
 extern "C" int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* seq_order, int B, int H, int dh,
                                  int max_len, float scale, int window, int products, float* ctx, mr_stream_t stream) {
     if (!qkv || !cu_seqlens || !ctx || B < 0 || H < 1 || max_len < 0) return MR_EINVAL;
-    if (dh != kDh || (products != 3 && products != 6)) return MR_EUNSUPPORTED;
+    if (dh != kDh || (products != 3 && products != 6 && products != MR_PRODUCTS_F16X3)) return MR_EUNSUPPORTED;
     if (!mr::aligned16(qkv) || !mr::aligned16(ctx)) return MR_EALIGN;
     if (B == 0 || max_len == 0) return MR_OK;
     const dim3 grid((max_len + 127) / 128, H, B);
     const float scale_log2e = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
-#define MR_ATTN_LAUNCH(W_, NP_)                                                                                          \
-    hipLaunchKernelGGL((attn_split_kernel<W_, NP_>), grid, dim3(kThreads), (size_t)2 * (2 * NP_ * KPIECE), st, qkv,       \
+#define MR_ATTN_LAUNCH(W_, NP_, F_)                                                                                          \
+    hipLaunchKernelGGL((attn_split_kernel<W_, NP_, F_>), grid, dim3(kThreads), (size_t)2 * (2 * NP_ * KPIECE), st, qkv,       \
                        cu_seqlens, seq_order, H, scale_log2e, window, ctx)
     if (window >= 0) {
-        if (products == 3) MR_ATTN_LAUNCH(true, 2); else MR_ATTN_LAUNCH(true, 3);
+        if (products == MR_PRODUCTS_F16X3) MR_ATTN_LAUNCH(true, 2, true); else if (products == 3) MR_ATTN_LAUNCH(true, 2, false); else MR_ATTN_LAUNCH(true, 3, false);
     } else {
-        if (products == 3) MR_ATTN_LAUNCH(false, 2); else MR_ATTN_LAUNCH(false, 3);
+        if (products == MR_PRODUCTS_F16X3) MR_ATTN_LAUNCH(false, 2, true); else if (products == 3) MR_ATTN_LAUNCH(false, 2, false); else MR_ATTN_LAUNCH(false, 3, false);
     }
 #undef MR_ATTN_LAUNCH
     return mr::check_launch();
@@ -644,8 +672,8 @@ extern "C" int mr_attn_split_f32(const float* qkv, const int32_t* cu_seqlens, co
 
 // ---- work-list form ------------------------------------------------------------------------------------------------------------
 extern "C" int mr_attn_split_q_rows(int window, int products) {
-    if (products != 3 && products != 6) return MR_EUNSUPPORTED;
-    return (products == 3 && window < 0) ? 256 : 128;
+    if (products != 3 && products != 6 && products != MR_PRODUCTS_F16X3) return MR_EUNSUPPORTED;
+    return (products != 6 && window < 0) ? 256 : 128;
 }
 
 extern "C" int64_t mr_attn_work_plan(const int64_t* lens, int B, int q_rows, int32_t* work, int64_t capacity) {
@@ -674,46 +702,49 @@ extern "C" int64_t mr_attn_work_plan(const int64_t* lens, int B, int q_rows, int
     return n_slots;
 }
 
-static int attn_split_work_launch(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale,
-                                  int window, int products, float* ctx, uint32_t thresh, float inv, uint32_t key, mr_stream_t stream);
+static int attn_split_work_launch(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int B, int q_rows, int H, int dh,
+                                  float scale, int window, int products, float* ctx, uint32_t thresh, float inv, uint32_t key, mr_stream_t stream);
 
-extern "C" int mr_attn_split_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh,
-                                      float scale, int window, int products, float* ctx, mr_stream_t stream) {
-    return attn_split_work_launch(qkv, cu_seqlens, work, n_slots, H, dh, scale, window, products, ctx, 0u, 1.f, 0u, stream);
+extern "C" int mr_attn_split_work_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int B, int q_rows, int H,
+                                      int dh, float scale, int window, int products, float* ctx, mr_stream_t stream) {
+    return attn_split_work_launch(qkv, cu_seqlens, work, n_slots, B, q_rows, H, dh, scale, window, products, ctx, 0u, 1.f, 0u, stream);
 }
 
 // training-graph form: dropout on the attention probabilities (drop_p in [0, 1); 0 = mr_attn_split_work_f32, bit for bit)
-extern "C" int mr_attn_split_work_train_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh,
-                                            float scale, int window, int products, float drop_p, uint32_t drop_key, float* ctx,
+extern "C" int mr_attn_split_work_train_f32(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int B, int q_rows,
+                                            int H, int dh, float scale, int window, int products, float drop_p, uint32_t drop_key, float* ctx,
                                             mr_stream_t stream) {
     uint32_t thresh;
     float inv;
     if (!mr::dropout_params(drop_p, &thresh, &inv)) return MR_EINVAL;
-    return attn_split_work_launch(qkv, cu_seqlens, work, n_slots, H, dh, scale, window, products, ctx, thresh, inv, drop_key, stream);
+    return attn_split_work_launch(qkv, cu_seqlens, work, n_slots, B, q_rows, H, dh, scale, window, products, ctx, thresh, inv, drop_key, stream);
 }
 
-static int attn_split_work_launch(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int H, int dh, float scale,
-                                  int window, int products, float* ctx, uint32_t thresh, float inv, uint32_t key, mr_stream_t stream) {
-    if (!qkv || !cu_seqlens || !ctx || n_slots < 0 || H < 1 || (n_slots > 0 && !work)) return MR_EINVAL;
-    if (dh != kDh || (products != 3 && products != 6)) return MR_EUNSUPPORTED;
+static int attn_split_work_launch(const float* qkv, const int32_t* cu_seqlens, const int32_t* work, int64_t n_slots, int B, int q_rows, int H, int dh,
+                                  float scale, int window, int products, float* ctx, uint32_t thresh, float inv, uint32_t key, mr_stream_t stream) {
+    if (!qkv || !cu_seqlens || !ctx || n_slots < 0 || B < 0 || H < 1 || (n_slots > 0 && !work)) return MR_EINVAL;
+    if (dh != kDh || (products != 3 && products != 6 && products != MR_PRODUCTS_F16X3)) return MR_EUNSUPPORTED;
+    // the list must have been planned for THIS kernel's block height (an entry holds a block index, not a row) and for this batch
+    if (q_rows != mr_attn_split_q_rows(window, products)) return MR_EINVAL;
     if (!mr::aligned16(qkv) || !mr::aligned16(ctx)) return MR_EALIGN;
     if (n_slots == 0) return MR_OK;
     if (n_slots * 8 * (int64_t)H > 0x7fffffff) return MR_EINVAL;
     const dim3 grid((unsigned)(n_slots * 8 * H));
     const float scale_log2e = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
-#define MR_ATTN_LAUNCH(W_, NP_, QT_, D_)                                                                                         \
-    hipLaunchKernelGGL((attn_split_work_kernel<W_, NP_, QT_, D_>), grid, dim3(kThreads), (size_t)2 * (2 * NP_ * KPIECE), st, qkv, \
-                       cu_seqlens, work, H, scale_log2e, window, ctx, thresh, inv, key)
+#define MR_ATTN_LAUNCH(W_, NP_, QT_, D_, F_)                                                                                         \
+    hipLaunchKernelGGL((attn_split_work_kernel<W_, NP_, QT_, D_, F_>), grid, dim3(kThreads), (size_t)2 * (2 * NP_ * KPIECE), st, qkv, \
+                       cu_seqlens, work, H, scale_log2e, window, ctx, B, thresh, inv, key)
+    const bool f16 = products == MR_PRODUCTS_F16X3;
     if (thresh == 0u) {
         if (window >= 0) {
-            if (products == 3) MR_ATTN_LAUNCH(true, 2, 1, false); else MR_ATTN_LAUNCH(true, 3, 1, false);
+            if (f16) MR_ATTN_LAUNCH(true, 2, 1, false, true); else if (products == 3) MR_ATTN_LAUNCH(true, 2, 1, false, false); else MR_ATTN_LAUNCH(true, 3, 1, false, false);
         } else {
-            if (products == 3) MR_ATTN_LAUNCH(false, 2, 2, false); else MR_ATTN_LAUNCH(false, 3, 1, false);
+            if (f16) MR_ATTN_LAUNCH(false, 2, 2, false, true); else if (products == 3) MR_ATTN_LAUNCH(false, 2, 2, false, false); else MR_ATTN_LAUNCH(false, 3, 1, false, false);
         }
-    } else {  // training graph with dropout: the bf16x3 arithmetic only (the six-product form is an inference mode)
+    } else {  // training graph with dropout: the bf16x3 arithmetic only (the other forms are inference modes)
         if (products != 3) return MR_EUNSUPPORTED;
-        if (window >= 0) MR_ATTN_LAUNCH(true, 2, 1, true); else MR_ATTN_LAUNCH(false, 2, 2, true);
+        if (window >= 0) MR_ATTN_LAUNCH(true, 2, 1, true, false); else MR_ATTN_LAUNCH(false, 2, 2, true, false);
     }
 #undef MR_ATTN_LAUNCH
     return mr::check_launch();

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * NW, (STATS ? 4 : 3)) void attn_bwd_q_kernel(co
                                                                 const int32_t* __restrict__ order, int H, float scale, int window,
                                                                 float* __restrict__ rowstat, float* __restrict__ dqkv,
                                                                 uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u,
-                                                                const int32_t* __restrict__ work = nullptr) {
+                                                                const int32_t* __restrict__ work = nullptr, int nseq = 0x7fffffff) {
     // drop_thresh != 0: the forward dropped attention probabilities (mask = mr::dropout_keep(key, query token * H + head, key position)):
     // dP = (dO . v) * mask / (1 - p); delta = dO . O already holds the dropped forward
     __shared__ float ks[kTile], vs[STATS ? 1 : kTile];
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64 * NW, (STATS ? 4 : 3)) void attn_bwd_q_kernel(co
         const int slot = blockIdx.x >> 3, e = slot / H, ent = work[e * 8 + (blockIdx.x & 7)];
         if (ent < 0) return;
         h = slot - e * H; b = ent & 0xffffff; Q0 = (ent >> 24) * kRows;
+        if (b >= nseq) return;
     } else {
         b = order ? order[blockIdx.z] : blockIdx.z; h = blockIdx.y; Q0 = blockIdx.x * kRows;
     }
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_kernel(const float* __
                                                                  const float* __restrict__ rowstat, const int32_t* __restrict__ cu,
                                                                  const int32_t* __restrict__ order, int H, float scale, int window,
                                                                  float* __restrict__ dqkv, uint32_t drop_thresh = 0u, float drop_inv = 1.f,
-                                                                 uint32_t drop_key = 0u, const int32_t* __restrict__ work = nullptr) {
+                                                                 uint32_t drop_key = 0u, const int32_t* __restrict__ work = nullptr, int nseq = 0x7fffffff) {
     __shared__ float qs[kTile], gs[kTile], stat[32][2];
     constexpr int kRows = 32 * NW;
     int b, h, K0;
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_kernel(const float* __
         const int slot = blockIdx.x >> 3, e = slot / H, ent = work[e * 8 + (blockIdx.x & 7)];
         if (ent < 0) return;
         h = slot - e * H; b = ent & 0xffffff; K0 = (ent >> 24) * kRows;
+        if (b >= nseq) return;
     } else {
         b = order ? order[blockIdx.z] : blockIdx.z; h = blockIdx.y; K0 = blockIdx.x * kRows;
     }
@@ -410,12 +412,13 @@ static int attn_bwd_launch(const float* qkv, const float* ctx, const float* dctx
 // work-list launch of the three backward kernels (work / n_slots from mr_attn_work_plan(lens, B, 128, ...)): no empty workgroups on ragged
 // batches; same results as mr_attn_bwd_train_f32 bit for bit (every output element has one owner and a fixed order in both)
 extern "C" int mr_attn_bwd_work_f32(const float* qkv, const float* ctx, const float* dctx, const int32_t* cu_seqlens, const int32_t* work,
-                                    int64_t n_slots, int H, int dh, float scale, int window, float drop_p, uint32_t drop_key, float* rowstat,
-                                    float* dqkv, mr_stream_t stream) {
+                                    int64_t n_slots, int B, int q_rows, int H, int dh, float scale, int window, float drop_p, uint32_t drop_key,
+                                    float* rowstat, float* dqkv, mr_stream_t stream) {
     uint32_t thresh;
     float inv;
     if (!mr::dropout_params(drop_p, &thresh, &inv)) return MR_EINVAL;
-    if (!qkv || !ctx || !dctx || !cu_seqlens || !rowstat || !dqkv || n_slots < 0 || H < 1 || (n_slots > 0 && !work)) return MR_EINVAL;
+    if (!qkv || !ctx || !dctx || !cu_seqlens || !rowstat || !dqkv || n_slots < 0 || B < 0 || H < 1 || (n_slots > 0 && !work)) return MR_EINVAL;
+    if (q_rows != 128) return MR_EINVAL;  // the three kernels own 128 rows per list entry
     if (dh != kDh) return MR_EUNSUPPORTED;
     if (!mr::aligned16(qkv) || !mr::aligned16(ctx) || !mr::aligned16(dctx)) return MR_EALIGN;
     if (n_slots == 0) return MR_OK;
@@ -424,11 +427,11 @@ extern "C" int mr_attn_bwd_work_f32(const float* qkv, const float* ctx, const fl
     hipStream_t st = (hipStream_t)stream;
     if (!thresh) inv = 1.f;
     hipLaunchKernelGGL((attn_bwd_q_kernel<true, 4>), grid, dim3(256), 0, st, qkv, ctx, dctx, cu_seqlens, nullptr, H, scale, window, rowstat, dqkv, thresh,
-                       inv, drop_key, work);
+                       inv, drop_key, work, B);
     hipLaunchKernelGGL((attn_bwd_q_kernel<false, 4>), grid, dim3(256), 0, st, qkv, ctx, dctx, cu_seqlens, nullptr, H, scale, window, rowstat, dqkv, thresh,
-                       inv, drop_key, work);
+                       inv, drop_key, work, B);
     hipLaunchKernelGGL((attn_bwd_kv_kernel<4>), grid, dim3(256), 0, st, qkv, dctx, rowstat, cu_seqlens, nullptr, H, scale, window, dqkv, thresh, inv, drop_key,
-                       work);
+                       work, B);
     return mr::check_launch();
 }
 

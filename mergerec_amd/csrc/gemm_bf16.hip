@@ -28,7 +28,16 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- "f16x3" (r04): the same three products hi*hi + hi*lo + lo*hi with FP16 pieces.  fp16 carries 11 significand bits, so two pieces hold
+// 22 (bf16: 16) and the dropped lo*lo term is 2^-22 (2^-16): per-product error ~2^-21 at the matrix-pipe cost of bf16x3.  Range instead of
+// precision is the price: |x| must stay below 65504 (activations of a post-LayerNorm encoder are far inside; weights are stored scaled by
+// kF16WScale = 2^8 -- exact -- so that the low piece of a typical 0.01..0.1 weight is a NORMAL fp16 number, and the GEMM epilogue multiplies
+// the accumulator by 2^-8).  Low pieces below 2^-14 are fp16 subnormals, which v_cvt_pk_f16_f32 produces and the matrix pipe honours
+// exactly (exp/f16_subnormal_probe.hip): a piece pair then represents x to an ABSOLUTE 2^-25, i.e. better than fp32's own ulp for |x| > 0.25.
+constexpr float kF16WScale = 256.0f, kF16WScaleInv = 1.0f / 256.0f;
 
 constexpr int BM = 128, BK = 16;
 constexpr int ROWB = 32;                 // bytes per LDS row: 16 bf16, unpadded; the two 16-B halves of rows 8..15 (mod 16)
@@ -46,6 +55,30 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 }
 __device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// two fp32 -> one dword of two fp16 (round-to-nearest-even), low half = first argument
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float lo_h(uint32_t u) {
+    float r;
+    asm("v_cvt_f32_f16 %0, %1" : "=v"(r) : "v"(u));  // reads the low 16 bits
+    return r;
+}
+__device__ __forceinline__ float hi_h(uint32_t u) {
+    float r;
+    asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(u));  // the high 16 bits, no shift
+    return r;
+}
+// split 4 fp32 into two pieces of 4 fp16 (hi, and the exact remainder rounded to fp16)
+__device__ __forceinline__ void split4h(const float4 x, uint2& h, uint2& m) {
+    h.x = pack2h(x.x, x.y);
+    h.y = pack2h(x.z, x.w);
+    m.x = pack2h(x.x - lo_h(h.x), x.y - hi_h(h.x));
+    m.y = pack2h(x.z - lo_h(h.y), x.w - hi_h(h.y));
+}
 
 // split 4 fp32 into three pieces of 4 bf16 (2 dwords each)
 __device__ __forceinline__ void split4(const float4 x, uint2& h, uint2& m, uint2& l) {
@@ -84,11 +117,14 @@ __device__ __forceinline__ void split8(const float4 x0, const float4 x1, uint4& 
 // One thread = one 16-byte OUTPUT chunk (8 consecutive k of one row): chunk c of a matrix is (k-block, row, half) with the half
 // fastest, so a wave writes 1 KB of contiguous k-blocked output per piece and reads 32 rows x 64 B (the other half of each 128-B
 // line is read by the wave handling the next k-block: an L2 hit).  `lo` may be NULL (bf16x3 keeps two pieces).
+// F16: two fp16 pieces of kF16WScale * w; a weight whose scaled magnitude leaves fp16's range raises *overflow (checked by the host at its
+// next synchronisation point: such a model needs the bf16 pieces).
+template <bool F16>
 __global__ __launch_bounds__(kThreads) void split_weights_kblock_kernel(const float* __restrict__ arena,
                                                                        const int64_t* __restrict__ table,
                                                                        const int64_t* __restrict__ unit_prefix, int n_mat,
                                                                        uint16_t* __restrict__ hi, uint16_t* __restrict__ mid,
-                                                                       uint16_t* __restrict__ lo) {
+                                                                       uint16_t* __restrict__ lo, int32_t* __restrict__ overflow) {
     const int64_t total = unit_prefix[n_mat] >> 1;  // 8-element chunks
     for (int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x; c < total; c += (int64_t)gridDim.x * kThreads) {
         int a = 0, b = n_mat - 1;  // largest i with unit_prefix[i] / 2 <= c
@@ -102,11 +138,26 @@ __global__ __launch_bounds__(kThreads) void split_weights_kblock_kernel(const fl
         const int64_t rowk = cm >> 1, kb = rowk / N, n = rowk - kb * N;
         const float* src = arena + off + n * K + kb * 16 + half * 8;
         uint4 h, m, l;
-        split8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4), h, m, l);
         const int64_t dst = off + cm * 8;
+        if (F16) {
+            float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+            x0.x *= kF16WScale; x0.y *= kF16WScale; x0.z *= kF16WScale; x0.w *= kF16WScale;
+            x1.x *= kF16WScale; x1.y *= kF16WScale; x1.z *= kF16WScale; x1.w *= kF16WScale;
+            const float big = fmaxf(fmaxf(fmaxf(fabsf(x0.x), fabsf(x0.y)), fmaxf(fabsf(x0.z), fabsf(x0.w))),
+                                    fmaxf(fmaxf(fabsf(x1.x), fabsf(x1.y)), fmaxf(fabsf(x1.z), fabsf(x1.w))));
+            const float nan_probe = (x0.x + x0.y) + (x0.z + x0.w) + (x1.x + x1.y) + (x1.z + x1.w);  // fmaxf drops NaNs; a sum keeps them
+            if ((!(big <= 65504.0f) || nan_probe != nan_probe) && overflow) *overflow = 1;
+            uint2 h0, m0, h1, m1;
+            split4h(x0, h0, m0);
+            split4h(x1, h1, m1);
+            h = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            m = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        } else {
+            split8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4), h, m, l);
+        }
         *reinterpret_cast<uint4*>(hi + dst) = h;
         *reinterpret_cast<uint4*>(mid + dst) = m;
-        if (lo) *reinterpret_cast<uint4*>(lo + dst) = l;
+        if (!F16 && lo) *reinterpret_cast<uint4*>(lo + dst) = l;
     }
 }
 
@@ -141,7 +192,8 @@ __global__ __launch_bounds__(kThreads) void split_tokens_kblock_kernel(const flo
 // twice the MFMAs per barrier / LDS read / A byte; 128 accumulator VGPRs, 2 workgroups/CU)
 // SK (split-K, training weight gradients: small outputs, token-deep K): blockIdx.y owns k in [y * kchunk, min(K, (y + 1) * kchunk))
 // and writes its partial product to C + y * split_stride; the caller adds the partials (splitk_sum_kernel).
-template <int ACT, bool HAS_R, bool PF2, int NP, int NT, bool SK = false>
+// F16 (NP == 2 only): fp16 pieces -- "f16x3"; the weight pieces hold kF16WScale * w and the epilogue undoes the scale.
+template <int ACT, bool HAS_R, bool PF2, int NP, int NT, bool SK = false, bool F16 = false>
 __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_kernel(
     const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ wh, const uint16_t* __restrict__ wm_,
     const uint16_t* __restrict__ wl, int64_t off0, int64_t off1, int64_t off2, const float* __restrict__ b0,
@@ -231,39 +283,19 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
     };
     auto lstore = [&](const Stage& st, unsigned char* buf) {
         uint2 h, m, l;
-#if defined(MR_ABL_NOSPLIT)  // diagnostic: no conversion work (wrong numerics)
-        h = make_uint2(__float_as_uint(st.a0.x), __float_as_uint(st.a0.y)); m = make_uint2(__float_as_uint(st.a0.z), __float_as_uint(st.a0.w)); l = h;
-#else
-        split4(st.a0, h, m, l);
-#endif
-#if defined(MR_ABL_NOLDSWRITE)  // diagnostic: values only kept alive
-        asm volatile("" ::"v"(h.x), "v"(h.y), "v"(m.x), "v"(m.y), "v"(l.x), "v"(l.y));
-#else
+        if (F16) split4h(st.a0, h, m); else split4(st.a0, h, m, l);
         *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa0) = h;
         *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa0) = m;
         if (NP == 3) *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa0) = l;
-#endif
-#if defined(MR_ABL_NOSPLIT)
-        h = make_uint2(__float_as_uint(st.a1.x), __float_as_uint(st.a1.y)); m = make_uint2(__float_as_uint(st.a1.z), __float_as_uint(st.a1.w)); l = h;
-#else
-        split4(st.a1, h, m, l);
-#endif
-#if defined(MR_ABL_NOLDSWRITE)
-        asm volatile("" ::"v"(h.x), "v"(h.y), "v"(m.x), "v"(m.y), "v"(l.x), "v"(l.y));
-#else
+        if (F16) split4h(st.a1, h, m); else split4(st.a1, h, m, l);
         *reinterpret_cast<uint2*>(buf + 0 * PIECE + wa1) = h;
         *reinterpret_cast<uint2*>(buf + 1 * PIECE + wa1) = m;
         if (NP == 3) *reinterpret_cast<uint2*>(buf + 2 * PIECE + wa1) = l;
-#endif
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {  // rows brow + 128 q: same swizzle bit
-#if defined(MR_ABL_NOLDSWRITE)
-            asm volatile("" ::"v"(st.bh[q].x), "v"(st.bh[q].w), "v"(st.bm[q].x), "v"(st.bm[q].w));
-#else
             *reinterpret_cast<uint4*>(buf + BOFF + 0 * BPIECE + q * PIECE + wb) = st.bh[q];
             *reinterpret_cast<uint4*>(buf + BOFF + 1 * BPIECE + q * PIECE + wb) = st.bm[q];
             if (NP == 3) *reinterpret_cast<uint4*>(buf + BOFF + 2 * BPIECE + q * PIECE + wb) = st.bl[q];
-#endif
         }
     };
     auto compute = [&](const unsigned char* buf) {
@@ -286,18 +318,19 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);  // hi  * lo
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);  // mid * mid
                 }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);  // mid * hi
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);  // hi  * mid
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);  // hi  * hi
+                if (F16) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][1]), __builtin_bit_cast(f16x8, b[j][0]), c, 0, 0, 0);  // lo * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][0]), __builtin_bit_cast(f16x8, b[j][1]), c, 0, 0, 0);  // hi * lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][0]), __builtin_bit_cast(f16x8, b[j][0]), c, 0, 0, 0);  // hi * hi
+                } else {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);  // mid * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);  // hi  * mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);  // hi  * hi
+                }
                 acc[i][j] = c;
             }
     };
 
-#ifdef MR_GEMM_SLOT_PRIO
-    // the two waves sharing a SIMD (one per resident workgroup) sit in different wave slots: give the odd slot priority so the
-    // pair runs in anti-phase (one wave's MFMA burst beside the other's staging phase) instead of contending in lockstep
-    if (__builtin_amdgcn_s_getreg(0x1804) & 1) __builtin_amdgcn_s_setprio(2);
-#endif
     MR_PH_DECL
     const int nk = K / BK;
     auto ktile = [&](int kt) { return (kt < nk ? kt : 0) * BK; };  // past-the-end prefetches re-read tile 0 (never consumed)
@@ -413,7 +446,7 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[i][j][4 * q + r] + bz[j];
+                    v[r] = (F16 ? acc[i][j][4 * q + r] * kF16WScaleInv : acc[i][j][4 * q + r]) + bz[j];  // (the power-of-two scale is exact)
                     if (ACT == MR_ACT_GELU_ERF) v[r] = gelu_erf(v[r]);
                     if (HAS_R) v[r] += rr[r];
                 }
@@ -478,8 +511,22 @@ extern "C" int mr_split_weights_kblock_f32(const float* arena, const int64_t* ta
     if (n_mat == 0 || total_units == 0) return MR_OK;
     int64_t blocks = (total_units / 2 + kThreads - 1) / kThreads;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(split_weights_kblock_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, arena, table,
-                       unit_prefix, n_mat, hi, mid, lo);
+    hipLaunchKernelGGL(split_weights_kblock_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, arena, table,
+                       unit_prefix, n_mat, hi, mid, lo, nullptr);
+    return mr::check_launch();
+}
+
+// fp16 pieces ("f16x3"): hi / lo of 2^8 * w in the same k-blocked layout.  *overflow (device int32, optional, never cleared here) is set when
+// a scaled weight leaves fp16's range (|w| >= 255.9) or is NaN: that model cannot use the fp16 pieces.
+extern "C" int mr_split_weights_kblock_f16_f32(const float* arena, const int64_t* table, const int64_t* unit_prefix, int n_mat,
+                                              int64_t total_units, uint16_t* hi, uint16_t* lo, int32_t* overflow, mr_stream_t stream) {
+    if (!arena || !table || !unit_prefix || !hi || !lo || n_mat < 0 || total_units < 0) return MR_EINVAL;
+    if (!mr::aligned16(arena) || (reinterpret_cast<uintptr_t>(hi) & 15) || (reinterpret_cast<uintptr_t>(lo) & 15)) return MR_EALIGN;
+    if (n_mat == 0 || total_units == 0) return MR_OK;
+    int64_t blocks = (total_units / 2 + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(split_weights_kblock_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, arena, table,
+                       unit_prefix, n_mat, hi, lo, nullptr, overflow);
     return mr::check_launch();
 }
 
@@ -499,7 +546,9 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
                                      const uint16_t* w_lo, int64_t off0, int64_t off1, int64_t off2, const float* b0,
                                      const float* b1, const float* b2, int nseg, int M, int seg_n, int K, int act,
                                      const float* R, int64_t ldr, float* C, int64_t ldc, int products, mr_stream_t stream) {
-    if (products != 6 && products != 3) return MR_EUNSUPPORTED;
+    if (products != 6 && products != 3 && products != MR_PRODUCTS_F16X3) return MR_EUNSUPPORTED;
+    const bool f16 = products == MR_PRODUCTS_F16X3;  // fp16 pieces (w_hi / w_mid from mr_split_weights_kblock_f16_f32), three products
+    if (f16) products = 3;
     if (!A || !w_hi || !w_mid || (products == 6 && !w_lo) || !C || nseg < 1 || nseg > 3 || M < 0 || seg_n < 1 || K < 1) return MR_EINVAL;
     if (K % BK) return MR_EUNSUPPORTED;
     if (nseg > 1 && (seg_n % 128)) return MR_EUNSUPPORTED;
@@ -533,15 +582,20 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
     const size_t shm = 2 * (size_t)(3 * PIECE + 3 * (BN / 128) * PIECE) + shm_pad;  // 48 KB (narrow) / 72 KB (wide)
     // (three pieces + 128 accumulators + two staging sets do not fit 256 VGPRs: the wide x6 kernel prefetches one tile ahead)
     const bool pf2 = ((K / BK) % 2 == 0) && !(wide && products == 6);
-#define MR_GEMM_LAUNCH5(ACT_, HASR_, PF2_, NP_, NT_)                                                                                  \
-    do {                                                                                                                              \
-        static mr::DynLdsCeiling lds_ceiling;                                                                                         \
-        if (const int e_ = lds_ceiling.ensure(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_>),     \
-                                              2 * (3 * PIECE + 3 * (NT_ / 2) * PIECE) + shm_pad))                                     \
-            return e_;                                                                                                                \
-        hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_>), dim3(nwg), dim3(kThreads), shm, st, A, lda, w_hi,     \
-                           w_mid, w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg, group_n,  \
-                           tiles_m);                                                                                                  \
+#define MR_GEMM_LAUNCH6(ACT_, HASR_, PF2_, NP_, NT_, F16_)                                                                                \
+    do {                                                                                                                                  \
+        static mr::DynLdsCeiling lds_ceiling;                                                                                             \
+        if (const int e_ = lds_ceiling.ensure(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_, false, F16_>), \
+                                              2 * (3 * PIECE + 3 * (NT_ / 2) * PIECE) + shm_pad))                                         \
+            return e_;                                                                                                                    \
+        hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<ACT_, HASR_, PF2_, NP_, NT_, false, F16_>), dim3(nwg), dim3(kThreads), shm, st, A, lda,  \
+                           w_hi, w_mid, w_lo, off0, off1, off2, b0, b1, b2, M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg,        \
+                           group_n, tiles_m);                                                                                             \
+    } while (0)
+#define MR_GEMM_LAUNCH5(ACT_, HASR_, PF2_, NP_, NT_)                           \
+    do {                                                                       \
+        if (NP_ == 2 && f16) MR_GEMM_LAUNCH6(ACT_, HASR_, PF2_, 2, NT_, true); \
+        else MR_GEMM_LAUNCH6(ACT_, HASR_, PF2_, NP_, NT_, false);              \
     } while (0)
 #define MR_GEMM_LAUNCH4(ACT_, HASR_, PF2_, NP_)                           \
     do {                                                                  \
@@ -567,6 +621,7 @@ extern "C" int mr_gemm_nt_bf16x6_f32(const float* A, int64_t lda, const uint16_t
 #undef MR_GEMM_LAUNCH3
 #undef MR_GEMM_LAUNCH4
 #undef MR_GEMM_LAUNCH5
+#undef MR_GEMM_LAUNCH6
     return mr::check_launch();
 }
 

@@ -376,6 +376,15 @@ extern "C" size_t mr_merge_bwd_alpha_ws_bytes(int N, int S, int64_t P) {
     return (size_t)(S + 1) * sizeof(int64_t) + 64 + (size_t)nchunk * N * sizeof(float);
 }
 
+// A/B and the bit-identity test: 1 = the per-vector loop for every N.  Initial value from MR_MERGE_BWD_GENERIC, read ONCE at load;
+// mr_merge_bwd_generic() changes it at run time (tests, tools/merge_bwd_bench.py) and returns the previous value.
+static int g_bwd_generic = [] { const char* e = getenv("MR_MERGE_BWD_GENERIC"); return (e && e[0] == '1') ? 1 : 0; }();
+extern "C" int mr_merge_bwd_generic(int on) {
+    const int old = g_bwd_generic;
+    if (on == 0 || on == 1) g_bwd_generic = on;
+    return old;
+}
+
 extern "C" int mr_merge_bwd_alpha_f32(const float* tv, int64_t tv_stride, const float* g, const int64_t* seg_off, int N,
                                       int S, int64_t P, float* dalpha, void* ws, size_t ws_bytes, mr_stream_t stream) {
     if (!tv || !g || !dalpha || !ws || N < 1 || S < 1 || P < 0) return MR_EINVAL;
@@ -390,8 +399,7 @@ extern "C" int mr_merge_bwd_alpha_f32(const float* tv, int64_t tv_stride, const 
     hipLaunchKernelGGL(merge_bwd_prologue, dim3(1), dim3(64), 0, st, seg_off, S, P, chunk_first);
     // exact chunk count is only known on device; launch the upper bound and let surplus blocks write zeros
 #define MR_BWD1(NN_) hipLaunchKernelGGL(merge_bwd_stage1_n<NN_>, dim3((unsigned)nchunk), dim3(kThreads), 0, st, tv, tv_stride, g, seg_off, S, P, chunk_first, partial)
-    const char* generic = getenv("MR_MERGE_BWD_GENERIC");  // A/B and the bit-identity test: the per-vector loop for every N (read per call)
-    switch ((generic && generic[0] == '1') ? 0 : N) {
+    switch (g_bwd_generic ? 0 : N) {
         case 1: MR_BWD1(1); break;
         case 2: MR_BWD1(2); break;
         case 3: MR_BWD1(3); break;

@@ -213,11 +213,7 @@ __global__ __launch_bounds__(kThreads, 1) void score_part_topk_kernel(const floa
         SF_GLOAD(y, (1 <= last ? 1 : 0) * SBK);
         SF_GLOAD(x, (2 <= last ? 2 : 0) * SBK);
         __syncthreads();
-#ifdef SF_ABL_NOGEMM     // timing ablation: one k-tile pair only (wrong results)
-        for (int kt = 0; kt < 2; kt += 2) {
-#else
         for (int kt = 0; kt < nk; kt += 2) {   // nk even (host-checked); past-the-end prefetches re-read tile 0 and are never consumed
-#endif
             SF_COMPUTE(buf0);
             __builtin_amdgcn_sched_barrier(0);
             SF_LSTORE(y, buf1);
@@ -253,11 +249,7 @@ __global__ __launch_bounds__(kThreads, 1) void score_part_topk_kernel(const floa
         const int row = m0 + r;
         if (row >= nU) break;  // wave-uniform
         const float* s = strip + r * PART;
-#ifdef SF_ABL_NOSELECT   // timing ablation: no selection (wrong results)
-        const unsigned long long v = ((unsigned long long)ord_key(s[lane]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)(c_begin + lane));
-#else
         const unsigned long long v = wave_topk(s, ncols, k, c_begin, hist, slots, lane);
-#endif
         const int64_t base = ((int64_t)row * P + part) * k;
         if (lane < k) {
             cand[base + lane] = v;

@@ -173,13 +173,25 @@ class ArenaLayout:
         return groups, seg_off, seg_gid
 
 
-GEMM_MODES = ("f32", "bf16x6", "bf16x3")
+GEMM_MODES = ("f32", "bf16x6", "f16x3", "bf16x3")
+_PRODUCTS = {"f32": 0, "bf16x6": 6, "bf16x3": 3, "f16x3": ops.PRODUCTS_F16X3}
+
+
+def _attn_products(mode: str) -> int:
+    """products of the attention kernels for an encoder arithmetic (0 = exact fp32).  MERGEREC_ATTN_PRODUCTS overrides it for error
+    attribution runs (tests/tools/trained_like_attribution.py: which half of an arithmetic's distance is the linears', which attention's)."""
+    import os
+
+    o = os.environ.get("MERGEREC_ATTN_PRODUCTS")
+    return int(o) if o in ("0", "3", "6", "35") else _PRODUCTS[mode]
 
 
 def default_gemm_mode() -> str:
     """Encoder GEMM arithmetic: "bf16x6" = six bf16 MFMA products per fp32 product (fp32-grade accuracy, 2.67x fewer
-    matrix-pipe cycles; the default), "bf16x3" = three products (two pieces per operand, ~2^-16 per product: measured
-    ~2e-6 on BLaIR-base embeddings), "f32" = exact fp32 MFMA (bit-identical to the oracle's FMA chain)."""
+    matrix-pipe cycles; the library default: no range limits), "f16x3" = three products of two FP16 pieces per operand (~2^-21 per
+    product at bf16x3's cost; fp32-grade on trained-like weights, fixture g22; operands must stay inside fp16's range -- activations
+    |x| < 65504, weights |w| < 255.9, checked), "bf16x3" = three products of two bf16 pieces (~2^-16 per product: inside 1e-4 on
+    init-like weights, NOT on trained-like ones -- opt-in only), "f32" = exact fp32 MFMA (bit-identical to the oracle's FMA chain)."""
     import os
 
     m = os.environ.get("MERGEREC_GEMM_MODE", "bf16x6")
@@ -200,6 +212,7 @@ class WeightSet:
             raise ValueError(f"gemm mode must be one of {GEMM_MODES}")
         self.pieces = None
         self._table = None
+        self._overflow = None  # f16x3: device flag raised by the weight split when a scaled weight leaves fp16's range
 
     def __getitem__(self, k):
         return self.views[k]
@@ -211,13 +224,26 @@ class WeightSet:
         return self.layout.offsets[name]
 
     def refresh(self):
-        if self.mode in ("bf16x6", "bf16x3"):
+        if self.mode in ("bf16x6", "bf16x3", "f16x3"):
             if self._table is None:  # every 2-D tensor a Linear reads (not the embedding tables), K % 16 == 0
                 ent = [(self.layout.offsets[k], shp[0], shp[1]) for k, shp in self.layout.shapes.items()
                        if len(shp) == 2 and "embeddings" not in k and shp[1] % 16 == 0]
                 self._table = ops.KBlockTable(ent, self.flat.device)
-            self.pieces = ops.split_weights_kblock(self.flat, self._table, self.pieces, n_pieces=3 if self.mode == "bf16x6" else 2)
+            if self.mode == "f16x3":
+                if self._overflow is None:
+                    self._overflow = torch.zeros(1, dtype=torch.int32, device=self.flat.device)
+                self.pieces = ops.split_weights_kblock(self.flat, self._table, self.pieces, f16=True, overflow=self._overflow)
+            else:
+                self.pieces = ops.split_weights_kblock(self.flat, self._table, self.pieces, n_pieces=3 if self.mode == "bf16x6" else 2)
         return self
+
+    def check_range(self):
+        """f16x3 only: raise if a weight split since the last call met a value outside fp16's range (one device read; the evaluation
+        loops call it where they synchronise anyway, through ``EncoderRunner.check_inputs``)."""
+        if self._overflow is not None and int(self._overflow.item()):
+            self._overflow.zero_()
+            raise InputError("a weight matrix holds |w| >= 255.9 (or NaN): outside the fp16 pieces of the 'f16x3' arithmetic -- "
+                             "use gemm_mode='bf16x6' (no range limit) for this model")
 
     @staticmethod
     def from_views(views: Dict[str, torch.Tensor]) -> "WeightSet":
@@ -375,11 +401,11 @@ class EncoderRunner:
             for i, (wn_, bn_) in enumerate(zip(wnames, bnames)):
                 self._linear(w, x, [wn_], [bn_], act, None, out[:, i * seg_n : (i + 1) * seg_n])
             return out
-        if w.mode in ("bf16x6", "bf16x3"):
+        if w.mode in ("bf16x6", "bf16x3", "f16x3"):
             if w.pieces is None:
                 w.refresh()
             return ops.gemm_nt_split(x, w.pieces, [w.offset(n) for n in wnames], seg_n, K, biases, act, residual, out,
-                                     products=6 if w.mode == "bf16x6" else 3)
+                                     products=_PRODUCTS[w.mode])
         return ops.gemm_nt(x, [w[n] for n in wnames], biases, act, residual, out)
 
     def _proj(self, w, lp, names, x):
@@ -410,7 +436,7 @@ class EncoderRunner:
             chain = ops.PROF.chain if (self.fuse_qkv and not rec) else (lambda: None)  # back-to-back launches: shared event stamps
             chain()
             ctx = ops.attention(qkv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, window=sp.one_sided_window if rec else -1,
-                                seq_order=pb.seq_order, products={"f32": 0, "bf16x6": 6, "bf16x3": 3}[w.mode], work=pb.attn_work)
+                                seq_order=pb.seq_order, products=_attn_products(w.mode), work=pb.attn_work)
             if rec:
                 qg = self._proj(w, lp, ("query_global",), ops.gather_rows(x, pb.cls_rows))
                 kvg = self._proj(w, lp, ("key_global", "value_global"), x)

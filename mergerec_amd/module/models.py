@@ -161,7 +161,7 @@ class BaseEncoderModel(nn.Module):
         self._views = self._weights.views
 
     def set_gemm_mode(self, mode: Optional[str]):
-        """Switch the encoder GEMM / attention arithmetic ("f32", "bf16x6", "bf16x3"; None keeps the current one)."""
+        """Switch the encoder GEMM / attention arithmetic ("f32", "bf16x6", "f16x3", "bf16x3"; None keeps the current one)."""
         if mode is None or mode == self._weights.mode:
             return
         from ..engine import GEMM_MODES
@@ -236,6 +236,7 @@ class BaseEncoderModel(nn.Module):
         unattended CLS position or an unsupported global-attention pattern.  The checks run inside the packing kernel (no host sync
         per batch); this is the one device read that surfaces them -- the evaluation loops call it at their epoch ends."""
         self.runner.check_inputs()
+        self._weights.check_range()  # f16x3: a weight outside fp16's range met by a weight split since the last call
 
 
 def random_init_state_dict(spec: EncoderSpec, seed: int, std: float = 0.02) -> "OrderedDict[str, torch.Tensor]":

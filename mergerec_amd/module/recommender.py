@@ -255,7 +255,10 @@ class RecModule(_Base):
                 raise IndexError(f"Target {int(self.eval_labels[bad][0])} is out of bounds.")
         self.eval_scores = scores
         if scores is None and self.item_embeddings is not None and (shard is None or shard.world == 1 or shard.rank == 0):
-            self._eval_scores_lazy = (self.eval_user_embeddings, self.item_embeddings.data)  # materialised on first access
+            # materialised on first access from a SNAPSHOT of the table the kernel ranked (a device copy: tens of MB at HBM rate, once
+            # per epoch): the live table may be rewritten in place before anyone asks (a catalog refresh, the next domain's encode), and
+            # upstream's eval_scores stays what the epoch computed (module.py:344-352) whatever happens to item_embeddings afterwards
+            self._eval_scores_lazy = (self.eval_user_embeddings, self.item_embeddings.data.clone())
         # cross_entropy(scores / T, labels) = mean(logsumexp(row / T) - row[label] / T)   (module.py:318, 356)
         loss = float((lse.double() - lab.double()).mean()) if lse.numel() else float("nan")
         metrics = self.evaluator.from_ranks(ranks, metric_prefix=prefix)

@@ -351,15 +351,26 @@ class KBlockTable:
         self.bytes = sum(n * k for _, n, k in ent) * 10.0  # 4 B read + 3 x 2 B written per element
 
 
-def split_weights_kblock(flat: torch.Tensor, table: KBlockTable, pieces=None, n_pieces: int = 3):
+PRODUCTS_F16X3 = 35  # include/mergerec_hip.h MR_PRODUCTS_F16X3: two fp16 pieces per operand, three products
+
+
+def split_weights_kblock(flat: torch.Tensor, table: KBlockTable, pieces=None, n_pieces: int = 3, f16: bool = False, overflow=None):
     """fp32 arena -> bf16 piece arenas (same length) holding the listed matrices in k-blocked form.  n_pieces = 2: only (hi, mid)
-    are produced -- all that the three-product GEMMs read -- and the returned tuple's third entry is None."""
+    are produced -- all that the three-product GEMMs read -- and the returned tuple's third entry is None.  f16: the two FP16 pieces of
+    256 w for the "f16x3" arithmetic (``overflow``: device int32 flag the kernel raises when a scaled weight leaves fp16's range)."""
     _dev(flat, "flat", torch.float32)
-    if pieces is None or sum(p is not None for p in pieces) != n_pieces:
-        pieces = tuple(torch.zeros(flat.numel(), dtype=torch.bfloat16, device=flat.device) if i < n_pieces else None for i in range(3))
+    dt = torch.float16 if f16 else torch.bfloat16
+    if f16:
+        n_pieces = 2
+    if pieces is None or sum(p is not None for p in pieces) != n_pieces or pieces[0].dtype != dt:
+        pieces = tuple(torch.zeros(flat.numel(), dtype=dt, device=flat.device) if i < n_pieces else None for i in range(3))
     ev = PROF.begin(flat.device)
-    check(_lib.load().mr_split_weights_kblock_f32(ptr(flat), ptr(table.table), ptr(table.prefix), table.n_mat, table.total_units,
-                                                  ptr(pieces[0]), ptr(pieces[1]), ptr(pieces[2]), _stream(flat)), "mr_split_weights_kblock_f32")
+    if f16:
+        check(_lib.load().mr_split_weights_kblock_f16_f32(ptr(flat), ptr(table.table), ptr(table.prefix), table.n_mat, table.total_units,
+                                                          ptr(pieces[0]), ptr(pieces[1]), ptr(overflow), _stream(flat)), "mr_split_weights_kblock_f16_f32")
+    else:
+        check(_lib.load().mr_split_weights_kblock_f32(ptr(flat), ptr(table.table), ptr(table.prefix), table.n_mat, table.total_units,
+                                                      ptr(pieces[0]), ptr(pieces[1]), ptr(pieces[2]), _stream(flat)), "mr_split_weights_kblock_f32")
     PROF.end(ev, flat.device, "split_weights", nbytes=table.bytes * (4 + 2 * n_pieces) / 10.0)
     return pieces
 
@@ -384,7 +395,7 @@ def gemm_nt_split(A: torch.Tensor, pieces, offsets: Sequence[int], seg_n: int, K
             products, _stream(A)),
         "mr_gemm_nt_bf16x6_f32",
     )
-    PROF.end(ev, A.device, "gemm_nt_bf16x6" if products == 6 else "gemm_nt_bf16x3", flops=2.0 * M * nseg * seg_n * K,
+    PROF.end(ev, A.device, {6: "gemm_nt_bf16x6", 3: "gemm_nt_bf16x3", PRODUCTS_F16X3: "gemm_nt_f16x3"}[products], flops=2.0 * M * nseg * seg_n * K,
              nbytes=4.0 * (M * K + M * nseg * seg_n * (2 if residual is not None else 1)) + 6.0 * nseg * seg_n * K)
     return out
 
@@ -433,17 +444,18 @@ def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_l
     use_list = bool(work) and os.environ.get("MR_ATTN_WORKLIST", "1") != "0"
     lib = _lib.load()
     if products and use_list and (drop_p == 0.0 or products == 3) and work.get(attn_q_rows(window, products)) is not None:
-        wl = work[attn_q_rows(window, products)]
+        qr = attn_q_rows(window, products)  # the list's key IS the block height it was planned with; the entry point checks it (and B)
+        wl = work[qr]
         if drop_p > 0.0:
-            check(lib.mr_attn_split_work_train_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, products, drop_p, drop_key,
+            check(lib.mr_attn_split_work_train_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], B, qr, H, dh, dh ** -0.5, window, products, drop_p, drop_key,
                                                    ptr(out), _stream(qkv)), "mr_attn_split_work_train_f32")
         else:
-            check(lib.mr_attn_split_work_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, products, ptr(out), _stream(qkv)),
+            check(lib.mr_attn_split_work_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], B, qr, H, dh, dh ** -0.5, window, products, ptr(out), _stream(qkv)),
                   "mr_attn_split_work_f32")
     elif (not products or drop_p > 0.0) and use_list and work.get(128) is not None:
         # exact-fp32 kernel on the work list (also the route of a dropout launch in the six-product mode, which has no dropout variant)
         wl = work[128]
-        check(lib.mr_attn_work_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, dh, dh ** -0.5, window, float(drop_p), drop_key, ptr(out), _stream(qkv)),
+        check(lib.mr_attn_work_f32(ptr(qkv), ptr(cu_seqlens), ptr(wl[0]), wl[1], B, 128, H, dh, dh ** -0.5, window, float(drop_p), drop_key, ptr(out), _stream(qkv)),
               "mr_attn_work_f32")
     elif drop_p > 0.0:
         check(lib.mr_attn_train_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, drop_p, drop_key, ptr(out), _stream(qkv)),
@@ -453,7 +465,8 @@ def attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor, B: int, H: int, max_l
               "mr_attn_split_f32")
     else:
         check(lib.mr_attn_f32(ptr(qkv), ptr(cu_seqlens), ptr(seq_order), B, H, dh, max_len, dh ** -0.5, window, ptr(out), _stream(qkv)), "mr_attn_f32")
-    PROF.end(ev, qkv.device, "attention" if not products else f"attention_bf16x{products}", flops=ATTN_FLOPS_HINT[0], nbytes=4.0 * T * 4 * H * dh)
+    PROF.end(ev, qkv.device, {0: "attention", 3: "attention_bf16x3", 6: "attention_bf16x6", PRODUCTS_F16X3: "attention_f16x3"}[products],
+             flops=ATTN_FLOPS_HINT[0], nbytes=4.0 * T * 4 * H * dh)
     ATTN_FLOPS_HINT[0] = 0.0
     return out
 
@@ -713,7 +726,7 @@ def attention_bwd(qkv: torch.Tensor, ctx: torch.Tensor, dctx: torch.Tensor, cu_s
     ev = PROF.begin(qkv.device)
     wl = work.get(128) if work else None
     if wl is not None and os.environ.get("MR_ATTN_WORKLIST", "1") != "0":  # the (sequence, 128-row block) pairs that exist: no empty workgroups
-        check(_lib.load().mr_attn_bwd_work_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), ptr(wl[0]), wl[1], H, 64, 0.125 if scale is None else scale,
+        check(_lib.load().mr_attn_bwd_work_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), ptr(wl[0]), wl[1], B, 128, H, 64, 0.125 if scale is None else scale,
                                                window, float(drop_p), drop_key, ptr(rowstat), ptr(dqkv), _stream(qkv)), "mr_attn_bwd_work_f32")
     elif drop_p > 0.0:
         check(_lib.load().mr_attn_bwd_train_f32(ptr(qkv), ptr(ctx), ptr(dctx), ptr(cu_seqlens), ptr(seq_order), B, H, 64, max_len,

@@ -33,15 +33,17 @@ def load_alpha_file(path: Path, line: int) -> dict:
 
 
 def precision_to_gemm_mode(precision) -> Optional[str]:
-    """Lightning precision flag -> encoder arithmetic.  "32-true" keeps the model's mode (library default bf16x6: fp32-grade).  The
-    reference's default "bf16-mixed" (torch autocast: 8-bit-mantissa products) maps to "bf16x3", the fastest arithmetic built -- three
-    bf16 MFMA products per fp32 product, ~1e-6 on the embeddings, i.e. orders of magnitude tighter than what that flag asks for."""
+    """Lightning precision flag -> encoder arithmetic.  "32-true" keeps the model's mode (library default bf16x6: fp32-grade, no range
+    limits).  The reference's default "bf16-mixed" (torch autocast: 8-bit-mantissa products) maps to "f16x3" -- three fp16 MFMA products
+    per fp32 product, ~2^-21 each: at the reference's own fp32 rounding level on trained-like weights (fixture g22), orders of magnitude
+    tighter than what that flag asks for, at the cost of the former choice "bf16x3" (2^-16 per product: 10x the fp32 noise on g22;
+    still selectable through ``gemm_mode`` / MERGEREC_GEMM_MODE)."""
     p = str(precision)
     if p in ("32-true", "32"):
         return None
     if p in ("bf16-mixed", "bf16", "16-mixed", "16", "bf16-true", "16-true"):
-        print(f"precision={p!r}: running the bf16x3 split-precision kernels (fp32 accumulation; stricter than autocast {p})")
-        return "bf16x3"
+        print(f"precision={p!r}: running the f16x3 split-precision kernels (fp32 accumulation; stricter than autocast {p})")
+        return "f16x3"
     if p in ("64-true", "64"):
         raise NotImplementedError("fp64 is not built")
     raise ValueError(f"unknown precision {precision!r}")

@@ -436,7 +436,7 @@ def longformer_layer(p: StateDict, lp: str, x: torch.Tensor, mask012: torch.Tens
     allowed = key_local | is_global[:, None, :]
     s = q @ k.transpose(-1, -2)  # (B,H,L,L)
     s = s.masked_fill(~allowed[:, None, :, :], float("-inf"))
-    pr = torch.softmax(s.float(), dim=-1)
+    pr = torch.softmax(s.to(torch.promote_types(s.dtype, torch.float32)), dim=-1)  # HF: softmax in (at least) fp32; float64 inputs (truth runs) stay float64
     pr = torch.nan_to_num(pr, nan=0.0)
     pr = pr.masked_fill(is_masked[:, None, :, None], 0.0)
     if drop is not None:
@@ -449,7 +449,7 @@ def longformer_layer(p: StateDict, lp: str, x: torch.Tensor, mask012: torch.Tens
         vg = proj("value_global", x)
         sg = qg @ kg.transpose(-1, -2)
         sg = sg.masked_fill(is_masked[:, None, None, :], torch.finfo(sg.dtype).min)
-        pg = torch.softmax(sg.float(), dim=-1)
+        pg = torch.softmax(sg.to(torch.promote_types(sg.dtype, torch.float32)), dim=-1)
         if drop is not None:
             pg = drop.global_probs(pg, layer)
         cg = pg @ vg

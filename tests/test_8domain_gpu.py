@@ -3,7 +3,7 @@ of BLaIR-base at true dimensions) evaluated on every domain's full catalog (4,96
 
 Fixture: tests/golden/g13_8domain_blair_base.pt, produced in the build container by oracle/gen_golden_8domain.py from the reference itself
 (its load_merging_module / get_state_dict, transformers' RobertaModel, user @ item.T, its Evaluator; CPU, fp32).  Inputs are regenerated from
-seeds here.  Checked per domain, in the product's default arithmetic (bf16x3) through the drop-in evaluation loop: user embeddings, sampled
+seeds here.  Checked per domain, in the arithmetic the reference's default precision flag selects (bf16-mixed -> f16x3) through the drop-in evaluation loop: user embeddings, sampled
 item rows and their logits within 1e-4; the ranked top-50 equal to the reference's up to its own near-ties (2e-6); label ranks equal up to
 near-ties; every Recall / NDCG value within 1e-3; the loss within 1e-3."""
 
@@ -81,7 +81,7 @@ def test_all_eight_domains_match_the_reference(merged, tmp_path):
             at += n
         _, metrics, scores, labels = test_model_on_dataloaders(module, [dom.item_batches], [seqs], [name], precision="bf16-mixed",
                                                                predictions_path=tmp_path / f"{name}.pt")
-        assert model._weights.mode == "bf16x3"
+        assert model._weights.mode == "f16x3"
         got, E, U = scores[0], module.item_embeddings.detach().cpu(), module.eval_user_embeddings.detach().cpu()
         assert got.shape == (n_users, d["n_items"]) and torch.equal(labels[0], d["labels"])
         # (1) embeddings, catalog checksum, logits on the sampled columns

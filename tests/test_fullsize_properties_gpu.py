@@ -93,7 +93,7 @@ def test_full_catalog_topk_order_statistics():
     torch.testing.assert_close(lab, lab_score.view(-1) * 20.0, rtol=1e-6, atol=0)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x3", "f32"])
 def test_encoder_is_invariant_to_batch_composition_at_full_size(arena, mode):
     """~69 k packed tokens (256 users + 128 items, Amazon-shaped lengths): a sequence's embedding does not depend on what else is in
     the batch, on its position in it, or on the padding it arrived with -- bit for bit"""

@@ -82,16 +82,16 @@ def test_merge_bwd_alpha(ops):
     assert torch.allclose(one[0], O.merge_bwd_alpha(tv, gr), rtol=1e-4, atol=2e-2)
     # the single-pass kernel (N <= 8: every stream of a chunk in flight at once) keeps each sum's operation order: equal, bit for bit, to
     # the per-vector loop that larger N still use -- for every N, with segments whose last chunk is ragged and shorter than a chunk
-    import os
+    from mergerec_amd import _lib
 
     for n in (1, 2, 3, 5, 8):
         tvn = torch.randn(n, P, generator=g).to(DEV)
         fast = ops.merge_bwd_alpha(tvn, gr.to(DEV), seg_off.to(DEV)).cpu()
-        os.environ["MR_MERGE_BWD_GENERIC"] = "1"
+        assert _lib.load().mr_merge_bwd_generic(1) == 0
         try:
             slow = ops.merge_bwd_alpha(tvn, gr.to(DEV), seg_off.to(DEV)).cpu()
         finally:
-            del os.environ["MR_MERGE_BWD_GENERIC"]
+            assert _lib.load().mr_merge_bwd_generic(0) == 1
         assert torch.equal(fast, slow), n
 
 
@@ -151,6 +151,55 @@ def test_gemm_bf16x6_split_precision(ops, M, N, K):
     got = ops.gemm_nt_split(A.to(DEV), pieces, [off], N, K, [b.to(DEV)], act=ops.ACT_GELU, residual=R.to(DEV)).cpu()
     want = torch.nn.functional.gelu(ref.float()) + R
     assert torch.allclose(got, want, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 768, 768), (257, 200, 3072), (64, 333, 16), (300, 896, 64), (6656, 2560, 32)])
+def test_gemm_f16x3_split_precision(ops, M, N, K):
+    """f16x3 (r04): two FP16 pieces per operand, three products.  The weight pieces hold 256 w (exact scale, undone in the epilogue) so that
+    the low piece of a 0.01..0.1 weight is a normal fp16 number; activations are split unscaled, their low pieces may be fp16 subnormals,
+    which the matrix pipe honours.  Error ~2^-21 per product: 30x tighter than bf16x3's bound at the same matrix-pipe cost; tiny and huge
+    (but in-range) operands included."""
+    g = _g(M * 5 + N + K)
+    A, b = torch.randn(M, K, generator=g), torch.randn(N, generator=g)
+    A[::7] *= 1e-3          # rows of small activations: low pieces in fp16's subnormal range
+    A[1::11, ::13] *= 300.0  # massive activations
+    arena = torch.zeros(64 * 5 + N * K + 64)
+    off = 64 * 5
+    W = torch.randn(N, K, generator=g) * 0.05
+    W[::5] *= 1e-3
+    arena[off : off + N * K] = W.reshape(-1)
+    ad = arena.to(DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    pieces = ops.split_weights_kblock(ad, ops.KBlockTable([(off, N, K)], DEV), f16=True, overflow=flag)
+    assert pieces[0].dtype == torch.float16 and pieces[2] is None and int(flag.item()) == 0
+    kb = lambda p: p.float().cpu()[off : off + N * K].view(K // 16, N, 16).permute(1, 0, 2).reshape(N, K)
+    hi, lo = kb(pieces[0]), kb(pieces[1])
+    assert torch.equal(hi, (W * 256).to(torch.float16).float())                      # hi = fp16(256 w), round-to-nearest-even
+    assert torch.equal(lo, (W * 256 - hi).to(torch.float16).float())                 # lo = fp16 of the exact remainder
+    assert float(((hi + lo) / 256 - W).abs().max()) <= 2.0 ** -21 * float(W.abs().max())
+    got = ops.gemm_nt_split(A.to(DEV), pieces, [off], N, K, [b.to(DEV)], products=ops.PRODUCTS_F16X3).cpu()
+    ref = (A.double() @ W.double().T + b.double())
+    scale = (A.abs().double() @ W.abs().double().T).max()
+    err = float((got.double() - ref).abs().max() / scale)
+    assert err <= 2.0 ** -20, err
+    x3 = ops.gemm_nt_split(A.to(DEV), ops.split_weights_kblock(ad, ops.KBlockTable([(off, N, K)], DEV), n_pieces=2), [off], N, K, [b.to(DEV)], products=3).cpu()
+    err3 = float((x3.double() - ref).abs().max() / scale)
+    print(f"[{M}x{N}x{K}] max |err| / max sum|a||w|: f16x3 {err:.2e} (2^{math.log2(err + 1e-300):.1f}), bf16x3 {err3:.2e} (2^{math.log2(err3 + 1e-300):.1f})")
+    R = torch.randn(M, N, generator=g)
+    got = ops.gemm_nt_split(A.to(DEV), pieces, [off], N, K, [b.to(DEV)], act=ops.ACT_GELU, residual=R.to(DEV), products=ops.PRODUCTS_F16X3).cpu()
+    want = torch.nn.functional.gelu(ref.float()) + R
+    assert float((got - want).abs().max()) <= 2.0 ** -19 * float(scale) + 2e-6
+
+
+def test_f16x3_weight_range_is_checked(ops):
+    """a weight whose 256-fold value leaves fp16's range (|w| >= 255.9) or a NaN raises the split's overflow flag; in-range extremes do not"""
+    n, K = 128, 64
+    for val, bad in ((255.0, False), (256.0, True), (float("nan"), True), (-255.8, False), (-1e4, True)):
+        arena = torch.zeros(n * K)
+        arena[1234] = val
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.split_weights_kblock(arena.to(DEV), ops.KBlockTable([(0, n, K)], DEV), f16=True, overflow=flag)
+        assert bool(flag.item()) == bad, val
 
 
 def test_gemm_bf16x6_segments(ops):
@@ -257,6 +306,41 @@ def _attn_ref(qkv, cu, H, window=-1):
     return out
 
 
+SPLIT_UNIT = {3: 2.0 ** -15, 6: 2.0 ** -22, 35: 2.0 ** -20}   # per-product relative error of the split arithmetics (two / three bf16 pieces
+                                               # per operand: 2^-17 / 2^-25 representation error per operand plus the dropped low x low products,
+                                               # doubled; 35 = f16x3: two fp16 pieces, 2^-23 + 2^-22)
+
+
+def _attn_split_bound(qkv, cu, H, window, products):
+    """A-priori error bound of split-precision attention DERIVED FROM THE INPUTS (fp64 on the host), per output element:
+    logit error  delta_i <= u * scale * max_j sum_k |q_ik| |k_jk|;  softmax under a logit perturbation of at most delta:
+    |p~_ij - p_ij| <= p_ij * expm1(2 delta_i);  P V evaluated with per-product error u:
+        |o~_id - o_id| <= (expm1(2 delta_i) + u) * sum_j p_ij |v_jd|   (+ fp32 accumulation: 64 ulp of the same sum).
+    It scales with the logits' magnitude -- peaky (trained-like) rows get a wider bound than unit-variance ones -- instead of one
+    absolute constant tuned on unit-variance inputs."""
+    u = SPLIT_UNIT[products]
+    qkv = qkv.double()
+    T, d3 = qkv.shape
+    d = d3 // 3
+    dh = d // H
+    bound = torch.zeros(T, d, dtype=torch.float64)
+    for b in range(len(cu) - 1):
+        a, e = int(cu[b]), int(cu[b + 1])
+        L = e - a
+        q, k, v = (qkv[a:e, i * d:(i + 1) * d].view(L, H, dh).transpose(0, 1) for i in range(3))
+        s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+        mag = (q.abs() @ k.abs().transpose(-1, -2)) * dh ** -0.5
+        if window >= 0:
+            i = torch.arange(L)
+            ok = ((i[:, None] - i[None, :]).abs() <= window) | (i[None, :] == 0)
+            s = s.masked_fill(~ok[None], float("-inf"))
+            mag = mag.masked_fill(~ok[None], 0.0)
+        delta = u * mag.max(-1, keepdim=True).values
+        pv = torch.softmax(s, -1) @ v.abs()
+        bound[a:e] = ((torch.expm1(2 * delta) + u + 64 * 2.0 ** -24) * pv).transpose(0, 1).reshape(L, d)
+    return bound
+
+
 @pytest.mark.parametrize("H,lens", [(12, [512, 1, 33, 40, 257]), (4, [5, 64, 31, 32, 96])])
 def test_attention_full(ops, H, lens):
     g = _g(H)
@@ -268,25 +352,32 @@ def test_attention_full(ops, H, lens):
     assert torch.allclose(got, want, atol=3e-6, rtol=1e-5), (got - want).abs().max()
 
 
-@pytest.mark.parametrize("products,tol", [(3, 3e-4), (6, 5e-6)])
+@pytest.mark.parametrize("products", [3, 6, 35])
 @pytest.mark.parametrize("window", [-1, 4, 32])
-def test_attention_split_precision(ops, products, tol, window):
+@pytest.mark.parametrize("qk_scale", [1.0, 2.5])   # 2.5: pre-softmax logits with sigma ~ 6 and |max| ~ 35 -- peaky rows, the rescale path taken
+def test_attention_split_precision(ops, products, window, qk_scale):
+    """Split-precision attention against fp64, inside the bound DERIVED from the inputs (``_attn_split_bound``), for unit-variance and
+    for peaky (trained-like) logits; the observed error / bound ratio is printed."""
     g = _g(100 + products + window)
     H, lens = 4, [300, 1, 2, 70, 33, 129, 512]
     cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
     T = int(cu[-1])
     qkv = torch.randn(T, 3 * H * 64, generator=g)
+    qkv[:, : 2 * H * 64] *= qk_scale
     ctx = torch.full((T, H * 64), 7.5, device=DEV)
     ops.attention(qkv.to(DEV), cu.to(DEV), len(lens), H, max(lens), window=window, out=ctx, products=products)
-    got, want = ctx.cpu(), _attn_ref(qkv, cu, H, window)
+    got, want = ctx.cpu().double(), _attn_ref(qkv.double(), cu, H, window)
+    bound = _attn_split_bound(qkv, cu, H, window, products)
     keep = torch.ones(T, dtype=torch.bool)
     if window >= 0:
         keep[cu[:-1].long()] = False
-        assert bool((got[~keep] == 7.5).all())
-    assert torch.allclose(got[keep], want[keep], atol=tol, rtol=tol), (got[keep] - want[keep]).abs().max()
+        assert bool((ctx.cpu()[~keep] == 7.5).all())
+    err = (got - want).abs()[keep]
+    assert bool((err <= bound[keep]).all()), float((err / bound[keep]).max())
+    print(f"[products {products} window {window} qk x{qk_scale}] max |err| {float(err.max()):.2e}; bound max {float(bound[keep].max()):.2e}; worst err / bound {float((err / bound[keep]).max()):.3f}")
 
 
-@pytest.mark.parametrize("products", [0, 3, 6])
+@pytest.mark.parametrize("products", [0, 3, 6, 35])
 @pytest.mark.parametrize("window", [-1, 4, 32])
 def test_attention_work_list_is_bit_identical_to_the_box_grid(ops, products, window):
     """mr_attn_work_f32 (products = 0: the exact-fp32 kernel) / mr_attn_split_work_f32 (host-built (sequence, query block) list, 256-row blocks with two query tiles per wave for full attention in
@@ -315,8 +406,10 @@ def test_attention_work_list_is_bit_identical_to_the_box_grid(ops, products, win
     if window >= 0:
         keep[cu[:-1].long()] = False
         assert bool((lst.cpu()[~keep] == 7.5).all())
-    tol = 3e-4 if products == 3 else 5e-6
-    assert torch.allclose(lst.cpu()[keep], want[keep], atol=tol, rtol=tol)
+    if products:
+        assert bool(((lst.cpu().double() - _attn_ref(qkv.cpu().double(), cu, H, window)).abs()[keep] <= _attn_split_bound(qkv.cpu(), cu, H, window, products)[keep]).all())
+    else:
+        assert torch.allclose(lst.cpu()[keep], want[keep], atol=5e-6, rtol=5e-6)
 
 
 def test_attention_work_plan_rejects_bad_arguments(ops):
@@ -328,6 +421,38 @@ def test_attention_work_plan_rejects_bad_arguments(ops):
         ops.attn_work_plan(torch.tensor([5]), 64)
     w, n = ops.attn_work_plan(torch.zeros(0, dtype=torch.int64), 256)
     assert n == 0 and w.numel() == 0
+
+
+def test_work_list_entry_points_check_the_block_height_and_the_batch(ops):
+    """An entry of a work list is a BLOCK index: the list only means something for the block height it was planned with and for its own
+    batch.  The entry points take (B, q_rows) and refuse a mismatched height; a list planned for a larger batch cannot index cu_seqlens
+    past its B + 1 entries (the kernel skips entries naming a sequence >= B)."""
+    import ctypes
+
+    from mergerec_amd import _lib
+
+    lib, H = _lib.load(), 2
+    lens = torch.tensor([300, 40, 257])
+    cu = torch.tensor([0, 300, 340, 597], dtype=torch.int32, device=DEV)
+    qkv = torch.randn(597, 3 * H * 64, generator=_g(9)).to(DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    plans = {q: ops.attn_work_plan(lens, q) for q in (128, 256)}
+    dev = {q: (w.to(DEV), n) for q, (w, n) in plans.items()}
+    out = torch.full((597, H * 64), 7.5, device=DEV)
+    # bf16x3 full attention owns 256 rows per entry, every other kernel 128
+    assert lib.mr_attn_split_work_f32(P(qkv), P(cu), P(dev[128][0]), dev[128][1], 3, 128, H, 64, 0.125, -1, 3, P(out), None) == -1
+    assert lib.mr_attn_split_work_f32(P(qkv), P(cu), P(dev[256][0]), dev[256][1], 3, 256, H, 64, 0.125, 4, 3, P(out), None) == -1
+    assert lib.mr_attn_split_work_f32(P(qkv), P(cu), P(dev[256][0]), dev[256][1], 3, 256, H, 64, 0.125, -1, 6, P(out), None) == -1
+    assert lib.mr_attn_work_f32(P(qkv), P(cu), P(dev[256][0]), dev[256][1], 3, 256, H, 64, 0.125, -1, 0.0, 0, P(out), None) == -1
+    assert lib.mr_attn_split_work_f32(P(qkv), P(cu), P(dev[256][0]), dev[256][1], -1, 256, H, 64, 0.125, -1, 3, P(out), None) == -1
+    torch.cuda.synchronize()
+    assert bool((out == 7.5).all()), "a refused call must not launch"
+    # a list planned for 3 sequences used with the first two only: rows of sequences 0 and 1 are computed, nothing past cu[2] is read or written
+    want = torch.full_like(out, 7.5)
+    ops.attention(qkv[:340], cu[:3], 2, H, 300, out=want[:340], products=3)
+    assert lib.mr_attn_split_work_f32(P(qkv), P(cu), P(dev[256][0]), dev[256][1], 2, 256, H, 64, 0.125, -1, 3, P(out), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
 
 
 @pytest.mark.parametrize("window", [4, 32])

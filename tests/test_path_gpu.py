@@ -31,10 +31,10 @@ def _dev_weights(sd, mode="bf16x6"):
     return WeightSet(layout, layout.pack(views, DEV), mode).refresh()
 
 
-MODES = ["f32", "bf16x6", "bf16x3"]
+MODES = ["f32", "bf16x6", "f16x3", "bf16x3"]
 # hidden-state tolerance per GEMM arithmetic on the STRESS goldens (tiny models with std-0.2 weights: |activations| and attention
 # logits far larger than in the real models); the contract of the path is 1e-4 on the cosine logits, asserted separately below
-HID_TOL = {"f32": 1e-4, "bf16x6": 1e-4, "bf16x3": 1e-3}
+HID_TOL = {"f32": 1e-4, "bf16x6": 1e-4, "f16x3": 1e-4, "bf16x3": 1e-3}
 
 
 def _cosine_logits_close(a, b, atol=1e-4):
@@ -364,13 +364,13 @@ def test_merge_test_cli_json_dataset_with_local_tokenizer(tmp_path):
 
 
 def test_precision_flag_selects_arithmetic():
-    """Lightning precision strings: 32-true keeps the model's mode, the reference's default bf16-mixed runs bf16x3, junk raises"""
+    """Lightning precision strings: 32-true keeps the model's mode, the reference's default bf16-mixed runs f16x3, junk raises"""
     from mergerec_amd.module import RecModule
     from mergerec_amd.evaluator import Evaluator
     from mergerec_amd.data import load_domain
     from mergerec_amd.utils import Trainer, precision_to_gemm_mode, test_model_on_dataloaders as test_model
 
-    assert precision_to_gemm_mode("32-true") is None and precision_to_gemm_mode("bf16-mixed") == "bf16x3"
+    assert precision_to_gemm_mode("32-true") is None and precision_to_gemm_mode("bf16-mixed") == "f16x3"
     with pytest.raises(ValueError):
         precision_to_gemm_mode("int4")
     model = _tiny_model(dict(hidden=128, heads=2, layers=2, intermediate=256, vocab=1000, max_pos=514))
@@ -379,8 +379,30 @@ def test_precision_flag_selects_arithmetic():
     _, m32, _, _ = test_model(mod, [dom.item_dataloader(16)], [dom.sequence_dataloader(16)], ["Tiny"], precision="32-true")
     assert model._weights.mode == "bf16x6"
     _, m16, _, _ = test_model(mod, [dom.item_dataloader(16)], [dom.sequence_dataloader(16)], ["Tiny"], precision="bf16-mixed")
-    assert model._weights.mode == "bf16x3"
+    assert model._weights.mode == "f16x3"
     assert abs(m32[0]["test/loss"] - m16[0]["test/loss"]) < 1e-3 and m32[0].keys() == m16[0].keys()
+
+
+def test_lazy_eval_scores_are_the_epochs_bits_even_if_the_catalog_is_rewritten_afterwards():
+    """module.py:344-352: ``eval_scores`` is what the epoch computed.  Here it is produced on first access -- from a snapshot of the table
+    the kernel ranked, not from the live ``item_embeddings``, which a catalog refresh or the next domain's encode may rewrite in place."""
+    from oracle import c_oracle as CO
+    from mergerec_amd.data import load_domain
+    from mergerec_amd.evaluator import Evaluator
+    from mergerec_amd.module import RecModule
+    from mergerec_amd.utils import test_model_on_dataloaders as test_model
+
+    model = _tiny_model(dict(hidden=128, heads=2, layers=2, intermediate=256, vocab=1000, max_pos=514))
+    dom = load_domain("synthetic:Tiny:120:40", vocab=1000)
+    mod = RecModule(model=model, evaluator=Evaluator(metrics=["NDCG", "RECALL"], ks=[10]), negative_sample=None, similarity="cosine")
+    test_model(mod, [dom.item_dataloader(16)], [dom.sequence_dataloader(16)], ["Tiny"])
+    assert mod._eval_scores is None and mod._eval_scores_lazy is not None
+    ranked = mod.item_embeddings.detach().cpu().clone()
+    mod.item_embeddings.data[:60] = 0.25                          # in place, after the epoch, before anyone read eval_scores
+    scores = mod.eval_scores
+    assert torch.equal(scores, CO.gemm_nt(mod.eval_user_embeddings, ranked))
+    assert torch.equal(torch.gather(scores, 1, mod.eval_topk_indices[:, :1]).squeeze(1), scores.max(1).values)
+    assert mod._eval_scores_lazy is None and mod.eval_scores is scores  # cached, snapshot released
 
 
 def test_extract_and_finetune_test_single_model(tmp_path):
@@ -621,7 +643,7 @@ def test_large_configs_match_oracle(kind):
     from mergerec_amd.engine import EncoderSpec
 
     res = L.check(kind, getattr(EncoderSpec, kind)(), verbose=False)
-    assert res["f32"][0] <= 5e-6 and res["bf16x6"][0] <= 5e-6 and res["bf16x3"][0] <= 5e-5, res
+    assert res["f32"][0] <= 5e-6 and res["bf16x6"][0] <= 5e-6 and res["f16x3"][0] <= 5e-6 and res["bf16x3"][0] <= 5e-5, res
     assert all(v[1] <= 1e-4 for v in res.values()), res  # the path's contract: cosine logits within 1e-4
 
 

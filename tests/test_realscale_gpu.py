@@ -60,7 +60,7 @@ def setup():
     return fx, sd, dom.item_batches, seqs, ref_scores
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3", "bf16x3"])
 def test_realscale_logits_ranks_and_ndcg_match_the_reference(setup, mode, tmp_path):
     from mergerec_amd.evaluator import Evaluator
     from mergerec_amd.module import ModelType, RecModule

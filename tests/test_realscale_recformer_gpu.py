@@ -73,7 +73,7 @@ def setup(request):
     return fx, sd, dom.item_batches, seqs, model_type
 
 
-@pytest.mark.parametrize("mode,precision", [("bf16x3", "bf16-mixed"), ("f32", "32-true")])
+@pytest.mark.parametrize("mode,precision", [("f16x3", "bf16-mixed"), ("f32", "32-true")])
 def test_logits_ranks_and_ndcg_match_the_reference(setup, mode, precision, tmp_path):
     from mergerec_amd.evaluator import Evaluator
     from mergerec_amd.module import ModelType, RecModule

@@ -51,7 +51,7 @@ def check(kind, spec, verbose=True):
     run = EncoderRunner(spec)
     pb = run.pack(batch, dev)
     res = {}
-    for mode in ("f32", "bf16x6", "bf16x3"):
+    for mode in ("f32", "bf16x6", "f16x3", "bf16x3"):
         W = WeightSet(layout, flat, mode).refresh()
         got = run.forward_packed(W, pb, normalize=True).cpu()
         res[mode] = (float((got - ref).abs().max()), float((got @ got.T - ref @ ref.T).abs().max()))

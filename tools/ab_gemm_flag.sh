@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of gemm_bf16.hip build flags on the GPU box: builds the library once per flag set (each argument is one set, quoted; "" = base) into
 # separate directories and runs the same microbench on all of them, twice, alternating.
-#   gpurun --timeout 900 -- 'bash tools/ab_gemm_flag.sh "" "-DMR_ABL_NT_A" "-DMR_C_STORE_AUX=2"'
+#   gpurun --timeout 900 -- 'bash tools/ab_gemm_flag.sh "" "-DSOME_FLAG=1"'
 set -e
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 python -m mergerec_amd.build > /dev/null 2>&1   # the other objects (mergerec_amd/lib/obj/ does not travel)
