@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pv[r] = __builtin_amdgcn_exp2f(s[r] - m_use);  // raw v_exp_f32 (arguments <= 0; results below 2^-126 flush to 0)
+                pv[r] = __builtin_amdgcn_exp2f(s[r] - (F16 ? m_use - 10.f : m_use));  // raw v_exp_f32; F16: p' = 2^10 p, see the work-list kernel
                 ps += pv[r];
             }
             ps += __shfl_xor(ps, 32, 64);
@@ -550,7 +550,10 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                 float pv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    pv[r] = __builtin_amdgcn_exp2f(s[j][r] - m_use);  // raw v_exp_f32 (arguments <= 0; tiny results flush to 0)
+                    // raw v_exp_f32 (arguments <= 0; tiny results flush to 0).  F16: probabilities carry a factor 2^10 (p' = 2^10 p <= 1024;
+                    // the row sum l and the output accumulate the same factor, which cancels in o / l) so that the fp16 low piece of an
+                    // ordinary 1e-3 probability is a NORMAL number: without it p is only held to an absolute 2^-25
+                    pv[r] = __builtin_amdgcn_exp2f(s[j][r] - (F16 ? m_use - 10.f : m_use));
                     ps += pv[r];
                 }
                 ps += __shfl_xor(ps, 32, 64);

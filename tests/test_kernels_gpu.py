@@ -336,8 +336,12 @@ def _attn_split_bound(qkv, cu, H, window, products):
             s = s.masked_fill(~ok[None], float("-inf"))
             mag = mag.masked_fill(~ok[None], 0.0)
         delta = u * mag.max(-1, keepdim=True).values
+        abs_v = 0.0
+        if products == 35:  # fp16 pieces: a low piece below 2^-14 is an fp16 subnormal, i.e. the value is held to an ABSOLUTE 2^-25
+            delta = delta + dh * 2.0 ** -25 * (q.abs().amax(-1, keepdim=True) * dh ** -0.5 + k.abs().max())
+            abs_v = 2.0 ** -25
         pv = torch.softmax(s, -1) @ v.abs()
-        bound[a:e] = ((torch.expm1(2 * delta) + u + 64 * 2.0 ** -24) * pv).transpose(0, 1).reshape(L, d)
+        bound[a:e] = ((torch.expm1(2 * delta) + u + 64 * 2.0 ** -24) * pv + abs_v).transpose(0, 1).reshape(L, d)
     return bound
 
 
