@@ -421,6 +421,28 @@ size_t mr_layernorm_bwd_ws_bytes(int T, int d);
 int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ldy, const float* gamma, float eps, int T, int d,
                          float* dx, int64_t lddx, float* stats, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mr_stream_t stream);
 
+/* Token-sized exact-fp32 products of the collaborative-merging step (merge_train.py; autograd through transformers' Linear layers under
+ * merger/weight_learning/module/_base.py:78-81 and module/distiller/sequence/module.py:59-79): C = Aop Bop^T where either operand is read
+ * in either orientation, so forward (Y = X W^T: trans_a = 0, trans_b = 0), input gradient (dX = dY W: 0, 1) and weight gradient
+ * (dW = dY^T X: 1, 1; K = tokens, any K >= 1) need no transposed copy of anything, and a 64 x 32 / 64 x 64 tile whose workgroup walks the
+ * whole k range needs no split-K reduction: every output element is the single ascending-k fp32 FMA chain of the C oracle, bit for bit.
+ *   A: trans_a = 0 -> (M, K) row-major, lda; K % 16 == 0.   trans_a = 1 -> (K, M) row-major, lda; M % 4 == 0.
+ *   B: trans_b = 0 -> (N, K) row-major, ldb; K % 16 == 0; nseg_b matrices stacked along N (seg_b % 64 == 0 columns each, bias_s each).
+ *      trans_b = 1 -> (K, N) row-major, ldb; N % 4 == 0; nseg_b matrices stacked along K (seg_b % 16 == 0 rows each); bias0 over all N.
+ *   C: nseg_c matrices stacked along M (seg_c % 64 == 0 rows each), ldc; colsum_s (optional) receives sum_k Aop[m][k] per C segment
+ *      (trans_a = 1: the bias gradient that belongs to the weight gradient).
+ *   epilogue, in this order: + bias[n]; dropout with the counter mask of csrc/dropout.h under (drop_p, drop_key), row = m, column = n;
+ *   + R[m][n]; epi = MR_EPI_GELU_FWD: C = v, C2 = gelu_erf(v) (the pre-activation the backward needs AND the activation);
+ *   epi = MR_EPI_GELU_BWD: C = v * gelu'(E[m][n]).   bn: 0 = choose the tile width, 32 / 64 = force it. */
+#define MR_EPI_NONE 0
+#define MR_EPI_GELU_FWD 1
+#define MR_EPI_GELU_BWD 2
+int mr_gemm_tile_f32(const float* A, int64_t lda, int trans_a, const float* b0, const float* b1, const float* b2, int64_t ldb, int trans_b,
+                     int nseg_b, int seg_b, const float* bias0, const float* bias1, const float* bias2, int M, int N, int K, const float* R,
+                     int64_t ldr, float* c0, float* c1, float* c2, int64_t ldc, int nseg_c, int seg_c, float* colsum0, float* colsum1,
+                     float* colsum2, int epi, const float* E, int64_t lde, float* C2, int64_t ldc2, float drop_p, uint32_t drop_key, int bn,
+                     mr_stream_t stream);
+
 /* Softmax self-attention backward on packed sequences: qkv (T, 3 H dh) = [Q | K | V] and ctx (T, H dh) as in mr_attn_f32,
  * dctx = d loss / d ctx; rowstat (T, H, 2) is workspace; dqkv (T, 3 H dh) receives [dQ | dK | dV].  dh must be 64.
  * window < 0: full attention; window >= 0: Longformer band |i - j| <= window plus the global key 0, query row 0 excluded (it

@@ -71,6 +71,8 @@ SIGNATURES = {
     "mr_gemm_nt_bias_act_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p]),
     "mr_gemm_nt_bf16x6_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_i, c_p]),
     "mr_split_weights_kblock_f16_f32": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p]),
+    "mr_gemm_tile_f32": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i,
+                               c_p, c_p, c_p, c_i, c_p, c_i64, c_p, c_i64, c_f, c_u32, c_i, c_p]),
     "mr_split_bf16x3_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     "mr_split_weights_kblock_f32": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "mr_layernorm_f32": (c_i, [c_p, c_i64, c_p, c_p, c_f, c_i, c_i, c_p, c_i64, c_p]),

@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "lib" / "obj"
 LIB = HERE / "lib" / "libmergerec_hip.so"
-SOURCES = ["capi.hip", "merge.hip", "embed.hip", "gemm.hip", "gemm_bf16.hip", "attn.hip", "attn_bf16.hip", "score.hip", "score_fused.hip", "select.hip", "distill.hip", "backward.hip", "attn_bwd.hip", "optim.hip", "dropout.hip"]
+SOURCES = ["capi.hip", "merge.hip", "embed.hip", "gemm.hip", "gemm_train.hip", "gemm_bf16.hip", "attn.hip", "attn_bf16.hip", "score.hip", "score_fused.hip", "select.hip", "distill.hip", "backward.hip", "attn_bwd.hip", "optim.hip", "dropout.hip"]
 # merge.hip must not contract a*b+c into an FMA: the reference rounds the products separately.
 # (no environment-supplied defines: an object built with a flag would be reused silently by the next plain build -- experiments compile
 # their own copies into /tmp, tools/ab_flag.sh)

@@ -1,0 +1,391 @@
+// Token-sized exact-fp32 products of the collaborative-merging step (merge_train.py: 16 pseudo-user sequences ~ 600 tokens against freshly
+// merged weights): forward  Y = X W^T,  input gradient  dX = dY W,  weight gradient  dW = dY^T X  -- all three through ONE kernel that
+// reads either operand in either orientation, so no operand is ever transposed in memory (r03: 168 / 480 transpose launches per step) and no
+// product is cut along k (r03: 176 / 512 split-K reduce launches): the tile is small enough that a 600 x 768 output alone fills the chip.
+//
+//   C[m][n] = sum_k Aop[m][k] * Bop[n][k]      TA = 0: A is (M, K) row-major (k contiguous)      TA = 1: A is (K, M) row-major (m contiguous)
+//                                              TB = 0: B is (N, K) row-major (a Linear weight)   TB = 1: B is (K, N) row-major
+//   forward  : TA = 0, TB = 0 (B = W)          dX : TA = 0, TB = 1 (A = dY, B = W, k = out features)
+//   dW       : TA = 1, TB = 1 (A = dY, B = X, k = tokens; K need not be a multiple of 16: rows past K read as zero)
+//
+// Block tile 64 x BN x 16 (BN = 64: wave tile 32 x 32 on v_mfma_f32_32x32x2_f32; BN = 32: wave tile 32 x 16 on two v_mfma_f32_16x16x4_f32),
+// 4 waves as 2 x 2.  Both MFMAs are fp32 FMA chains over k, and a workgroup walks its whole k range, so every output element is the single
+// ascending-k chain of the C oracle (oracle/oracle_c.c gemm_nt_ref) -- bit for bit, for every orientation and tile width.
+// LDS holds both operand tiles k-major ([k][m], [k][n]): a lane's MFMA operand for k-step s is one ds_read_b32, conflict-free by the row
+// pitch; m-contiguous sources are stored with one ds_write_b128 per thread, k-contiguous sources with four ds_write_b32 (lanes along m).
+// These products are LATENCY-bound (48 k-tiles of 512 matrix-pipe cycles each per workgroup, one or two workgroups per CU): the global
+// loads run kDepth k-tiles ahead through a register ring (8 VGPRs per stage; the accumulator is only 16), so a tile has kDepth - 1 MFMA
+// phases to arrive.  Fused epilogue: bias, dropout (the counter mask of dropout.h), residual, GELU forward (pre-activation AND activation
+// written), GELU backward (x gelu'(u)); weight-gradient launches also emit the bias gradient (column sums of dY, ascending k per parity).
+#include "common.h"
+#include "dropout.h"
+#include <stdlib.h>
+
+#ifndef MR_TILE_SCHED
+#define MR_TILE_SCHED 1
+#endif
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, kThreads = 256;
+
+struct Args {
+    const float* A; int64_t lda;
+    const float* B[3]; int64_t ldb; int seg_b;      // TB = 0: segments along N (seg_b rows of N each); TB = 1: along K (seg_b rows of K each)
+    const float* bias[3];                           // TB = 0: per N segment; TB = 1: bias[0] over all N (or NULL)
+    int M, N, K;
+    const float* R; int64_t ldr;
+    float* C[3]; int64_t ldc; int seg_c;            // segments of C along M (seg_c rows each): the stacked q / k / v weight gradients
+    float* colsum[3];                               // per C segment: sum_k Aop[m][k] (bias gradient); NULL = not wanted
+    int epi; const float* E; int64_t lde; float* C2; int64_t ldc2;
+    uint32_t drop_thresh; float drop_inv; uint32_t drop_key;
+    int tiles_m, tiles_n, nwg;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float x) {  // as csrc/backward.hip gelu_bwd_kernel
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// BK = k depth of one LDS tile (one barrier).  Global loads are shaped for the texture path first: a k-contiguous source is read with
+// BK / 4 lanes per row (a full 128- or 256-byte piece of each row per instruction -- one lane per row, 16 bytes each, costs 4 x the address
+// processing and ran the whole kernel at 0.2 of the fp32 peak), an m-contiguous source with ROWS / 4 lanes per k row.
+template <bool TRANS, int ROWS, int BK, bool WIDE>
+struct Tile {
+    static constexpr int NV = ROWS * BK / 1024;                       // float4 per thread and k-tile
+    // LDS pitch (floats per k row).  Reads: lanes of different k must hit different banks (32x32x2: two k per instruction, 16x16x4: four).
+    // Writes of a k-contiguous source are four ds_write_b32 per float4 with BK / 4 lanes along k: the pitch makes those lanes hit
+    // different banks too (pitch = 1 mod 16 for 16 lanes per row, 2 mod 16 for 8).
+    static constexpr int BASE = WIDE ? 96 : (ROWS == 64 ? 80 : 48);
+    static constexpr int S = TRANS ? BASE : BASE + (BK == 64 ? 1 : 2);
+    static constexpr int LPR = TRANS ? ROWS / 4 : BK / 4;             // lanes along the contiguous direction
+    static constexpr int PER_PASS = 256 / LPR;                        // rows (k rows if TRANS) covered by one pass of the workgroup
+};
+
+// ZF: K is not a multiple of BK -- the last k-tile is zero-filled past K (token-deep weight gradients); otherwise no select is compiled in
+template <bool TA, bool TB, int BN, int BK, int KD, bool ZF>
+__global__ __launch_bounds__(kThreads, 2) void gemm_tile_kernel(const Args g) {
+    constexpr bool WIDE = BN == 64;
+    using TAi = Tile<TA, BM, BK, WIDE>;
+    using TBi = Tile<TB, BN, BK, WIDE>;
+    constexpr int SA = TAi::S, SB = TBi::S;
+    constexpr bool kSched = MR_TILE_SCHED;
+    constexpr int kDepth = KD;                // k-tiles in flight (even: the LDS buffer of a ring slot is then a compile-time constant)
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float* const As0 = lds_dyn;               // [2][BK * SA]
+    float* const Bs0 = lds_dyn + 2 * BK * SA; // [2][BK * SB]
+
+    // tile order: row tile fastest -- the (few) row tiles that share a weight panel run together on one XCD
+    const int pid = mr::xcd_remap(blockIdx.x, g.nwg);
+    const int tn = pid / g.tiles_m, tm = pid - tn * g.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = g.M, N = g.N, K = g.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- global -> registers -> LDS ([k][m] / [k][n] images)
+    const int ca = tid % TAi::LPR, ra_ = tid / TAi::LPR;   // position along the contiguous direction / across it
+    const int cb = tid % TBi::LPR, rb_ = tid / TBi::LPR;
+    struct Stage { float4 a[TAi::NV], b[TBi::NV]; };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // per-thread source OFFSETS of k-tile 0 (32-bit, in floats, against a workgroup-uniform base: one v_add per load instead of 64-bit
+    // pointer arithmetic), one per pass; rows / columns clamped once (re-reads of valid data, discarded by the epilogue).  gload only adds the
+    // tile's k offset: no data-dependent work behind a load (a select on the loaded value would make the wave wait for its own prefetch
+    // at once) -- rows past K are zeroed when the stage is written to LDS, and only in launches whose K is not a multiple of BK (ZF).
+    uint32_t oa[TAi::NV], ob[TBi::NV];
+    const uint32_t lda = (uint32_t)g.lda, ldb = (uint32_t)g.ldb;
+#pragma unroll
+    for (int p = 0; p < TAi::NV; ++p) {
+        if (TA) {   // (K, M) source: k row ra_ + p * PER_PASS (+ k0), columns m0 + 4 ca .. + 3
+            int col = m0 + 4 * ca;
+            col = col <= M - 4 ? col : M - 4;
+            oa[p] = (uint32_t)col + (uint32_t)(ra_ + p * TAi::PER_PASS) * lda;
+        } else {    // (M, K) source: row, k = 4 ca .. + 3 (+ k0)
+            int row = m0 + ra_ + p * TAi::PER_PASS;
+            row = row < M ? row : M - 1;
+            oa[p] = (uint32_t)row * lda + 4u * ca;
+        }
+    }
+    const int nseg = TB ? 0 : (n0 >= g.seg_b) + (n0 >= 2 * g.seg_b);   // !TB: this tile lies inside one N segment (seg_b % 64 == 0)
+    const float* __restrict__ Bn = TB ? nullptr : g.B[nseg];
+#pragma unroll
+    for (int p = 0; p < TBi::NV; ++p) {
+        if (TB) {   // (K, N) sources stacked along K: k row rb_ + p * PER_PASS (+ k0 inside its segment)
+            int col = n0 + 4 * cb;
+            col = col <= N - 4 ? col : N - 4;
+            ob[p] = (uint32_t)col + (uint32_t)(rb_ + p * TBi::PER_PASS) * ldb;
+        } else {
+            int row = n0 + rb_ + p * TBi::PER_PASS;
+            row = row < N ? row : N - 1;
+            ob[p] = (uint32_t)(row - nseg * g.seg_b) * ldb + 4u * cb;
+        }
+    }
+    const float* __restrict__ Ag = g.A;
+    auto gload = [&](int kt, Stage& st) {
+        const int k0 = kt * BK;   // uniform
+        // past-K rows / columns (ZF launches only) re-read the tile's first row / column: any valid address, zeroed in lstore
+#pragma unroll
+        for (int p = 0; p < TAi::NV; ++p) {
+            if (TA) {
+                const bool in = !ZF || (k0 + ra_ + p * TAi::PER_PASS < K);
+                st.a[p] = *reinterpret_cast<const float4*>(Ag + (in ? oa[p] : oa[p] - (uint32_t)(ra_ + p * TAi::PER_PASS) * lda) + (uint32_t)k0 * lda);
+            } else {
+                const bool in = !ZF || (k0 + 4 * ca < K);
+                st.a[p] = *reinterpret_cast<const float4*>(Ag + (in ? oa[p] : oa[p] - 4u * ca) + (uint32_t)k0);
+            }
+        }
+        const int kseg = TB ? ((k0 >= g.seg_b) + (k0 >= 2 * g.seg_b)) : 0;   // TB: a k-tile lies inside one K segment (seg_b % 64 == 0)
+        const float* __restrict__ Bk = TB ? g.B[kseg] : Bn;
+        const uint32_t kin = (uint32_t)(k0 - kseg * g.seg_b);
+#pragma unroll
+        for (int p = 0; p < TBi::NV; ++p) {
+            if (TB) {
+                const bool in = !ZF || (k0 + rb_ + p * TBi::PER_PASS < K);
+                st.b[p] = *reinterpret_cast<const float4*>(Bk + (in ? ob[p] : ob[p] - (uint32_t)(rb_ + p * TBi::PER_PASS) * ldb) + kin * ldb);
+            } else {
+                const bool in = !ZF || (k0 + 4 * cb < K);
+                st.b[p] = *reinterpret_cast<const float4*>(Bk + (in ? ob[p] : ob[p] - 4u * cb) + (uint32_t)k0);
+            }
+        }
+    };
+    auto lstore = [&](int buf, const Stage& st, int kt) {   // kt = the k-tile the stage holds (for the zero fill past K)
+        float* as = As0 + buf * (BK * SA);
+        float* bs = Bs0 + buf * (BK * SB);
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int p = 0; p < TAi::NV; ++p) {
+            const bool ok = !ZF || (TA ? (k0 + ra_ + p * TAi::PER_PASS < K) : (k0 + 4 * ca < K));
+            const float4 v = ok ? st.a[p] : zero4;
+            if (TA) {
+                *reinterpret_cast<float4*>(as + (ra_ + p * TAi::PER_PASS) * SA + 4 * ca) = v;
+            } else {
+                float* d = as + (4 * ca) * SA + ra_ + p * TAi::PER_PASS;
+                d[0] = v.x; d[SA] = v.y; d[2 * SA] = v.z; d[3 * SA] = v.w;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < TBi::NV; ++p) {
+            const bool ok = !ZF || (TB ? (k0 + rb_ + p * TBi::PER_PASS < K) : (k0 + 4 * cb < K));
+            const float4 v = ok ? st.b[p] : zero4;
+            if (TB) {
+                *reinterpret_cast<float4*>(bs + (rb_ + p * TBi::PER_PASS) * SB + 4 * cb) = v;
+            } else {
+                float* d = bs + (4 * cb) * SB + rb_ + p * TBi::PER_PASS;
+                d[0] = v.x; d[SB] = v.y; d[2 * SB] = v.z; d[3 * SB] = v.w;
+            }
+        }
+    };
+
+    // ---- MFMA operand reads and accumulators
+    const int lr = lane & 31, lh = lane >> 5;   // 32x32x2: lane = (row / col lr, k parity lh)
+    const int li = lane & 15, lk = lane >> 4;   // 16x16x4: lane = (row / col li, k residue lk)
+    f32x16 acc32;
+    f32x4 acc16[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc32[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[i][r] = 0.f;
+    const bool want_colsum = (g.colsum[0] != nullptr) && tn == 0 && wn == 0;  // wave-uniform
+    float cs0 = 0.f, cs1 = 0.f;
+    auto compute = [&](int buf) {
+        const float* as = As0 + buf * (BK * SA);
+        const float* bs = Bs0 + buf * (BK * SB);
+        if (WIDE) {
+            const float* ap = as + lh * SA + wm * 32 + lr;
+            const float* bp = bs + lh * SB + wn * 32 + lr;
+#pragma unroll
+            for (int s = 0; s < BK / 2; ++s) {
+                const float av = ap[2 * s * SA], bv = bp[2 * s * SB];
+                if (want_colsum) cs0 += av;
+                acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc32, 0, 0, 0);
+            }
+        } else {
+            const float* ap = as + lk * SA + wm * 32 + li;
+            const float* bp = bs + lk * SB + wn * 16 + li;
+#pragma unroll
+            for (int s = 0; s < BK / 4; ++s) {
+                const float a0 = ap[4 * s * SA], a1 = ap[4 * s * SA + 16], bv = bp[4 * s * SB];
+                if (want_colsum) { cs0 += a0; cs1 += a1; }
+                acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc16[0], 0, 0, 0);
+                acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc16[1], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop: register ring of kDepth stages, double-buffered LDS, one barrier per k-tile
+    const int nk = (K + BK - 1) / BK;
+    auto ktile = [&](int kt) { return kt < nk ? kt : 0; };  // past-the-end prefetches re-read tile 0 (never consumed)
+    Stage ring[kDepth];
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j) gload(ktile(j), ring[j]);
+    lstore(0, ring[0], 0);
+    __syncthreads();
+    for (int kt0 = 0; kt0 < nk; kt0 += kDepth) {
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j) {
+            const int kt = kt0 + j;
+            if (kt < nk) {  // uniform
+                gload(ktile(kt + kDepth), ring[j]);  // slot j's tile (kt) is already in LDS: refill it with tile kt + kDepth
+                compute(j & 1);
+                lstore((j + 1) & 1, ring[(j + 1) % kDepth], ktile(kt + 1));  // tile kt + 1 (a re-read of tile 0 after the last one)
+                // ONE scheduling region per k-tile: with one workgroup per CU a SIMD holds a single wave, so nothing but this wave's own
+                // instruction stream can fill the matrix pipe's dependency gaps -- interleave the zero-fill selects, address updates and LDS
+                // traffic of the staging with the MFMA chain instead of running them behind it.
+                if (kSched) {
+#pragma unroll
+                    for (int q = 0; q < (WIDE ? BK / 2 : BK / 2); ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // a few VALU
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // LDS reads
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS write
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue
+    const int cseg = (m0 >= g.seg_c) + (m0 >= 2 * g.seg_c);  // a row tile lies inside one C segment (seg_c % 64 == 0, or one segment)
+    float* __restrict__ Cb = g.C[cseg];
+    const int mloc0 = m0 - cseg * g.seg_c;         // row of the tile inside its segment
+    if (want_colsum) {
+        float* out = g.colsum[cseg];
+        if (WIDE) {
+            cs0 += __shfl_xor(cs0, 32, 64);
+            const int m = m0 + wm * 32 + lr;
+            if (lh == 0 && m < M) out[mloc0 + wm * 32 + lr] = cs0;
+        } else {
+            cs0 += __shfl_xor(cs0, 16, 64); cs0 += __shfl_xor(cs0, 32, 64);
+            cs1 += __shfl_xor(cs1, 16, 64); cs1 += __shfl_xor(cs1, 32, 64);
+            const int m = m0 + wm * 32 + li;
+            if (lk == 0) {
+                if (m < M) out[mloc0 + wm * 32 + li] = cs0;
+                if (m + 16 < M) out[mloc0 + wm * 32 + 16 + li] = cs1;
+            }
+        }
+    }
+    const int bseg = TB ? 0 : (n0 >= g.seg_b) + (n0 >= 2 * g.seg_b);
+    const float* __restrict__ bias = g.bias[bseg];
+    const int nb0 = TB ? 0 : bseg * g.seg_b;       // first column of the bias segment
+    auto finish = [&](float v, int m, int n) {     // m, n global; m < M and n < N
+        if (bias) v += bias[n - nb0];
+        if (g.drop_thresh) v = mr::dropout_keep(g.drop_key, (uint32_t)m, (uint32_t)n, g.drop_thresh) ? v * g.drop_inv : 0.f;
+        if (g.R) v += g.R[(int64_t)m * g.ldr + n];
+        const int64_t ci = (int64_t)(m - cseg * g.seg_c) * g.ldc + n;
+        if (g.epi == MR_EPI_GELU_BWD) v *= gelu_grad(g.E[(int64_t)m * g.lde + n]);
+        Cb[ci] = v;
+        if (g.epi == MR_EPI_GELU_FWD) g.C2[(int64_t)m * g.ldc2 + n] = gelu_erf(v);
+    };
+    if (WIDE) {
+        const int n = n0 + wn * 32 + lr;
+        if (n < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) finish(acc32[r], m, n);
+            }
+        }
+    } else {
+        const int n = n0 + wn * 16 + li;
+        if (n < N) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 32 + i * 16 + 4 * lk + r;
+                    if (m < M) finish(acc16[i][r], m, n);
+                }
+        }
+    }
+}
+
+}  // namespace
+
+// C = Aop Bop^T with the fused epilogue (header).  Segments: up to three B matrices (trans_b = 0: stacked along N, seg_b columns each -- the
+// fused q / k / v projection; trans_b = 1: stacked along K, seg_b rows each -- the input gradient through the stacked projections) and up
+// to three C matrices stacked along M (seg_c rows each; with their bias gradients colsum) for trans_a = 1 -- the q / k / v weight gradients
+// from one (T, 3 d) dY.  bn: 0 = choose, 32 / 64 = force the tile width (A/B runs).
+extern "C" int mr_gemm_tile_f32(const float* A, int64_t lda, int trans_a, const float* b0, const float* b1, const float* b2, int64_t ldb, int trans_b,
+                                int nseg_b, int seg_b, const float* bias0, const float* bias1, const float* bias2, int M, int N, int K,
+                                const float* R, int64_t ldr, float* c0, float* c1, float* c2, int64_t ldc, int nseg_c, int seg_c, float* colsum0,
+                                float* colsum1, float* colsum2, int epi, const float* E, int64_t lde, float* C2, int64_t ldc2, float drop_p,
+                                uint32_t drop_key, int bn, mr_stream_t stream) {
+    if (!A || !b0 || !c0 || M < 0 || N < 1 || K < 1 || nseg_b < 1 || nseg_b > 3 || nseg_c < 1 || nseg_c > 3) return MR_EINVAL;
+    if ((nseg_b > 1 && !b1) || (nseg_b > 2 && !b2) || (nseg_c > 1 && !c1) || (nseg_c > 2 && !c2)) return MR_EINVAL;
+    if (epi != MR_EPI_NONE && epi != MR_EPI_GELU_FWD && epi != MR_EPI_GELU_BWD) return MR_EUNSUPPORTED;
+    if ((epi == MR_EPI_GELU_FWD && !C2) || (epi == MR_EPI_GELU_BWD && !E)) return MR_EINVAL;
+    uint32_t thresh;
+    float inv;
+    if (!mr::dropout_params(drop_p, &thresh, &inv)) return MR_EINVAL;
+    // orientation-specific shape rules
+    if ((!trans_a || !trans_b) && (K & 3)) return MR_EUNSUPPORTED;  // k-contiguous rows are read as float4 (zeros past K)
+    if (trans_a && (M < 4 || (M & 3))) return MR_EUNSUPPORTED;
+    if (trans_b && (N < 4 || (N & 3))) return MR_EUNSUPPORTED;
+    if (nseg_b > 1) {
+        if (trans_b ? (seg_b % 64 || (int64_t)seg_b * nseg_b != K) : (seg_b % 64 || (int64_t)seg_b * nseg_b != N)) return MR_EUNSUPPORTED;
+    } else {
+        seg_b = trans_b ? K : N;
+    }
+    if (nseg_c > 1) {
+        if (seg_c % BM || (int64_t)seg_c * nseg_c != M) return MR_EUNSUPPORTED;
+    } else {
+        seg_c = M > 0 ? M : 1;
+    }
+    if ((lda & 3) || (ldb & 3) || !mr::aligned16(A) || !mr::aligned16(b0) || (b1 && !mr::aligned16(b1)) || (b2 && !mr::aligned16(b2))) return MR_EALIGN;
+    if (bn != 0 && bn != 32 && bn != 64) return MR_EINVAL;
+    if (M == 0) return MR_OK;
+    const int tiles_m = (M + BM - 1) / BM;
+    if (bn == 0) {
+        // a launch takes about ceil(workgroups / 256 CUs) x (tile width) of time: the narrow tile when the wide one leaves CUs idle
+        const int64_t w64 = (int64_t)tiles_m * ((N + 63) / 64), w32 = (int64_t)tiles_m * ((N + 31) / 32);
+        const double t64 = (double)((w64 + 255) / 256) * 1.0, t32 = (double)((w32 + 255) / 256) * 0.55;
+        bn = t32 < t64 ? 32 : 64;
+        static const int force = [] { const char* e = getenv("MR_GEMM_TILE_BN"); return e ? atoi(e) : 0; }();
+        if (force == 32 || force == 64) bn = force;
+    }
+    Args g;
+    g.A = A; g.lda = lda;
+    g.B[0] = b0; g.B[1] = b1; g.B[2] = b2; g.ldb = ldb; g.seg_b = seg_b;
+    g.bias[0] = bias0; g.bias[1] = bias1; g.bias[2] = bias2;
+    g.M = M; g.N = N; g.K = K;
+    g.R = R; g.ldr = ldr;
+    g.C[0] = c0; g.C[1] = c1; g.C[2] = c2; g.ldc = ldc; g.seg_c = seg_c;
+    g.colsum[0] = colsum0; g.colsum[1] = colsum1; g.colsum[2] = colsum2;
+    g.epi = epi; g.E = E; g.lde = lde; g.C2 = C2; g.ldc2 = ldc2;
+    g.drop_thresh = thresh; g.drop_inv = thresh ? inv : 1.f; g.drop_key = drop_key;
+    g.tiles_m = tiles_m; g.tiles_n = (N + bn - 1) / bn;
+    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n;
+    if (nwg > 0x7fffffff) return MR_EUNSUPPORTED;
+    g.nwg = (int)nwg;
+    hipStream_t st = (hipStream_t)stream;
+    // 32-bit element offsets inside the kernel
+    if ((int64_t)(trans_a ? K : M) * lda >= (1ll << 31) || (int64_t)(trans_b ? seg_b : N) * ldb >= (1ll << 31)) return MR_EUNSUPPORTED;
+    const bool zf = (K % 64) != 0;
+#define MR_GT(TA_, TB_, BN_, ZF_)                                                                                                          \
+    do {                                                                                                                                   \
+        constexpr size_t shm_ = (size_t)2 * 64 * (Tile<TA_, BM, 64, BN_ == 64>::S + Tile<TB_, BN_, 64, BN_ == 64>::S) * sizeof(float);      \
+        static mr::DynLdsCeiling lds_ceiling;                                                                                              \
+        if (const int e_ = lds_ceiling.ensure(reinterpret_cast<const void*>(&gemm_tile_kernel<TA_, TB_, BN_, 64, 2, ZF_>), shm_)) return e_; \
+        hipLaunchKernelGGL((gemm_tile_kernel<TA_, TB_, BN_, 64, 2, ZF_>), dim3(g.nwg), dim3(kThreads), shm_, st, g);                        \
+    } while (0)
+#define MR_GT3(TA_, TB_, BN_) do { if (zf) MR_GT(TA_, TB_, BN_, true); else MR_GT(TA_, TB_, BN_, false); } while (0)
+    if (bn == 64) {
+        if (trans_a) { if (trans_b) MR_GT3(true, true, 64); else MR_GT3(true, false, 64); }
+        else { if (trans_b) MR_GT3(false, true, 64); else MR_GT3(false, false, 64); }
+    } else {
+        if (trans_a) { if (trans_b) MR_GT3(true, true, 32); else MR_GT3(true, false, 32); }
+        else { if (trans_b) MR_GT3(false, true, 32); else MR_GT3(false, false, 32); }
+    }
+#undef MR_GT3
+#undef MR_GT
+    return mr::check_launch();
+}

@@ -12,6 +12,7 @@ Recformer: the band + global-key attention backward is the same pair of kernels 
 (query_global / key_global / value_global projections) has its own one-query backward kernel; four embedding tables."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -41,6 +42,9 @@ class Dropout:
     @property
     def active(self) -> bool:
         return self.p_hidden > 0.0 or self.p_attn > 0.0
+
+# A/B switch of the r04 token-sized tile kernel in the exact-fp32 graph (1 = default; 0 = the r03 route: NT kernel + split-K + transposes)
+_TILE = os.environ.get("MR_TRAIN_TILE", "1") != "0"
 
 _LINEARS = ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "intermediate.dense", "output.dense")
 
@@ -127,6 +131,8 @@ class EncoderTrainGraph:
     # ---------------------------------------------------------------------------------------------- products
     def _linear(self, x, w, name: str, residual=None, out=None):
         """x W^T + b for the Linear ``name`` (arena key without ".weight")."""
+        if self.mode == "f32" and _TILE:
+            return ops.gemm_tile(x, [w[name + ".weight"]], biases=[w[name + ".bias"]], residual=residual, out=out)
         if self.mode == "f32":
             return ops.gemm_nt_train(x, w[name + ".weight"], w[name + ".bias"], residual=residual, out=out)
         n, k = self.layout.shapes[name + ".weight"]
@@ -159,7 +165,9 @@ class EncoderTrainGraph:
             lp = f"{p}encoder.layer.{l}."
             names = [f"{lp}attention.self.{n}" for n in ("query", "key", "value")]
             qkv = torch.empty(pb.T, 3 * sp.hidden, dtype=torch.float32, device=x.device)
-            if self.mode == "f32":
+            if self.mode == "f32" and _TILE:  # one launch over the three weights (csrc/gemm_train.hip: no split-K, no reduce)
+                ops.gemm_tile(x, [w[n + ".weight"] for n in names], biases=[w[n + ".bias"] for n in names], out=qkv)
+            elif self.mode == "f32":
                 for s, n in enumerate(names):
                     ops.gemm_nt_train(x, w[n + ".weight"], w[n + ".bias"], out=qkv[:, s * sp.hidden:(s + 1) * sp.hidden])
             else:  # one launch over the three weight segments
@@ -174,23 +182,37 @@ class EncoderTrainGraph:
                 x_cls = ops.gather_rows(x, pb.cls_rows)
                 qg = self._linear(x_cls, w, f"{lp}attention.self.query_global")
                 kvg = torch.empty(pb.T, 2 * sp.hidden, dtype=torch.float32, device=x.device)
-                for s, n in enumerate(("key_global", "value_global")):
-                    self._linear(x, w, f"{lp}attention.self.{n}", out=kvg[:, s * sp.hidden:(s + 1) * sp.hidden])
+                if self.mode == "f32" and _TILE:
+                    gn = [f"{lp}attention.self.{n}" for n in ("key_global", "value_global")]
+                    ops.gemm_tile(x, [w[n + ".weight"] for n in gn], biases=[w[n + ".bias"] for n in gn], out=kvg)
+                else:
+                    for s, n in enumerate(("key_global", "value_global")):
+                        self._linear(x, w, f"{lp}attention.self.{n}", out=kvg[:, s * sp.hidden:(s + 1) * sp.hidden])
                 ops.attention_global_row(qg, kvg, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx,
                                          drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_GLOBAL_ROW) if pa > 0.0 else 0)
-            if ph > 0.0:  # a = dropout(ctx Wo^T + bo) + x ; o = dropout(i W2^T + b2) + h: the residual joins after the mask
-                a = self._linear(ctx, w, lp + "attention.output.dense")
-                ops.dropout_rows(a, ph, dr.key(l, ops.DROP_SITE_ATTN_OUT), residual=x, out=a)
+            if self.mode == "f32" and _TILE:  # the product's epilogue carries bias, dropout mask, residual and GELU: one launch per Linear
+                n_o, n_1, n_2 = lp + "attention.output.dense", lp + "intermediate.dense", lp + "output.dense"
+                a = ops.gemm_tile(ctx, [w[n_o + ".weight"]], biases=[w[n_o + ".bias"]], residual=x, drop_p=ph,
+                                  drop_key=dr.key(l, ops.DROP_SITE_ATTN_OUT) if ph > 0.0 else 0)
+                h = ops.layernorm(a, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps)
+                i = torch.empty(pb.T, sp.intermediate, dtype=torch.float32, device=x.device)
+                u = ops.gemm_tile(h, [w[n_1 + ".weight"]], biases=[w[n_1 + ".bias"]], epi=ops.EPI_GELU_FWD, out2=i)
+                o = ops.gemm_tile(i, [w[n_2 + ".weight"]], biases=[w[n_2 + ".bias"]], residual=h, drop_p=ph,
+                                  drop_key=dr.key(l, ops.DROP_SITE_FFN_OUT) if ph > 0.0 else 0)
             else:
-                a = self._linear(ctx, w, lp + "attention.output.dense", residual=x)
-            h = ops.layernorm(a, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps)
-            u = self._linear(h, w, lp + "intermediate.dense")
-            i = ops.gelu_fwd(u)
-            if ph > 0.0:
-                o = self._linear(i, w, lp + "output.dense")
-                ops.dropout_rows(o, ph, dr.key(l, ops.DROP_SITE_FFN_OUT), residual=h, out=o)
-            else:
-                o = self._linear(i, w, lp + "output.dense", residual=h)
+                if ph > 0.0:  # a = dropout(ctx Wo^T + bo) + x ; o = dropout(i W2^T + b2) + h: the residual joins after the mask
+                    a = self._linear(ctx, w, lp + "attention.output.dense")
+                    ops.dropout_rows(a, ph, dr.key(l, ops.DROP_SITE_ATTN_OUT), residual=x, out=a)
+                else:
+                    a = self._linear(ctx, w, lp + "attention.output.dense", residual=x)
+                h = ops.layernorm(a, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps)
+                u = self._linear(h, w, lp + "intermediate.dense")
+                i = ops.gelu_fwd(u)
+                if ph > 0.0:
+                    o = self._linear(i, w, lp + "output.dense")
+                    ops.dropout_rows(o, ph, dr.key(l, ops.DROP_SITE_FFN_OUT), residual=h, out=o)
+                else:
+                    o = self._linear(i, w, lp + "output.dense", residual=h)
             x_next = ops.layernorm(o, w[lp + "output.LayerNorm.weight"], w[lp + "output.LayerNorm.bias"], sp.ln_eps)
             saved["layers"].append(dict(x=x, qkv=qkv, ctx=ctx, a=a, h=h, u=u, i=i, o=o, qg=qg, kvg=kvg, l=l))
             x = x_next
@@ -230,11 +252,77 @@ class EncoderTrainGraph:
         else:
             ops.gemm_nt_split_k(dy_t, pieces, 0, x_t[0], x_t[1], out=out)
 
+    def _backward_f32(self, d_cls: torch.Tensor) -> torch.Tensor:
+        """The exact-fp32 backward on the token-sized tile kernel (csrc/gemm_train.hip): every weight gradient reads dY and X as they lie
+        (k = tokens down the rows), every input gradient reads W as it lies (k = output features down the rows) -- no transposed copy of
+        anything -- and the epilogues carry what used to be separate launches: the bias gradient with its weight gradient, GELU' with
+        the FFN input gradient, the residual adds.  Per layer: 8 products (+ 4 for Recformer's global projections) instead of 8 products
+        + 8 split-K reductions + 14 transposes + 4 row sums + a GELU-backward launch."""
+        sv = self._saved
+        sp, p, pb = self.spec, self.prefix, sv["pb"]
+        w = self.layout.views(sv["flat"])
+        g_flat = torch.zeros_like(sv["flat"])
+        g = self.layout.views(g_flat)
+        d = sp.hidden
+        dx = torch.zeros(pb.T, d, dtype=torch.float32, device=d_cls.device)
+        ops.scatter_add_rows(d_cls.contiguous(), pb.cls_rows, dx)
+        dr = self.drop
+        ph, pa = (dr.p_hidden, dr.p_attn) if dr else (0.0, 0.0)
+        T = True
+        for l in reversed(range(sp.layers)):
+            lp = f"{p}encoder.layer.{l}."
+            s = sv["layers"][l]
+            n_o, n_1, n_2 = lp + "attention.output.dense", lp + "intermediate.dense", lp + "output.dense"
+            do = ops.layernorm_bwd(s["o"], dx, w[lp + "output.LayerNorm.weight"], sp.ln_eps, g[lp + "output.LayerNorm.weight"],
+                                   g[lp + "output.LayerNorm.bias"])
+            dod = ops.dropout_rows(do, ph, dr.key(l, ops.DROP_SITE_FFN_OUT)) if ph > 0.0 else do   # the dense sees the masked gradient
+            ops.gemm_tile(dod, [s["i"]], trans_a=T, trans_b=T, out=[g[n_2 + ".weight"]], colsum=[g[n_2 + ".bias"]])       # dW2 = dY^T i, db2
+            du = ops.gemm_tile(dod, [w[n_2 + ".weight"]], trans_b=T, epi=ops.EPI_GELU_BWD, E=s["u"])                      # (dY W2) * gelu'(u)
+            ops.gemm_tile(du, [s["h"]], trans_a=T, trans_b=T, out=[g[n_1 + ".weight"]], colsum=[g[n_1 + ".bias"]])         # dW1, db1
+            dh = ops.gemm_tile(du, [w[n_1 + ".weight"]], trans_b=T, residual=do)                                          # + the residual path of o
+            da = ops.layernorm_bwd(s["a"], dh, w[lp + "attention.output.LayerNorm.weight"], sp.ln_eps,
+                                   g[lp + "attention.output.LayerNorm.weight"], g[lp + "attention.output.LayerNorm.bias"])
+            dad = ops.dropout_rows(da, ph, dr.key(l, ops.DROP_SITE_ATTN_OUT)) if ph > 0.0 else da
+            ops.gemm_tile(dad, [s["ctx"]], trans_a=T, trans_b=T, out=[g[n_o + ".weight"]], colsum=[g[n_o + ".bias"]])     # dWo, dbo
+            dctx = ops.gemm_tile(dad, [w[n_o + ".weight"]], trans_b=T)
+            dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window, max_len=pb.max_len, seq_order=pb.seq_order,
+                                     drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_ATTN_PROBS) if pa > 0.0 else 0, work=pb.attn_work)
+            if self.rec:
+                dqg, dkvg = ops.attention_global_row_bwd(s["qg"], s["kvg"], ops.gather_rows(s["ctx"], pb.cls_rows), ops.gather_rows(dctx, pb.cls_rows),
+                                                         pb.cu_seqlens, pb.B, sp.heads,
+                                                         drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_GLOBAL_ROW) if pa > 0.0 else 0)
+                gn = [f"{lp}attention.self.{n}" for n in ("key_global", "value_global")]
+                ops.gemm_tile(dkvg, [s["x"]], trans_a=T, trans_b=T, out=[g[n + ".weight"] for n in gn], colsum=[g[n + ".bias"] for n in gn])
+                da = ops.gemm_tile(dkvg, [w[n + ".weight"] for n in gn], trans_b=T, residual=da)
+                # query_global reads the CLS rows only
+                name = f"{lp}attention.self.query_global"
+                x_cls = ops.gather_rows(s["x"], pb.cls_rows)
+                ops.gemm_tile(dqg, [x_cls], trans_a=T, trans_b=T, out=[g[name + ".weight"]], colsum=[g[name + ".bias"]])
+                ops.scatter_add_rows(ops.gemm_tile(dqg, [w[name + ".weight"]], trans_b=T), pb.cls_rows, da)
+            qn = [f"{lp}attention.self.{n}" for n in ("query", "key", "value")]
+            ops.gemm_tile(dqkv, [s["x"]], trans_a=T, trans_b=T, out=[g[n + ".weight"] for n in qn], colsum=[g[n + ".bias"] for n in qn])
+            dx = ops.gemm_tile(dqkv, [w[n + ".weight"] for n in qn], trans_b=T, residual=da)                               # + the residual path of a
+        e = p + "embeddings."
+        if ph > 0.0:  # x0 = dropout(LN(emb))
+            dx = ops.dropout_rows(dx, ph, dr.key(0, ops.DROP_SITE_EMBED), out=dx)
+        de = ops.layernorm_bwd(sv["emb"], dx, w[e + "LayerNorm.weight"], sp.ln_eps, g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"])
+        ops.scatter_add_rows(de, pb.tok_word, g[e + "word_embeddings.weight"])
+        ops.scatter_add_rows(de, pb.tok_pos, g[e + "position_embeddings.weight"])
+        if self.rec:
+            ops.scatter_add_rows(de, pb.tok_tt, g[e + "token_type_embeddings.weight"])
+            ops.scatter_add_rows(de, pb.tok_ip, g[e + "item_position_embeddings.weight"])
+        else:
+            ops.colsum(de, g[e + "token_type_embeddings.weight"][0])
+        self._saved = None
+        return g_flat
+
     def backward(self, d_cls: torch.Tensor) -> torch.Tensor:
         """d loss / d CLS rows (B, d) -> d loss / d parameters, flat, arena layout (pads zero)."""
         sv = self._saved
         if sv is None:
             raise RuntimeError("backward() without a preceding forward()")
+        if self.mode == "f32" and _TILE:
+            return self._backward_f32(d_cls)
         sp, p, pb = self.spec, self.prefix, sv["pb"]
         w = self.layout.views(sv["flat"])
         g_flat = torch.zeros_like(sv["flat"])

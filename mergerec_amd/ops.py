@@ -648,6 +648,55 @@ def gemm_nt_train(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
+EPI_NONE, EPI_GELU_FWD, EPI_GELU_BWD = 0, 1, 2
+
+
+def gemm_tile(A: torch.Tensor, Bs, trans_a: bool = False, trans_b: bool = False, biases=None, residual: Optional[torch.Tensor] = None, out=None,
+              colsum=None, epi: int = EPI_NONE, E: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, drop_p: float = 0.0,
+              drop_key: int = 0, bn: int = 0) -> torch.Tensor:
+    """Token-sized exact-fp32 product of the training graph (mr_gemm_tile_f32): ``Aop @ Bop^T`` with either operand in either orientation,
+    no transposed copies, no split-K; every output element is the ascending-k FMA chain.
+      A: (M, K), or with trans_a (K, M).   Bs: 1..3 matrices -- (seg_n, K) each, stacked along N; with trans_b (seg_k, N) each, stacked along K.
+      out: an (M, N) tensor, or (trans_a only) a list of 1..3 (seg_m, N) tensors stacked along M with optional ``colsum`` (seg_m,) each.
+      epilogue: + bias (per N segment; one bias with trans_b), dropout (drop_p, drop_key; row = m, column = n), + residual,
+      EPI_GELU_FWD (out = pre-activation, out2 = gelu) or EPI_GELU_BWD (out = product * gelu'(E))."""
+    Bs = list(Bs)
+    if not (A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.stride(1) == 1):
+        raise ValueError("A must be a 2-D fp32 GPU tensor with unit inner stride (the HIP path has no CPU fallback)")
+    (K, M) = A.shape if trans_a else A.shape[::-1]
+    nb = len(Bs)
+    if trans_b:
+        N, seg_b = Bs[0].shape[1], Bs[0].shape[0]
+        if sum(b.shape[0] for b in Bs) != K:
+            raise ValueError("B segments must cover K")
+    else:
+        seg_b, N = Bs[0].shape[0], Bs[0].shape[0] * nb
+        if any(b.shape[1] != K for b in Bs):
+            raise ValueError("every B segment must be (seg_n, K)")
+    if any(b.stride(1) != 1 or b.stride(0) != Bs[0].stride(0) or b.shape != Bs[0].shape for b in Bs):
+        raise ValueError("B segments must share one shape and row pitch")
+    outs = list(out) if isinstance(out, (list, tuple)) else [out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A.device)]
+    nc = len(outs)
+    seg_c = outs[0].shape[0]
+    if any(o.shape != (seg_c, N) or o.stride(1) != 1 or o.stride(0) != outs[0].stride(0) for o in outs) or seg_c * nc != M:
+        raise ValueError("out must be (M, N), or equally shaped segments covering M")
+    biases = list(biases) if biases is not None else []
+    biases += [None] * (3 - len(biases))
+    cs = list(colsum) if colsum is not None else []
+    cs += [None] * (3 - len(cs))
+    Bp = Bs + [None] * (3 - nb)
+    Cp = outs + [None] * (3 - nc)
+    ev = PROF.begin(A.device)
+    check(_lib.load().mr_gemm_tile_f32(
+        ptr(A), A.stride(0) if A.shape[0] > 1 else A.shape[1], int(trans_a), ptr(Bp[0]), ptr(Bp[1]), ptr(Bp[2]),
+        Bs[0].stride(0) if Bs[0].shape[0] > 1 else Bs[0].shape[1], int(trans_b), nb, seg_b, ptr(biases[0]), ptr(biases[1]),
+        ptr(biases[2]), M, N, K, ptr(residual), 0 if residual is None else residual.stride(0), ptr(Cp[0]), ptr(Cp[1]), ptr(Cp[2]), outs[0].stride(0), nc,
+        seg_c, ptr(cs[0]), ptr(cs[1]), ptr(cs[2]), epi, ptr(E), 0 if E is None else E.stride(0), ptr(out2), 0 if out2 is None else out2.stride(0),
+        float(drop_p), int(drop_key), bn, _stream(A)), "mr_gemm_tile_f32")
+    PROF.end(ev, A.device, "gemm_tile", flops=2.0 * M * N * K, nbytes=4.0 * (M * K + N * K + M * N))
+    return outs[0] if nc == 1 else outs
+
+
 def transpose_pad(x: torch.Tensor, out: Optional[torch.Tensor] = None, pad: int = 16) -> torch.Tensor:
     """(R, C) -> (C, R padded to a multiple of ``pad``) with the pad columns zeroed: the K-contiguous operand layout of the NT GEMM."""
     _dev(x, "x", torch.float32)

@@ -4,7 +4,7 @@
 TEST INFRASTRUCTURE.  north_star's clause "NDCG@10 within 1e-3 of reference across all 8 Amazon domains", for BASELINE configs[3]'s model:
 ONE 8-domain task-vector merge of BLaIR-base at true dimensions (the reference's ``load_merging_module(TASK_VECTOR, TASK_WISE)`` +
 ``load_weights_from_dict`` + ``get_state_dict()``, merge_test.py:35-71, fixed per-domain alpha), evaluated the way merge_test.py evaluates
-it -- on EVERY domain's full catalog (mergerec_amd.synthetic.CATALOG_SIZES: 4,968 ... 27,932 items, 114,075 in all) with 1,024 test users
+it -- on EVERY domain's full catalog (mergerec_amd.synthetic.CATALOG_SIZES: 4,968 ... 27,932 items, 114,075 in all) with 4,096 test users
 per domain: transformers' RobertaModel (the arithmetic the reference delegates to, models/_base.py:56, encoder/_base.py:37-45), CLS pooled,
 ``F.normalize`` (module.py:74-77), ``user @ item.T`` (module.py:137), ``cross_entropy(scores / 0.05)`` (module.py:356), the reference's
 ``Evaluator`` (evaluator.py:31-49, metrics.py:38-88) as imported -- all on the CPU in fp32.
@@ -25,12 +25,12 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "oracle"))
 
-N_USERS, U_KEEP, E_STRIDE = 1024, 256, 64
-# r03: with 1,024 users ONE label crossing a Recall cut-off through a verified 2e-6 near-tie moves that metric by 9.8e-4 -- the whole 1e-3 bound.
-# The five domains where that happened are evaluated on 4,096 users (2.4e-4 per user); `python oracle/gen_golden_8domain.py <names>` regenerates
-# a subset into g13_partial.pt and `--merge` folds it into the fixture.
-LABEL_WIN = 8  # reference scores kept either side of the label's rank (r02: 3; a 4,096-user domain holds a label that moves 4 places through near-ties)
-N_USERS_WIDE = {"Beauty": 4096, "Sports": 4096, "Instruments": 4096, "Office": 4096, "Scientific": 4096}
+N_USERS, U_KEEP, E_STRIDE = 4096, 256, 64
+# With 1,024 users ONE label crossing a Recall cut-off through a verified near-tie moves that metric by 9.8e-4 -- the whole 1e-3 bound; with
+# 4,096 users it is 2.4e-4.  r04: EVERY domain is evaluated on 4,096 users (r03 had widened only the five domains where the crossing had been
+# observed -- a fixture tuned per domain) and every entry is written by THIS revision of the script (17-column label windows).
+# `python oracle/gen_golden_8domain.py <names>` regenerates a subset into g13_partial.pt and `--merge` folds it into the fixture.
+LABEL_WIN = 8  # reference scores kept either side of the label's rank
 SEED_PRE, SEED_FT = 2000, tuple(range(2001, 2009))
 ALPHAS = (0.30, 0.10, 0.20, 0.15, 0.05, 0.25, 0.10, 0.20)
 SEED_DOMAIN0 = 31000
@@ -47,6 +47,7 @@ def merge_partial():
         full["domains"][name] = d
     for name, d in full["domains"].items():
         d.setdefault("n_users", full["n_users"])
+    full["n_users"] = part["n_users"]
     torch.save(full, full_p)
     part_p.unlink()
     print("merged", list(part["domains"]), "->", full_p, full_p.stat().st_size)
@@ -113,7 +114,6 @@ def main():
         if only and name not in only:
             continue
         seed = SEED_DOMAIN0 + d
-        N_USERS = N_USERS_WIDE.get(name, 1024)
         dom = make_domain(name, M, N_USERS, 32, cfg.vocab, seed)
         E = encode(dom.item_batches, "items", name)
         U = encode(dom.sequence_batches, "sequence", name)
@@ -136,7 +136,7 @@ def main():
                              metrics={k: float(v) for k, v in metrics.items()}, loss=loss)
         print(f"{name}: M={M} NDCG@10={metrics['test/NDCG@10']:.4f} loss={loss:.4f}  {time.time() - t0:.0f}s", flush=True)
 
-    out = dict(n_users=1024, u_keep=U_KEEP, e_stride=E_STRIDE, seed_pre=SEED_PRE, seed_ft=list(SEED_FT), alphas=list(ALPHAS), ft_std=1e-3, ks=ks,
+    out = dict(n_users=N_USERS, u_keep=U_KEEP, e_stride=E_STRIDE, seed_pre=SEED_PRE, seed_ft=list(SEED_FT), alphas=list(ALPHAS), ft_std=1e-3, ks=ks,
                key_order=list(pre.keys()), pre_checksum=float(sum(v.double().sum() for v in pre.values())),
                merged_checksum=float(sum(v.double().sum() for v in merged.values())), domains=domains,
                versions=dict(torch=str(torch.__version__), transformers=str(__import__("transformers").__version__)))

@@ -663,3 +663,59 @@ def test_randomised_differential_fuzz(tool, env):
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, str(root / "tools" / tool)], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------ token-sized training products (csrc/gemm_train.hip)
+@pytest.mark.parametrize("bn", [32, 64])
+@pytest.mark.parametrize("ta,tb,M,N,K", [(False, False, 602, 768, 768), (False, False, 70, 192, 3072), (False, True, 602, 768, 2304), (False, True, 33, 3072, 768),
+                                        (True, True, 768, 768, 602), (True, True, 2304, 768, 37), (True, True, 128, 3072, 1), (True, False, 64, 100, 32)])
+def test_gemm_tile_is_the_k_ordered_fma_chain_in_every_orientation(ops, bn, ta, tb, M, N, K):
+    """C = Aop Bop^T read from either orientation of either operand, 64 x 32 and 64 x 64 tiles on the two fp32 MFMA shapes: bit-equal to the
+    C oracle's ascending-k FMA chain (oracle/oracle_c.c gemm_nt_ref), ragged M / N / K tails, token-deep K that is no multiple of 16."""
+    g = _g(M + 3 * N + 7 * K + bn)
+    Aop, Bop = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    A = (Aop.t().contiguous() if ta else Aop).to(DEV)
+    B = (Bop.t().contiguous() if tb else Bop).to(DEV)
+    got = ops.gemm_tile(A, [B], trans_a=ta, trans_b=tb, bn=bn).cpu()
+    assert torch.equal(got, CO.gemm_nt(Aop, Bop)), float((got - CO.gemm_nt(Aop, Bop)).abs().max())
+
+
+def test_gemm_tile_segments_and_epilogues(ops):
+    g = _g(4242)
+    T, d, di = 150, 128, 256
+    x = torch.randn(T, d, generator=g)
+    Ws = [torch.randn(d, d, generator=g) * 0.1 for _ in range(3)]
+    bs = [torch.randn(d, generator=g) for _ in range(3)]
+    xd = x.to(DEV)
+    # forward of the stacked q / k / v projection: three weights, one launch
+    qkv = ops.gemm_tile(xd, [w.to(DEV) for w in Ws], biases=[b.to(DEV) for b in bs]).cpu()
+    want = torch.cat([CO.gemm_nt(x, w) + b for w, b in zip(Ws, bs)], dim=1)
+    assert torch.equal(qkv, want)
+    # its input gradient: dX = dQKV [Wq; Wk; Wv] (+ residual), the weights stacked along k
+    dqkv, res = torch.randn(T, 3 * d, generator=g), torch.randn(T, d, generator=g)
+    dx = ops.gemm_tile(dqkv.to(DEV), [w.to(DEV) for w in Ws], trans_b=True, residual=res.to(DEV)).cpu()
+    wcat = torch.cat(Ws, dim=0)
+    assert torch.equal(dx, CO.gemm_nt(dqkv, wcat.t().contiguous()) + res)
+    # its weight gradients and bias gradients: three (d, d) outputs + three (d,) column sums from one (T, 3 d) dY
+    dws = [torch.full((d, d), 7.5, device=DEV) for _ in range(3)]
+    dbs = [torch.full((d,), 7.5, device=DEV) for _ in range(3)]
+    ops.gemm_tile(dqkv.to(DEV), [xd], trans_a=True, trans_b=True, out=dws, colsum=dbs)
+    for s_ in range(3):
+        dy = dqkv[:, s_ * d:(s_ + 1) * d]
+        assert torch.equal(dws[s_].cpu(), CO.gemm_nt(dy.t().contiguous(), x.t().contiguous()))
+        assert torch.allclose(dbs[s_].cpu(), dy.sum(0), rtol=1e-5, atol=1e-5)
+    # GELU forward (both outputs) and backward epilogues, dropout + residual
+    W1, b1 = torch.randn(di, d, generator=g) * 0.1, torch.randn(di, generator=g)
+    act = torch.empty(T, di, device=DEV)
+    u = ops.gemm_tile(xd, [W1.to(DEV)], biases=[b1.to(DEV)], epi=ops.EPI_GELU_FWD, out2=act).cpu()
+    assert torch.equal(u, CO.gemm_nt(x, W1) + b1)
+    assert torch.allclose(act.cpu(), torch.nn.functional.gelu(u), atol=2e-6, rtol=1e-6)
+    dyo = torch.randn(T, d, generator=g)
+    W2 = torch.randn(d, di, generator=g) * 0.1
+    du = ops.gemm_tile(dyo.to(DEV), [W2.to(DEV)], trans_b=True, epi=ops.EPI_GELU_BWD, E=u.to(DEV)).cpu()
+    di_ = CO.gemm_nt(dyo, W2.t().contiguous())
+    assert torch.allclose(du, ops.gelu_bwd(u.to(DEV), di_.to(DEV)).cpu(), atol=1e-6, rtol=1e-6)
+    key = ops.dropout_site_key(3, 1, 0, ops.DROP_SITE_ATTN_OUT)
+    y = ops.gemm_tile(xd, [Ws[0].to(DEV)], biases=[bs[0].to(DEV)], residual=res.to(DEV), drop_p=0.1, drop_key=key).cpu()
+    plain = (CO.gemm_nt(x, Ws[0]) + bs[0]).to(DEV)
+    assert torch.equal(y, ops.dropout_rows(plain, 0.1, key, residual=res.to(DEV)).cpu())
