@@ -21,16 +21,12 @@
 #include "dropout.h"
 #include <stdlib.h>
 
-#ifndef MR_TILE_SCHED
-#define MR_TILE_SCHED 1
-#endif
-
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, kThreads = 256;
+constexpr int BM = 64, kThreads = 512;   // 4 consumer waves (MFMA) + 4 producer waves (global -> LDS staging)
 
 struct Args {
     const float* A; int64_t lda;
@@ -74,7 +70,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tile_kernel(const Args g) {
     using TAi = Tile<TA, BM, BK, WIDE>;
     using TBi = Tile<TB, BN, BK, WIDE>;
     constexpr int SA = TAi::S, SB = TBi::S;
-    constexpr bool kSched = MR_TILE_SCHED;
     constexpr int kDepth = KD;                // k-tiles in flight (even: the LDS buffer of a ring slot is then a compile-time constant)
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     float* const As0 = lds_dyn;               // [2][BK * SA]
@@ -85,7 +80,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tile_kernel(const Args g) {
     const int tn = pid / g.tiles_m, tm = pid - tn * g.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int M = g.M, N = g.N, K = g.K;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Wave specialisation: waves 0-3 own the accumulators and do nothing but LDS operand reads and MFMAs; waves 4-7 stage the operand tiles
+    // (global -> registers -> LDS).  A SIMD then holds one wave of each kind, and the staging work (address updates, zero fill, LDS writes,
+    // waiting for global memory) overlaps the other wave's MFMA chain instead of queueing behind it in one instruction stream -- with one
+    // 256-thread workgroup per CU the matrix pipe sat idle 70 % of the time (SQ counters, profiles/r04_sq_gemm_tile.txt).
+    const bool producer = threadIdx.x >= 256;   // wave-uniform
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
     // ---- global -> registers -> LDS ([k][m] / [k][n] images)
@@ -219,38 +219,32 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tile_kernel(const Args g) {
         }
     };
 
-    // ---- main loop: register ring of kDepth stages, double-buffered LDS, one barrier per k-tile
+    // ---- main loop: double-buffered LDS, ONE barrier per k-tile, executed by both kinds of wave (the same count on either path)
     const int nk = (K + BK - 1) / BK;
     auto ktile = [&](int kt) { return kt < nk ? kt : 0; };  // past-the-end prefetches re-read tile 0 (never consumed)
-    Stage ring[kDepth];
+    if (producer) {
+        Stage ring[kDepth];   // register ring: tile kt + kDepth is requested while tile kt + 1 is written to LDS
 #pragma unroll
-    for (int j = 0; j < kDepth; ++j) gload(ktile(j), ring[j]);
-    lstore(0, ring[0], 0);
-    __syncthreads();
-    for (int kt0 = 0; kt0 < nk; kt0 += kDepth) {
+        for (int j = 0; j < kDepth; ++j) gload(ktile(j), ring[j]);
+        lstore(0, ring[0], 0);
+        __syncthreads();                                   // tile 0 is in LDS
+        for (int kt0 = 0; kt0 < nk; kt0 += kDepth) {
 #pragma unroll
-        for (int j = 0; j < kDepth; ++j) {
-            const int kt = kt0 + j;
-            if (kt < nk) {  // uniform
-                gload(ktile(kt + kDepth), ring[j]);  // slot j's tile (kt) is already in LDS: refill it with tile kt + kDepth
-                compute(j & 1);
-                lstore((j + 1) & 1, ring[(j + 1) % kDepth], ktile(kt + 1));  // tile kt + 1 (a re-read of tile 0 after the last one)
-                // ONE scheduling region per k-tile: with one workgroup per CU a SIMD holds a single wave, so nothing but this wave's own
-                // instruction stream can fill the matrix pipe's dependency gaps -- interleave the zero-fill selects, address updates and LDS
-                // traffic of the staging with the MFMA chain instead of running them behind it.
-                if (kSched) {
-#pragma unroll
-                    for (int q = 0; q < (WIDE ? BK / 2 : BK / 2); ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // a few VALU
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // LDS reads
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS write
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
-                    }
+            for (int j = 0; j < kDepth; ++j) {
+                const int kt = kt0 + j;
+                if (kt < nk) {  // uniform
+                    gload(ktile(kt + kDepth), ring[j]);    // slot j's tile (kt) is already in LDS: refill it
+                    lstore((kt + 1) & 1, ring[(j + 1) % kDepth], ktile(kt + 1));  // buffer (kt + 1) & 1 was last read for tile kt - 1
+                    __syncthreads();                       // consumers finished tile kt; tile kt + 1 is in LDS
                 }
-                __syncthreads();
             }
         }
+        return;   // the epilogue belongs to the consumer waves (no barrier behind this point)
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        compute(kt & 1);
+        __syncthreads();
     }
 
     // ---- epilogue
@@ -370,14 +364,17 @@ extern "C" int mr_gemm_tile_f32(const float* A, int64_t lda, int trans_a, const 
     // 32-bit element offsets inside the kernel
     if ((int64_t)(trans_a ? K : M) * lda >= (1ll << 31) || (int64_t)(trans_b ? seg_b : N) * ldb >= (1ll << 31)) return MR_EUNSUPPORTED;
     const bool zf = (K % 64) != 0;
-#define MR_GT(TA_, TB_, BN_, ZF_)                                                                                                          \
-    do {                                                                                                                                   \
-        constexpr size_t shm_ = (size_t)2 * 64 * (Tile<TA_, BM, 64, BN_ == 64>::S + Tile<TB_, BN_, 64, BN_ == 64>::S) * sizeof(float);      \
-        static mr::DynLdsCeiling lds_ceiling;                                                                                              \
-        if (const int e_ = lds_ceiling.ensure(reinterpret_cast<const void*>(&gemm_tile_kernel<TA_, TB_, BN_, 64, 2, ZF_>), shm_)) return e_; \
-        hipLaunchKernelGGL((gemm_tile_kernel<TA_, TB_, BN_, 64, 2, ZF_>), dim3(g.nwg), dim3(kThreads), shm_, st, g);                        \
+    static const int kd_env = [] { const char* e = getenv("MR_GEMM_TILE_KD"); return e ? atoi(e) : 0; }();  // A/B: 2 / 3 / 4 tiles in flight
+    const int kd = (kd_env >= 2 && kd_env <= 4) ? kd_env : 3;
+#define MR_GT(TA_, TB_, BN_, ZF_, KD_)                                                                                                       \
+    do {                                                                                                                                     \
+        constexpr size_t shm_ = (size_t)2 * 64 * (Tile<TA_, BM, 64, BN_ == 64>::S + Tile<TB_, BN_, 64, BN_ == 64>::S) * sizeof(float);        \
+        static mr::DynLdsCeiling lds_ceiling;                                                                                                \
+        if (const int e_ = lds_ceiling.ensure(reinterpret_cast<const void*>(&gemm_tile_kernel<TA_, TB_, BN_, 64, KD_, ZF_>), shm_)) return e_; \
+        hipLaunchKernelGGL((gemm_tile_kernel<TA_, TB_, BN_, 64, KD_, ZF_>), dim3(g.nwg), dim3(kThreads), shm_, st, g);                        \
     } while (0)
-#define MR_GT3(TA_, TB_, BN_) do { if (zf) MR_GT(TA_, TB_, BN_, true); else MR_GT(TA_, TB_, BN_, false); } while (0)
+#define MR_GT4(TA_, TB_, BN_, ZF_) do { if (kd == 2) MR_GT(TA_, TB_, BN_, ZF_, 2); else if (kd == 3) MR_GT(TA_, TB_, BN_, ZF_, 3); else MR_GT(TA_, TB_, BN_, ZF_, 4); } while (0)
+#define MR_GT3(TA_, TB_, BN_) do { if (zf) MR_GT4(TA_, TB_, BN_, true); else MR_GT4(TA_, TB_, BN_, false); } while (0)
     if (bn == 64) {
         if (trans_a) { if (trans_b) MR_GT3(true, true, 64); else MR_GT3(true, false, 64); }
         else { if (trans_b) MR_GT3(false, true, 64); else MR_GT3(false, false, 64); }
@@ -386,6 +383,7 @@ extern "C" int mr_gemm_tile_f32(const float* A, int64_t lda, int trans_a, const 
         else { if (trans_b) MR_GT3(false, true, 32); else MR_GT3(false, false, 32); }
     }
 #undef MR_GT3
+#undef MR_GT4
 #undef MR_GT
     return mr::check_launch();
 }
