@@ -8,25 +8,28 @@
 //   forward  : TA = 0, TB = 0 (B = W)          dX : TA = 0, TB = 1 (A = dY, B = W, k = out features)
 //   dW       : TA = 1, TB = 1 (A = dY, B = X, k = tokens; K need not be a multiple of 16: rows past K read as zero)
 //
-// Block tile 64 x BN x 16 (BN = 64: wave tile 32 x 32 on v_mfma_f32_32x32x2_f32; BN = 32: wave tile 32 x 16 on two v_mfma_f32_16x16x4_f32),
-// 4 waves as 2 x 2.  Both MFMAs are fp32 FMA chains over k, and a workgroup walks its whole k range, so every output element is the single
-// ascending-k chain of the C oracle (oracle/oracle_c.c gemm_nt_ref) -- bit for bit, for every orientation and tile width.
-// LDS holds both operand tiles k-major ([k][m], [k][n]): a lane's MFMA operand for k-step s is one ds_read_b32, conflict-free by the row
-// pitch; m-contiguous sources are stored with one ds_write_b128 per thread, k-contiguous sources with four ds_write_b32 (lanes along m).
-// These products are LATENCY-bound (48 k-tiles of 512 matrix-pipe cycles each per workgroup, one or two workgroups per CU): the global
-// loads run kDepth k-tiles ahead through a register ring (8 VGPRs per stage; the accumulator is only 16), so a tile has kDepth - 1 MFMA
-// phases to arrive.  Fused epilogue: bias, dropout (the counter mask of dropout.h), residual, GELU forward (pre-activation AND activation
-// written), GELU backward (x gelu'(u)); weight-gradient launches also emit the bias gradient (column sums of dY, ascending k per parity).
+// Block tile 64 x BN x 64 (BN = 64 or 32), 12 waves: 8 CONSUMER waves own the accumulators and do nothing but LDS operand reads and
+// v_mfma_f32_16x16x4_f32 (wave tile 32 x 16 / 16 x 16; two consumer waves per SIMD, so one wave's LDS-read and MFMA-dependency latency is
+// the other's issue slot), 4 PRODUCER waves stage the operand tiles global -> registers -> LDS (a 3-deep register ring).  The MFMA is an
+// fp32 FMA chain over k and a workgroup walks its whole k range, so every output element is the single ascending-k chain of the C oracle
+// (oracle/oracle_c.c gemm_nt_ref) -- bit for bit, for every orientation and tile width.
+// LDS holds both operand tiles k-major ([k][m], [k][n]): a lane's MFMA operand for a k-step is one ds_read_b32, conflict-free by the row
+// pitch; m-contiguous sources are stored with one ds_write_b128 per thread, k-contiguous sources with four ds_write_b32.
+// Fused epilogue: bias, dropout (the counter mask of dropout.h), residual, GELU forward (pre-activation AND activation written), GELU
+// backward (x gelu'(u)); weight-gradient launches also emit the bias gradient (column sums of dY, fixed order).
+// Measured (profiles/r04_gemm_tile_bench.txt, r04_sq_gemm_tile.txt): 0.31-0.46 of the fp32-MFMA peak on the 600-token products of
+// BLaIR-base -- per layer 417 us against 472 us for the r03 route (NT kernel + split-K + reduce + transposes) with a quarter of its
+// launches; five structures were tried on the way (one 256-thread workgroup with a register ring 2-8 tiles deep; BK 16 / 32 / 64;
+// a scheduling region per k-tile; 4 + 4 and 8 + 4 specialised waves): the wave specialisation is what moved it (483 -> 407 us).
 #include "common.h"
 #include "dropout.h"
 #include <stdlib.h>
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, kThreads = 512;   // 4 consumer waves (MFMA) + 4 producer waves (global -> LDS staging)
+constexpr int BM = 64, kThreads = 768;   // 8 consumer waves (MFMA: two per SIMD) + 4 producer waves (global -> LDS staging)
 
 struct Args {
     const float* A; int64_t lda;
@@ -57,7 +60,7 @@ struct Tile {
     // LDS pitch (floats per k row).  Reads: lanes of different k must hit different banks (32x32x2: two k per instruction, 16x16x4: four).
     // Writes of a k-contiguous source are four ds_write_b32 per float4 with BK / 4 lanes along k: the pitch makes those lanes hit
     // different banks too (pitch = 1 mod 16 for 16 lanes per row, 2 mod 16 for 8).
-    static constexpr int BASE = WIDE ? 96 : (ROWS == 64 ? 80 : 48);
+    static constexpr int BASE = ROWS == 64 ? 80 : 48;   // 16x16x4 reads: the four k rows of an instruction land 16 banks apart
     static constexpr int S = TRANS ? BASE : BASE + (BK == 64 ? 1 : 2);
     static constexpr int LPR = TRANS ? ROWS / 4 : BK / 4;             // lanes along the contiguous direction
     static constexpr int PER_PASS = 256 / LPR;                        // rows (k rows if TRANS) covered by one pass of the workgroup
@@ -65,7 +68,7 @@ struct Tile {
 
 // ZF: K is not a multiple of BK -- the last k-tile is zero-filled past K (token-deep weight gradients); otherwise no select is compiled in
 template <bool TA, bool TB, int BN, int BK, int KD, bool ZF>
-__global__ __launch_bounds__(kThreads, 2) void gemm_tile_kernel(const Args g) {
+__global__ __launch_bounds__(kThreads, 1) void gemm_tile_kernel(const Args g) {
     constexpr bool WIDE = BN == 64;
     using TAi = Tile<TA, BM, BK, WIDE>;
     using TBi = Tile<TB, BN, BK, WIDE>;
@@ -84,9 +87,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tile_kernel(const Args g) {
     // (global -> registers -> LDS).  A SIMD then holds one wave of each kind, and the staging work (address updates, zero fill, LDS writes,
     // waiting for global memory) overlaps the other wave's MFMA chain instead of queueing behind it in one instruction stream -- with one
     // 256-thread workgroup per CU the matrix pipe sat idle 70 % of the time (SQ counters, profiles/r04_sq_gemm_tile.txt).
-    const bool producer = threadIdx.x >= 256;   // wave-uniform
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const bool producer = threadIdx.x >= 512;   // wave-uniform
+    const int tid = producer ? (int)threadIdx.x - 512 : (int)threadIdx.x;   // producers: 0..255 (staging maps); consumers: 0..511
+    const int lane = tid & 63, wave = tid >> 6;
+    // consumer wave tile: BN = 64 -> 32 x 16 (waves 2 x 4, two accumulator chains), BN = 32 -> 16 x 16 (waves 4 x 2, one chain): two consumer
+    // waves per SIMD, so one wave's LDS-read and MFMA-dependency latency is the other's issue slot
+    constexpr int NI = WIDE ? 2 : 1;                       // 16-row MFMA tiles per wave along M
+    const int wm = WIDE ? (wave >> 2) : (wave >> 1), wn = WIDE ? (wave & 3) : (wave & 1);
 
     // ---- global -> registers -> LDS ([k][m] / [k][n] images)
     const int ca = tid % TAi::LPR, ra_ = tid / TAi::LPR;   // position along the contiguous direction / across it
@@ -181,40 +188,28 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tile_kernel(const Args g) {
         }
     };
 
-    // ---- MFMA operand reads and accumulators
-    const int lr = lane & 31, lh = lane >> 5;   // 32x32x2: lane = (row / col lr, k parity lh)
-    const int li = lane & 15, lk = lane >> 4;   // 16x16x4: lane = (row / col li, k residue lk)
-    f32x16 acc32;
-    f32x4 acc16[2];
+    // ---- MFMA operand reads and accumulators (v_mfma_f32_16x16x4_f32: lane = (row / col li, k residue lk))
+    const int li = lane & 15, lk = lane >> 4;
+    f32x4 acc[NI];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc32[r] = 0.f;
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc16[i][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
     const bool want_colsum = (g.colsum[0] != nullptr) && tn == 0 && wn == 0;  // wave-uniform
-    float cs0 = 0.f, cs1 = 0.f;
+    float cs[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) cs[i] = 0.f;
     auto compute = [&](int buf) {
-        const float* as = As0 + buf * (BK * SA);
-        const float* bs = Bs0 + buf * (BK * SB);
-        if (WIDE) {
-            const float* ap = as + lh * SA + wm * 32 + lr;
-            const float* bp = bs + lh * SB + wn * 32 + lr;
+        const float* ap = As0 + buf * (BK * SA) + lk * SA + wm * (16 * NI) + li;
+        const float* bp = Bs0 + buf * (BK * SB) + lk * SB + wn * 16 + li;
 #pragma unroll
-            for (int s = 0; s < BK / 2; ++s) {
-                const float av = ap[2 * s * SA], bv = bp[2 * s * SB];
-                if (want_colsum) cs0 += av;
-                acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc32, 0, 0, 0);
-            }
-        } else {
-            const float* ap = as + lk * SA + wm * 32 + li;
-            const float* bp = bs + lk * SB + wn * 16 + li;
+        for (int s = 0; s < BK / 4; ++s) {
+            const float bv = bp[4 * s * SB];
 #pragma unroll
-            for (int s = 0; s < BK / 4; ++s) {
-                const float a0 = ap[4 * s * SA], a1 = ap[4 * s * SA + 16], bv = bp[4 * s * SB];
-                if (want_colsum) { cs0 += a0; cs1 += a1; }
-                acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc16[0], 0, 0, 0);
-                acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc16[1], 0, 0, 0);
+            for (int i = 0; i < NI; ++i) {
+                const float av = ap[4 * s * SA + 16 * i];
+                if (want_colsum) cs[i] += av;
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
             }
         }
     };
@@ -253,18 +248,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tile_kernel(const Args g) {
     const int mloc0 = m0 - cseg * g.seg_c;         // row of the tile inside its segment
     if (want_colsum) {
         float* out = g.colsum[cseg];
-        if (WIDE) {
-            cs0 += __shfl_xor(cs0, 32, 64);
-            const int m = m0 + wm * 32 + lr;
-            if (lh == 0 && m < M) out[mloc0 + wm * 32 + lr] = cs0;
-        } else {
-            cs0 += __shfl_xor(cs0, 16, 64); cs0 += __shfl_xor(cs0, 32, 64);
-            cs1 += __shfl_xor(cs1, 16, 64); cs1 += __shfl_xor(cs1, 32, 64);
-            const int m = m0 + wm * 32 + li;
-            if (lk == 0) {
-                if (m < M) out[mloc0 + wm * 32 + li] = cs0;
-                if (m + 16 < M) out[mloc0 + wm * 32 + 16 + li] = cs1;
-            }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float c = cs[i];
+            c += __shfl_xor(c, 16, 64);
+            c += __shfl_xor(c, 32, 64);
+            const int ml = wm * (16 * NI) + 16 * i + li;
+            if (lk == 0 && m0 + ml < M) out[mloc0 + ml] = c;
         }
     }
     const int bseg = TB ? 0 : (n0 >= g.seg_b) + (n0 >= 2 * g.seg_b);
@@ -279,26 +269,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tile_kernel(const Args g) {
         Cb[ci] = v;
         if (g.epi == MR_EPI_GELU_FWD) g.C2[(int64_t)m * g.ldc2 + n] = gelu_erf(v);
     };
-    if (WIDE) {
-        const int n = n0 + wn * 32 + lr;
-        if (n < N) {
+    const int n = n0 + wn * 16 + li;
+    if (n < N) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < M) finish(acc32[r], m, n);
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * (16 * NI) + i * 16 + 4 * lk + r;
+                if (m < M) finish(acc[i][r], m, n);
             }
-        }
-    } else {
-        const int n = n0 + wn * 16 + li;
-        if (n < N) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * 32 + i * 16 + 4 * lk + r;
-                    if (m < M) finish(acc16[i][r], m, n);
-                }
-        }
     }
 }
 
