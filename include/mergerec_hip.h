@@ -421,6 +421,22 @@ size_t mr_layernorm_bwd_ws_bytes(int T, int d);
 int mr_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ldy, const float* gamma, float eps, int T, int d,
                          float* dx, int64_t lddx, float* stats, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mr_stream_t stream);
 
+/* mr_distill_loss_rows_f32 with a per-row length: row r holds row_M[r] logits (device int32, every entry in [1, M_max]) -- ONE launch for the
+ * rows of several catalogs (module/distiller/sequence/module.py:62-72 loops the samples; a step's 16 samples are spread over the domains). */
+int mr_distill_loss_rows_var_f32(const float* z, int64_t ldz, const float* t, int64_t ldt, int64_t rows, int64_t M_max, const int32_t* row_M,
+                                 int label_src, float w_ce, float w_kd, float temperature, float w_ent, float w_mse, float w_pair, float margin,
+                                 float w_listnet, float* loss_row, float* dz, int64_t lddz, float grad_scale, mr_stream_t stream);
+
+/* Skinny scoring of the distillation step: out[i][m] = <reps[i], E[m]> for n <= 8 representation rows against a whole catalog (M, d),
+ * d % 4 == 0, d <= 1024 -- one HBM-bound stream over E (module/distiller/sequence/module.py:66: ``rep @ item_embedding.T`` per sample;
+ * the MFMA tile kernel needs >= 64 rows to pay).  mr_skinny_bwd_f32: d_reps[i][:] = scale * sum_m dz[i][m] E[m][:] (its autograd),
+ * per-workgroup partial sums in ws (mr_skinny_bwd_ws_bytes) added in a fixed order. */
+int mr_skinny_scores_f32(const float* reps, int64_t ldr, int n, const float* E, int64_t lde, int64_t M, int d, float* out, int64_t ldo,
+                         mr_stream_t stream);
+size_t mr_skinny_bwd_ws_bytes(int n, int64_t M, int d);
+int mr_skinny_bwd_f32(const float* dz, int64_t lddz, int n, const float* E, int64_t lde, int64_t M, int d, float scale, float* d_reps, void* ws,
+                      size_t ws_bytes, mr_stream_t stream);
+
 /* Token-sized exact-fp32 products of the collaborative-merging step (merge_train.py; autograd through transformers' Linear layers under
  * merger/weight_learning/module/_base.py:78-81 and module/distiller/sequence/module.py:59-79): C = Aop Bop^T where either operand is read
  * in either orientation, so forward (Y = X W^T: trans_a = 0, trans_b = 0), input gradient (dX = dY W: 0, 1) and weight gradient

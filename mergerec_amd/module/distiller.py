@@ -12,6 +12,8 @@ through ``mr_merge_bwd_alpha_f32``.  (Row normalisation of the teacher embedding
 plain torch ops: a few (rows, d) tensors per step.)"""
 from __future__ import annotations
 
+import os
+
 from typing import List, Literal, Optional, Sequence
 
 import torch
@@ -55,6 +57,47 @@ class _GroupLossFn(torch.autograd.Function):
         if ctx.dz_pad is None:
             return None, None, None, None, None, None
         d_reps = ops.gemm_nt_train(ctx.dz_pad, ctx.Et_pad)  # (n, Mpad) @ (d, Mpad).T: a handful of rows, k = catalog size -> split-K
+        return d_reps * grad_out, None, None, None, None, None
+
+
+class _BatchedLossFn(torch.autograd.Function):
+    """module.py:62-72 for the whole batch at once: z = rep @ E_ds.T per dataset group (ops.skinny_scores: a handful of rows against a whole
+    catalog is one stream over E, not an MFMA tile job), ONE fused loss launch over all rows with per-row catalog sizes, and in backward
+    d rep = dz @ E_ds per group (ops.skinny_scores_bwd).  Values equal the per-group path's up to summation order."""
+
+    @staticmethod
+    def forward(ctx, reps_sorted, module, groups, sid_dev, loss_fn: DistillLossBase, batch_size: int):
+        dev = reps_sorted.device
+        B = reps_sorted.shape[0]
+        m_max = max(module._items[d_i].shape[0] for d_i, _, _ in groups)
+        ld = m_max
+        z = torch.empty(B, ld, dtype=torch.float32, device=dev)
+        t = torch.empty(B, ld, dtype=torch.float32, device=dev)
+        row_m = torch.empty(B, dtype=torch.int32)
+        reps_c = reps_sorted.contiguous()
+        for d_i, off, n in groups:
+            M = module._items[d_i].shape[0]
+            row_m[off:off + n] = M
+            ops.skinny_scores(reps_c[off:off + n], module._items[d_i], out=z[off:off + n, :M])
+            ops.gather_rows(module.score_embeddings[d_i], sid_dev[off:off + n], out=t[off:off + n, :M])
+        row_m_dev = row_m.to(dev, non_blocking=True)
+        need_grad = reps_sorted.requires_grad
+        dz = torch.empty(B, ld, dtype=torch.float32, device=dev) if need_grad else None
+        rows, _ = ops.distill_loss_rows(z[:, :m_max], t[:, :m_max], grad_scale=1.0 / batch_size, dz=None if dz is None else dz[:, :m_max], row_M=row_m_dev,
+                                        **loss_fn.spec())
+        ctx.dz, ctx.groups, ctx.module = dz, groups, module
+        return rows.sum() / batch_size
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.dz is None:
+            return None, None, None, None, None, None
+        B = ctx.dz.shape[0]
+        d = ctx.module._items[ctx.groups[0][0]].shape[1]
+        d_reps = torch.empty(B, d, dtype=torch.float32, device=ctx.dz.device)
+        for d_i, off, n in ctx.groups:
+            M = ctx.module._items[d_i].shape[0]
+            ops.skinny_scores_bwd(ctx.dz[off:off + n, :M], ctx.module._items[d_i], out=d_reps[off:off + n])
         return d_reps * grad_out, None, None, None, None, None
 
 
@@ -123,14 +166,16 @@ class DistillSequenceModule(nn.Module):
         idx_dev = torch.cat([perm, sid[perm]]).to(torch.int32).to(self.device, non_blocking=True)
         perm_dev, sid_dev = idx_dev[:B], idx_dev[B:]
         reps_sorted = representations.index_select(0, perm_dev.long())
-        total, off = None, 0
-        for d_i, n in enumerate(counts):
-            if n == 0:
-                continue
+        groups = [(d_i, off0, n) for d_i, n, off0 in zip(range(len(counts)), counts, [sum(counts[:i]) for i in range(len(counts))]) if n]
+        if os.environ.get("MR_DISTILL_BATCHED", "1") != "0":
+            # the whole batch through ONE loss launch: logits of every group written into one (B, M_max) block by the skinny scoring
+            # kernel (a stream over each catalog), teacher rows gathered beside them, per-row catalog sizes in a small table
+            return _BatchedLossFn.apply(reps_sorted, self, groups, sid_dev, self.loss_fn, B)
+        total = None
+        for d_i, off, n in groups:
             rows = ops.gather_rows(self.score_embeddings[d_i], sid_dev[off:off + n])
             part = _GroupLossFn.apply(reps_sorted[off:off + n], self._items[d_i], self._items_t[d_i], rows, self.loss_fn, B)
             total = part if total is None else total + part
-            off += n
         return total
 
     def _forward_distill(self, batch: BatchDistillationSequence):

@@ -568,11 +568,49 @@ def score_topk(U: torch.Tensor, E: torch.Tensor, k: int, labels: Optional[torch.
 
 
 # ------------------------------------------------------------------------------------------ distillation losses (next-row 2)
+def skinny_scores(reps: torch.Tensor, E: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i][m] = <reps[i], E[m]> for a handful of rows (any count: 8 per launch) against a whole catalog: one stream over E."""
+    _dev(reps, "reps", torch.float32), _dev(E, "E", torch.float32)
+    n, d = reps.shape
+    M = E.shape[0]
+    if E.shape[1] != d or reps.stride(1) != 1 or E.stride(1) != 1:
+        raise ValueError("reps (n, d) and E (M, d) with unit inner stride expected")
+    out = torch.empty(n, M, dtype=torch.float32, device=reps.device) if out is None else out
+    lib = _lib.load()
+    for i0 in range(0, n, 8):
+        k = min(8, n - i0)
+        check(lib.mr_skinny_scores_f32(ptr(reps[i0:]), reps.stride(0), k, ptr(E), E.stride(0), M, d, ptr(out[i0:]), out.stride(0), _stream(reps)),
+              "mr_skinny_scores_f32")
+    return out
+
+
+def skinny_scores_bwd(dz: torch.Tensor, E: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d_reps[i][:] = scale * sum_m dz[i][m] E[m][:] (dz (n, M) with unit inner stride, possibly a view of wider rows)."""
+    _dev(E, "E", torch.float32)
+    if not (isinstance(dz, torch.Tensor) and dz.is_cuda and dz.dtype == torch.float32 and dz.dim() == 2):
+        raise ValueError("dz must be a 2-D fp32 GPU tensor (the HIP path has no CPU fallback)")
+    n, M = dz.shape
+    d = E.shape[1]
+    if E.shape[0] != M or dz.stride(1) != 1:
+        raise ValueError("dz (n, M) and E (M, d) expected")
+    out = torch.empty(n, d, dtype=torch.float32, device=dz.device) if out is None else out
+    lib = _lib.load()
+    for i0 in range(0, n, 8):
+        k = min(8, n - i0)
+        nbytes = lib.mr_skinny_bwd_ws_bytes(k, M, d)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dz.device)
+        check(lib.mr_skinny_bwd_f32(ptr(dz[i0:]), dz.stride(0), k, ptr(E), E.stride(0), M, d, float(scale), ptr(out[i0:]), ptr(ws), nbytes, _stream(dz)),
+              "mr_skinny_bwd_f32")
+    return out
+
+
 def distill_loss_rows(z: torch.Tensor, t: Optional[torch.Tensor], *, label_src: int = 0, w_ce: float = 0.0, w_kd: float = 0.0,
                       temperature: float = 1.0, w_ent: float = 0.0, w_mse: float = 0.0, w_pair: float = 0.0, margin: float = 0.0,
-                      w_listnet: float = 0.0, want_grad: bool = False, grad_scale: float = 1.0, dz: Optional[torch.Tensor] = None):
+                      w_listnet: float = 0.0, want_grad: bool = False, grad_scale: float = 1.0, dz: Optional[torch.Tensor] = None,
+                      row_M: Optional[torch.Tensor] = None):
     """Per-row loss (rows,) and, if asked, grad_scale * d loss_row / d z (rows, M); see mr_distill_loss_rows_f32.
-    ``dz`` may be a caller-owned (rows, M) view with a padded leading dimension."""
+    ``dz`` may be a caller-owned (rows, M) view with a padded leading dimension.  ``row_M`` (device int32, rows): row r holds only
+    row_M[r] <= M logits -- the rows of several catalogs in one launch (mr_distill_loss_rows_var_f32)."""
     _dev(z, "z", torch.float32)
     if z.dim() != 2 or z.stride(1) != 1:
         raise ValueError("z must be a (rows, M) matrix with unit column stride")
@@ -587,9 +625,14 @@ def distill_loss_rows(z: torch.Tensor, t: Optional[torch.Tensor], *, label_src: 
     if dz is not None and (dz.shape != z.shape or dz.stride(1) != 1):
         raise ValueError("dz must match z")
     ev = PROF.begin(z.device)
-    check(_lib.load().mr_distill_loss_rows_f32(ptr(z), z.stride(0), ptr(t), t.stride(0) if t is not None else 0, rows, M, label_src, w_ce,
-                                               w_kd, temperature, w_ent, w_mse, w_pair, margin, w_listnet, ptr(loss_row), ptr(dz),
-                                               dz.stride(0) if dz is not None else 0, grad_scale, _stream(z)), "mr_distill_loss_rows_f32")
+    if row_M is not None:
+        check(_lib.load().mr_distill_loss_rows_var_f32(ptr(z), z.stride(0), ptr(t), t.stride(0) if t is not None else 0, rows, M, ptr(row_M), label_src,
+                                                       w_ce, w_kd, temperature, w_ent, w_mse, w_pair, margin, w_listnet, ptr(loss_row), ptr(dz),
+                                                       dz.stride(0) if dz is not None else 0, grad_scale, _stream(z)), "mr_distill_loss_rows_var_f32")
+    else:
+        check(_lib.load().mr_distill_loss_rows_f32(ptr(z), z.stride(0), ptr(t), t.stride(0) if t is not None else 0, rows, M, label_src, w_ce,
+                                                   w_kd, temperature, w_ent, w_mse, w_pair, margin, w_listnet, ptr(loss_row), ptr(dz),
+                                                   dz.stride(0) if dz is not None else 0, grad_scale, _stream(z)), "mr_distill_loss_rows_f32")
     PROF.end(ev, z.device, "distill_loss_rows", flops=0.0, nbytes=4.0 * rows * M * (2 + (1 if dz is not None else 0)))
     return loss_row, dz
 

@@ -105,7 +105,29 @@ class _FakeMerged(torch.nn.Module):
         return {"global_weights": {"g": [1.0]}, "global_biases": {"g": [0.0]}, "weights": {"g": [0.25, 0.75]}}
 
 
-def test_distill_module_matches_reference_loop_and_rep_gradient():
+@pytest.mark.parametrize("n,M,d", [(1, 1000, 768), (2, 22855, 768), (5, 4968, 1024), (8, 333, 128), (11, 777, 64)])
+def test_skinny_scores_and_their_gradient(n, M, d):
+    """a handful of representation rows against a whole catalog (the distillation step's ``rep @ E_ds.T`` per sample): the streaming kernels
+    against float64, forward and backward, row counts above one launch's eight, widths that are no multiple of 256"""
+    from mergerec_amd import ops
+
+    g = torch.Generator().manual_seed(n * 7 + M + d)
+    reps, E = torch.randn(n, d, generator=g), torch.nn.functional.normalize(torch.randn(M, d, generator=g), dim=-1)
+    out = torch.full((n, M + 5), 7.5, device=DEV)
+    ops.skinny_scores(reps.to(DEV), E.to(DEV), out=out[:, :M])
+    want = reps.double() @ E.double().T
+    assert float((out[:, :M].cpu().double() - want).abs().max()) <= 2e-6 * float(reps.abs().sum(1).max()) and bool((out[:, M:] == 7.5).all())
+    dz = torch.randn(n, M + 3, generator=g)
+    got = ops.skinny_scores_bwd(dz.to(DEV)[:, :M], E.to(DEV), scale=0.5).cpu()
+    wantg = 0.5 * (dz[:, :M].double() @ E.double())
+    assert float((got.double() - wantg).abs().max()) <= 1e-5 * float(wantg.abs().max())
+    again = ops.skinny_scores_bwd(dz.to(DEV)[:, :M], E.to(DEV), scale=0.5).cpu()
+    assert torch.equal(got, again)  # fixed summation order
+
+
+@pytest.mark.parametrize("batched", ["1", "0"])
+def test_distill_module_matches_reference_loop_and_rep_gradient(batched, monkeypatch):
+    monkeypatch.setenv("MR_DISTILL_BATCHED", batched)  # "1": one loss launch over every row (default); "0": the per-dataset loop of r01-r03
     from mergerec_amd.model_batch import BatchDistillationSequence
     from mergerec_amd.module import DistillSequenceModule
     from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
