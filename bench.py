@@ -68,9 +68,15 @@ def parse():
                     help="encoder arithmetic: f16x3 (bench default: 3 fp16 MFMA products per fp32 product, ~2^-21 each) / bf16x6 / bf16x3 = "
                          "6 / 3 bf16 products (~2^-24 / ~2^-16), f32 = exact fp32 MFMA.  The in-run `parity` object reports the distance to "
                          "the CPU oracle for the chosen mode.")
+    ap.add_argument("--pipelined-merge", type=int, choices=[0, 1], default=None,
+                    help="1: the per-step merge (+ arena all-gather under the sliced placement) + weight split run on a second HIP stream into a "
+                         "second arena, under the previous step's encoder kernels (TaskVectorMergingModuleBase.pipeline_merges); 0: on the step's "
+                         "own stream.  Default: 1 only where there is a collective to hide (N > 1 with --merge-placement sliced) -- on one GPU the "
+                         "A/B is a wash (38.36 / 38.38 ms: the 5 TB/s merge stream takes from the GEMMs what it saves)")
     ap.add_argument("--merge-placement", choices=["sliced", "replicated"], default=None,
-                    help="N > 1: 'sliced' (default; north_star's split) = each rank holds 1/N of the base vector and of every task vector, merges "
-                         "that arena slice, ONE all-gather assembles the arena; 'replicated' = every rank holds everything and merges alone")
+                    help="N > 1: 'replicated' (bench default: the merge runs every step) = every rank holds everything and merges alone, no "
+                         "collective; 'sliced' (north_star's split, the library default for merge-once runs) = each rank holds 1/N of the base "
+                         "vector and of every task vector, merges that arena slice, ONE all-gather assembles the arena")
     return ap.parse_args()
 
 
@@ -241,8 +247,14 @@ def _main(real_stdout):
     model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 1000, "gemm_mode": gemm_mode})
     spec, d = model.spec, model.spec.hidden
     pre, fts = synth_state_dicts(model, n_dom, dev)
+    # N > 1 default: "replicated".  The bench re-merges EVERY step (as the reference re-merges on every forward, _base.py:78-81); at that
+    # cadence the sliced placement's arena all-gather (499 MB x (N - 1) / N received per rank and step) costs more than the local merge it
+    # saves at N = 2 and 4 and about the same at N = 8 (predicted 2.6 / 1.6 / 0.9 ms against 1.1 ms), and 8 task vectors
+    # are 4 GB of a 288 GB part.  "sliced" stays the library default (merge_test.py merges ONCE: 1 / N of the upload and of the memory) and is
+    # north_star's wording; --merge-placement sliced measures it.
+    placement = args.merge_placement or ("replicated" if world > 1 else None)
     merged_model = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, pre, fts, set(), disable_softmax=True,
-                                       placement=args.merge_placement)
+                                       placement=placement)
     sliced = merged_model.slice_plan is not None
     del fts
     torch.cuda.empty_cache()
@@ -250,6 +262,8 @@ def _main(real_stdout):
                                          "per_weights": {"all": [1.0 / n_dom] * n_dom}})  # "average" (merge_test.py:47-55)
     module = RecModule(model=model, evaluator=Evaluator(["NDCG", "RECALL"], [1, 5, 10, 50]), similarity="cosine")
     module.eval()
+    if args.pipelined_merge if args.pipelined_merge is not None else sliced:
+        merged_model.pipeline_merges(True)
 
     n_total = args.steps + args.warmup
     g = torch.Generator().manual_seed(1234 + rank)
@@ -357,14 +371,18 @@ def _main(real_stdout):
         sampler.start()
     ops.PROF.enabled = not args.no_profile
     ops.PROF.records.clear()
+    parallel.COLL.enabled = world > 1
+    parallel.COLL.records.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     metrics = epoch(args.warmup, n_total, items_timed)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0   # this rank's own time to the end of its work (before the closing barrier)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.PROF.enabled = False
+    parallel.COLL.enabled = False
     if sampler is not None:
         sampler.stop_flag.set()
         sampler.join(timeout=1.0)
@@ -372,6 +390,13 @@ def _main(real_stdout):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        # per-rank view: every rank's own time to finish its work, and the time it spent inside the data-path collectives
+        coll = parallel.COLL.summary()
+        mine = torch.tensor([own_elapsed, coll["ms"] / 1e3, float(coll["bytes_received_per_rank"])], dtype=torch.float64,
+                            device=dev if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = torch.stack(every).cpu()
     value = U_step * world * args.steps / elapsed
 
     # ---------------- per-kernel rooflines from HIP events over the timed region ----------------
@@ -482,6 +507,12 @@ def _main(real_stdout):
             # multi-GPU record: ranks of the RCCL communicator (backend "nccl" IS RCCL on ROCm; 0 = no communicator, e.g. N = 1 or a gloo rehearsal)
             dist_backend=backend, rccl_ranks=(dist.get_world_size() if backend == "nccl" else 0),
             merge_placement=("sliced" if sliced else "replicated") if world > 1 else "single",
+            # per-rank view (N > 1): each rank's own time to the end of its work, and what it spent inside the data-path collectives
+            per_rank=(None if world == 1 else dict(
+                ms_per_step_min=float(per_rank[:, 0].min()) / args.steps * 1e3, ms_per_step_max=float(per_rank[:, 0].max()) / args.steps * 1e3,
+                collective_ms_per_step_max=float(per_rank[:, 1].max()) / args.steps * 1e3,
+                collective_bytes_received_per_rank_and_step=float(per_rank[:, 2].max()) / args.steps,
+                note="collective time = event-bracketed all-gathers on each rank's stream (includes waiting for the slowest rank)")),
             roofline=roofline, cpu_baseline=cpu_baseline, kernels=kernels, parity=parity,
             epoch_metrics_sample={k: round(v, 6) for k, v in list(metrics.items())[:3]},
         )

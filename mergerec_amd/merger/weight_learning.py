@@ -116,6 +116,9 @@ class TaskVectorMergingModuleBase(nn.Module):
                     v = v[: table[k].numel()]  # _base.py:72
                 assert v.shape == table[k].shape, f"Shape mismatch for key '{k}', ({v.shape} != {table[k].shape})"
                 table[k].data = v.to(dev)
+        if getattr(self, "_pipe", None) is not None and self._pipe["pending"] is not None:
+            pend = self._pipe["pending"]  # a prefetched merge speculated on the old coefficients: its arena is the spare again
+            self._pipe["spare"], self._pipe["spare_ws"], self._pipe["pending"] = pend["arena"], pend["ws"], None
 
     def forward(self, batch):
         """_base.py:78-81.  Under autograd (alpha requires grad and grad mode is on) the merge AND the encoder are differentiable:
@@ -198,11 +201,82 @@ class TaskVectorMergingModuleBase(nn.Module):
         return _MergeFunction.apply(self.effective_alpha(), self.base_model_tensor.data, self.task_vectors_tensor.data,
                                     self._seg_off, torch.empty_like(self._merged))
 
+    # -- pipelined re-merge (evaluation loops that re-merge per step, as the reference does on every forward) ---------------------------
+    def pipeline_merges(self, on: bool = True):
+        """Double-buffer the merged arena: while the encoder of step s reads arena A, the merge (+ weight split) of step s + 1 runs on a
+        SECOND HIP stream into arena B, speculating that alpha stays what it is now; the next ``load_weights(force=True)`` checks that
+        alpha is bit-identical to the one the prefetched arena was merged with (else it merges again, synchronously), waits for the
+        side stream's event and swaps the arenas -- no kernel of its own on the critical path.  Every step still gets its own merge,
+        executed inside the step before; nothing is cached across steps.  +1 arena (+ its bf16 / fp16 pieces) of HBM."""
+        if not on:
+            self._pipe = None
+            return self
+        if not hasattr(self.model, "bind_arena"):
+            raise RuntimeError("pipelined merges need a HIP encoder model (bind_arena)")
+        other = torch.zeros_like(self._arena)
+        self._pipe = dict(stream=torch.cuda.Stream(device=self._arena.device), spare=other, spare_ws=None, pending=None)
+        return self
+
+    def _alpha_key(self):
+        """(storage address, in-place version) of every coefficient tensor: changes whenever an optimizer step, ``load_weights_from_dict``
+        or an assignment touches alpha (``load_weights_from_dict`` also drops a pending prefetch outright)."""
+        return tuple((p.data_ptr(), p._version) for table in (self.global_weights, self.global_biases, self.per_weights) for p in table.values())
+
+    def _swap_arena(self, arena: torch.Tensor, weightset):
+        """make ``arena`` the one the model reads (pointer swaps only); returns the previous (arena, WeightSet)"""
+        old = (self._arena, self.model._weights)
+        self._arena = arena
+        self._merged = arena[: self.layout.padded_numel]
+        self.model._flat = self._merged
+        self.model._weights = weightset
+        self.model._views = weightset.views
+        return old
+
+    def _pipelined_load(self, alpha: torch.Tensor):
+        from ..engine import WeightSet
+
+        pipe, main = self._pipe, torch.cuda.current_stream(self._arena.device)
+        pend = pipe["pending"]
+        key = self._alpha_key()   # host-side identity of the coefficient tensors (no device read on the step's path)
+        hit = pend is not None and pend["key"] == key
+        if hit:
+            main.wait_event(pend["done"])                     # the prefetched merge + split of THIS step
+            pipe["spare"], pipe["spare_ws"] = self._swap_arena(pend["arena"], pend["ws"])
+        else:                                                  # first call, or alpha moved: merge now, into the live arena
+            if pend is not None:                               # the speculative arena goes back to being the spare (its merge is ordered
+                pipe["spare"], pipe["spare_ws"] = pend["arena"], pend["ws"]  # before the next one on the same side stream)
+                pipe["pending"] = None
+            self._merge_task_vectors()
+            self.model.weights_updated()
+        # the next step's merge, under this step's encoder kernels: the spare arena was the live one until the swap above, so the side
+        # stream first waits for everything enqueued on the main stream so far (the previous step's readers)
+        spare = pipe["spare"]
+        ws = pipe["spare_ws"]
+        if ws is None or ws.flat.data_ptr() != spare.data_ptr():
+            ws = WeightSet(self.layout, spare[: self.layout.padded_numel], self.model._weights.mode)
+        fence = torch.cuda.Event()
+        fence.record(main)
+        side = pipe["stream"]
+        with torch.cuda.stream(side):
+            side.wait_event(fence)
+            self._merge_task_vectors(out=spare if self.slice_plan is not None else spare[: self.layout.padded_numel])
+            ws.refresh()
+            done = torch.cuda.Event()
+            done.record(side)
+        pipe["pending"] = dict(key=key, arena=spare, ws=ws, done=done)
+        pipe["spare"], pipe["spare_ws"] = None, None
+
     def load_weights(self, force: bool = False):
         """Re-merge into the model's arena (``force``: unconditionally, as the reference does on every forward) -- skipped when alpha is bit-identical to the one the arena was merged with AND nothing
         else has written the arena since (the model counts in-place writes: load_state_dict, optimizer steps).  The reference
         re-merges on every forward; a catalog encode is hundreds of forwards with the same alpha."""
         alpha = self.effective_alpha().detach()
+        if force and getattr(self, "_pipe", None) is not None:
+            self._pipelined_load(alpha)
+            self._merged_alpha = alpha.clone()
+            self.model.arena_changed()
+            self._merged_version = getattr(self.model, "_arena_version", 0)
+            return self.model
         cached = getattr(self, "_merged_alpha", None)
         version = getattr(self.model, "_arena_version", 0)
         if not force and cached is not None and cached.shape == alpha.shape and getattr(self, "_merged_version", None) == version \

@@ -19,6 +19,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence, Tuple
 
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -109,15 +111,51 @@ def balanced_share(pool_lengths: torch.Tensor, world_size: int, rank: int) -> to
     return rounds[:, rank]
 
 
+class CollectiveLog:
+    """Time and bytes of the data-path collectives (bench.py reports them beside the step time).  Device collectives ("nccl" = RCCL) are
+    bracketed by two events on the stream they are enqueued on -- no synchronisation, the durations are read after the run; host-staged
+    ones (gloo rehearsals) by the host clock.  Off unless ``enabled``."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []   # (name, bytes received per rank, (start event, end event) | host seconds)
+
+    def summary(self):
+        ms, nbytes, n = 0.0, 0, 0
+        for _, b, t in self.records:
+            ms += (t[0].elapsed_time(t[1]) if isinstance(t, tuple) else t * 1e3)
+            nbytes += b
+            n += 1
+        return dict(calls=n, ms=ms, bytes_received_per_rank=nbytes)
+
+
+COLL = CollectiveLog()
+
+
 def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None):
     """all_gather_into_tensor; with the gloo backend (CPU rehearsals, or several ranks sharing one GPU in tests)
     device tensors are staged through host memory.  The production backend is "nccl" (= RCCL over xGMI)."""
+    rec = COLL.enabled
+    nbytes = out.numel() * out.element_size() - inp.numel() * inp.element_size()
     if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        if rec:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
         dist.all_gather_into_tensor(o, i, group=group)
         out.copy_(o)
+        if rec:
+            torch.cuda.synchronize()
+            COLL.records.append(("all_gather(host-staged)", nbytes, time.perf_counter() - t0))
     else:
+        ev = None
+        if rec and inp.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         dist.all_gather_into_tensor(out, inp, group=group)
+        if ev is not None:
+            ev[1].record()
+            COLL.records.append(("all_gather", nbytes, ev))
 
 
 def sharded_merge(merge_slice: Callable[[int, int, torch.Tensor], None], arena: torch.Tensor, plan: SlicePlan,

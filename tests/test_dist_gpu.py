@@ -153,12 +153,18 @@ def test_bench_gpus_2_starts_its_own_ranks():
     env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0", MERGEREC_DIST_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
-    assert out["dist_backend"] == "gloo" and out["rccl_ranks"] == 0 and out["merge_placement"] == "sliced"
-    assert out["value"] > 0 and out["config"]["parallelism"].startswith("dp2")
+    for extra, placement in (([], "replicated"), (["--merge-placement", "sliced"], "sliced")):  # bench default at N > 1 / north_star's split
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+        assert out["dist_backend"] == "gloo" and out["rccl_ranks"] == 0 and out["merge_placement"] == placement
+        assert out["value"] > 0 and out["config"]["parallelism"].startswith("dp2")
+        pr = out["per_rank"]  # each rank's own step time and its time inside the data-path collectives, separately
+        assert 0 < pr["ms_per_step_min"] <= pr["ms_per_step_max"] <= out["ms_per_step"] * 1.05
+        assert pr["collective_ms_per_step_max"] > 0 and pr["collective_bytes_received_per_rank_and_step"] > 0
+        if placement == "sliced":  # the arena all-gather dominates the bytes: half of 499 MB per merge, two merges per epoch + one per step here
+            assert pr["collective_bytes_received_per_rank_and_step"] > 200e6

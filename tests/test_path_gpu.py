@@ -405,6 +405,43 @@ def test_lazy_eval_scores_are_the_epochs_bits_even_if_the_catalog_is_rewritten_a
     assert mod._eval_scores_lazy is None and mod.eval_scores is scores  # cached, snapshot released
 
 
+def test_pipelined_merges_are_bit_identical_and_follow_alpha():
+    """``pipeline_merges``: the merge of step s + 1 runs on a second stream into a second arena while step s encodes.  Same bits as the
+    in-stream merge on every step; a coefficient change between steps (in place, by assignment, through load_weights_from_dict) is never
+    served from the speculative arena."""
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.module import ModelType
+    from mergerec_amd.synthetic import make_domain
+
+    over = dict(hidden=128, heads=2, layers=2, intermediate=256, vocab=300, max_pos=200)
+    dom = make_domain("Toy", n_items=64, n_users=8, batch_size=32, vocab=300, seed=5, max_seq_len=120, item_len_scale=0.3)
+    batches = [b.items for b in dom.item_batches]
+
+    def run(pipelined):
+        model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 21, "spec_overrides": over, "device": DEV})
+        pre = OrderedDict((k, v.cpu().clone()) for k, v in model.state_dict().items())
+        fts = [O.perturbed_state_dict(pre, seed=90 + i, std=0.05) for i in range(3)]
+        mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, model, pre, fts, set(), disable_softmax=True)
+        if pipelined:
+            mm.pipeline_merges(True)
+        outs = []
+        for step in range(8):
+            if step == 3:    # in-place update, as an optimizer step does it
+                with torch.no_grad():
+                    mm.per_weights["all"].mul_(0.5)
+            if step == 5:    # the alpha file path
+                mm.load_weights_from_dict({"global_weights": {"all": [0.9]}, "global_biases": {"all": [0.01]}, "per_weights": {"all": [0.3, 0.1, 0.2]}})
+            mm.load_weights(force=True)
+            outs.append(model.encode_normalized(batches[step % len(batches)], True).clone())
+            outs.append(torch.cat([v.reshape(-1) for v in model.state_dict().values()]).clone())
+        torch.cuda.synchronize()
+        return outs
+
+    a, b = run(False), run(True)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), i
+
+
 def test_extract_and_finetune_test_single_model(tmp_path):
     """Lightning-style checkpoint -> scripts/extract.py -> finetune_test.py (single-model path): state_dict.pt keys are
     ``model.model.*`` + ``item_embeddings``; the CLI must load it (prefix stripped, item_embeddings dropped) and evaluate"""
