@@ -359,6 +359,8 @@ __global__ __launch_bounds__(kThreads, (NT == 4 ? 2 : 3)) void gemm_nt_bf16x6_ke
     MR_SLOT_V MR_SLOT_V MR_SLOT_V MR_SLOT_V MR_SLOT_V MR_SLOT_V MR_SLOT_V MR_SLOT_V                                      \
     MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD MR_SLOT_VD                              \
     MR_SLOT_VM MR_SLOT_VM MR_SLOT_VM MR_SLOT_VM MR_SLOT_VM MR_SLOT_VM MR_SLOT_V MR_SLOT_V
+        // (the fp16 split carries two more VALU instructions per float4 than the bf16 one; pipes with three VALU per slot measured the same:
+        // tools/ab_gemm_flag.sh, r04)
         constexpr bool ILV = (NP == 2 && NT == 4);
         for (int kt = 0; kt < nk; kt += 2) {
             compute(buf0);

@@ -16,7 +16,7 @@ for r in 1 2; do
   i=0
   for defs in "$@"; do
     echo "== [$defs]"
-    MERGEREC_HIP_LIB=/tmp/lib_$i/libmergerec_hip.so GB_MODE=bf16x3 GB_ROUNDS=8 python tools/gemm_bench.py 2>&1 | grep bf16x3
+    MERGEREC_HIP_LIB=/tmp/lib_$i/libmergerec_hip.so GB_MODE=${GB_MODE:-bf16x3} GB_ROUNDS=8 python tools/gemm_bench.py 2>&1 | grep x3
     i=$((i + 1))
   done
 done

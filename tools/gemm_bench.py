@@ -1,5 +1,5 @@
 """Micro-benchmark of the encoder GEMMs at BLaIR-base shapes (HIP events, interleaved rounds).
-GB_MODE = f32 | bf16x6 (default both)."""
+GB_MODE = f32 | bf16x6 | bf16x3 | f16x3 (comma-separated; default f32,bf16x6)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,12 +18,15 @@ for name, n, k, nseg in shapes:
     Ws = [W[i * n * k:(i + 1) * n * k].view(n, k) for i in range(nseg)]
     bs = [torch.randn(n, device=dev, generator=g) for _ in range(nseg)]
     out = torch.empty(M, n * nseg, device=dev)
-    bufs[name] = (A, W, Ws, bs, out, ops.split_weights_kblock(W, ops.KBlockTable([(i * n * k, n, k) for i in range(nseg)], dev)))
+    tab = ops.KBlockTable([(i * n * k, n, k) for i in range(nseg)], dev)
+    bufs[name] = (A, W, Ws, bs, out, ops.split_weights_kblock(W, tab), ops.split_weights_kblock(W, tab, f16=True))
 
 def run(mode, name, n, k, nseg):
-    A, W, Ws, bs, out, pieces = bufs[name]
+    A, W, Ws, bs, out, pieces, pieces_h = bufs[name]
     if mode == "f32":
         ops.gemm_nt(A, Ws, bs, out=out)
+    elif mode == "f16x3":
+        ops.gemm_nt_split(A, pieces_h, [i * n * k for i in range(nseg)], n, k, bs, out=out, products=ops.PRODUCTS_F16X3)
     else:
         ops.gemm_nt_split(A, pieces, [i * n * k for i in range(nseg)], n, k, bs, out=out, products=6 if mode == "bf16x6" else 3)
 
