@@ -440,7 +440,10 @@ def _main(real_stdout):
             points it at the passes it has just made -- the tracked profiles/ directory is never written by a run), else from the committed
             profiles/ (this round's file if it exists, else the newest earlier round's); the path read is what ``*_source`` records"""
             override = os.environ.get("MERGEREC_COUNTER_DIR")
-            for base, shown in ((override, override), (os.path.join(ROOT, "profiles"), "profiles")) if override else ((os.path.join(ROOT, "profiles"), "profiles"),):
+            if override and os.path.abspath(override).startswith(ROOT + os.sep):
+                override = os.path.relpath(os.path.abspath(override), ROOT)   # recorded as a path inside the repository
+            for base, shown in ((os.path.join(ROOT, override) if override and not os.path.isabs(override) else override, override),
+                                (os.path.join(ROOT, "profiles"), "profiles")) if override else ((os.path.join(ROOT, "profiles"), "profiles"),):
                 for rnd in PROFILE_ROUNDS:
                     path = os.path.join(base, f"{rnd}_{kind}_{gemm_mode}.json")
                     if os.path.exists(path):

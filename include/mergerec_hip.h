@@ -39,6 +39,7 @@ extern "C" {
 
 #define MR_ACT_NONE 0
 #define MR_ACT_GELU_ERF 1
+#define MR_ACT_TANH 2 /* mr_gemm_nt_bias_act_f32 only: the RoBERTa pooler head tanh(W h_cls + b) (encoder/_base.py:46-47, pooling_method='pooler') */
 /* `products` of the split-precision entry points: 3 = two bf16 pieces per operand (hi*hi + hi*lo + lo*hi, ~2^-16 per product), 6 = three
  * bf16 pieces (six products, ~2^-24), MR_PRODUCTS_F16X3 = two FP16 pieces per operand and the same three products (~2^-21 per product at
  * the cost of bf16x3; operands must stay inside fp16's range: |x| < 65504, weights |w| < 255.9 -- see mr_split_weights_kblock_f16_f32). */

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemm_nt_kernel(
                 for (int r = 0; r < 4; ++r) {
                     v[r] = acc[i][j][4 * q + r] + bz[j];
                     if (ACT == MR_ACT_GELU_ERF) v[r] = gelu_erf(v[r]);
+                    if (ACT == MR_ACT_TANH) v[r] = tanhf(v[r]);
                     if (HAS_R) v[r] += rr[r];
                 }
 #pragma unroll
@@ -257,7 +258,8 @@ extern "C" int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float*
     if ((nseg > 1 && !w1) || (nseg > 2 && !w2)) return MR_EINVAL;
     if (K % BK) return MR_EUNSUPPORTED;
     if (nseg > 1 && (seg_n % BN)) return MR_EUNSUPPORTED;
-    if (act != MR_ACT_NONE && act != MR_ACT_GELU_ERF) return MR_EUNSUPPORTED;
+    if (act != MR_ACT_NONE && act != MR_ACT_GELU_ERF && act != MR_ACT_TANH) return MR_EUNSUPPORTED;
+    if (act == MR_ACT_TANH && R) return MR_EUNSUPPORTED;  // the pooler head has no residual
     if (lda & 3) return MR_EALIGN;  // A and W rows are read as float4; C and R are accessed per element
     if (!mr::aligned16(A) || !mr::aligned16(w0) || (w1 && !mr::aligned16(w1)) || (w2 && !mr::aligned16(w2)))
         return MR_EALIGN;
@@ -287,7 +289,9 @@ extern "C" int mr_gemm_nt_bias_act_f32(const float* A, int64_t lda, const float*
 #define MR_GEMM_LAUNCH(ACT_, HASR_)                                                                                   \
     hipLaunchKernelGGL((gemm_nt_kernel<ACT_, HASR_>), dim3(nwg), dim3(kThreads), 0, st, A, lda, w0, w1, w2, b0, b1, b2, \
                        M, seg_n, K, R, ldr, C, ldc, tiles_n_seg, tiles_n, nwg, K, (int64_t)0)
-    if (act == MR_ACT_GELU_ERF) {
+    if (act == MR_ACT_TANH) {
+        MR_GEMM_LAUNCH(MR_ACT_TANH, false);
+    } else if (act == MR_ACT_GELU_ERF) {
         if (R) MR_GEMM_LAUNCH(MR_ACT_GELU_ERF, true); else MR_GEMM_LAUNCH(MR_ACT_GELU_ERF, false);
     } else {
         if (R) MR_GEMM_LAUNCH(MR_ACT_NONE, true); else MR_GEMM_LAUNCH(MR_ACT_NONE, false);

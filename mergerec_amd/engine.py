@@ -471,11 +471,20 @@ class EncoderRunner:
             x = self.layer(w, l, x, pb, cls_only=last and not return_hidden)
             if return_hidden:
                 hidden.append(x)
+        pooler = getattr(self, "pooling_method", "cls") == "pooler"
         if return_hidden or L == 0:
-            out = ops.cls_pool_normalize(x, pb.cu_seqlens, pb.B, normalize)
-            return (out, hidden) if return_hidden else out
-        # x already holds one row per sequence
-        return ops.cls_pool_normalize(x, None, pb.B, normalize)
+            out = ops.cls_pool_normalize(x, pb.cu_seqlens, pb.B, normalize and not pooler)
+        else:  # x already holds one row per sequence
+            out = ops.cls_pool_normalize(x, None, pb.B, normalize and not pooler)
+        if pooler:
+            # encoder/_base.py:46-47: ``outputs.pooler_output`` = RobertaPooler: tanh(dense(h[:, 0])), exact fp32 (a (B, d) product)
+            p = self.prefix + "pooler.dense."
+            if p + "weight" not in w:
+                raise RuntimeError("pooling_method='pooler' needs a model with a pooler head (Recformer has none: upstream returns None there)")
+            out = ops.gemm_nt(out, [w[p + "weight"]], [w[p + "bias"]], act=ops.ACT_TANH)
+            if normalize:
+                out = ops.cls_pool_normalize(out, None, pb.B, True)
+        return (out, hidden) if return_hidden else out
 
     def encode(self, w: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], device, normalize: bool, lens=None, validate: bool = True):
         return self.forward_packed(w, self.pack(batch, device, lens=lens, validate=validate), normalize)

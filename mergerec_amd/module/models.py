@@ -42,8 +42,13 @@ class BaseEncoderModel(nn.Module):
         model_kwargs = dict(model_kwargs or {})
         if lora_config is not None:
             raise ValueError("LoRA wrappers are outside the merged-inference hot path (SURVEY section 2, row 4)")
-        if pooling_method != "cls":
-            raise NotImplementedError("only pooling_method='cls' is on the hot path (encoder/_base.py:44-45)")
+        if pooling_method == "mean":
+            # upstream: last_hidden_state.mean(dim=1) over the PADDED batch length -- the hidden states of pad positions included, so an
+            # embedding depends on what else is in its batch; no shipped script selects it (configs/base.py:26 default "cls")
+            raise NotImplementedError("pooling_method='mean' (mean over the padded batch length, pad positions included) is not built; "
+                                      "'cls' (default) and 'pooler' are")
+        if pooling_method not in ("cls", "pooler"):
+            raise ValueError(f"Invalid pooling method: {pooling_method}.")  # encoder/_base.py:48-49
         if model_name_or_path is None and tokenizer_name_or_path is None:
             model_name_or_path = tokenizer_name_or_path = self.DEFAULT_MODEL_PATH
         self.model_name_or_path = model_name_or_path
@@ -74,6 +79,7 @@ class BaseEncoderModel(nn.Module):
         self.spec = spec
         self.device = _resolve_device(model_kwargs)
         self.runner = EncoderRunner(spec, prefix="model.")
+        self.runner.pooling_method = pooling_method
         self.layout = ArenaLayout(spec.param_shapes("model."))
         self.gemm_mode = model_kwargs.pop("gemm_mode", None)  # None -> MERGEREC_GEMM_MODE or "bf16x6"
         self._flat = torch.zeros(self.layout.padded_numel, dtype=torch.float32, device=self.device)

@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from ._lib import MergeRecHipError, check, ptr
 
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_TANH = 0, 1, 2
 EMBED_ROBERTA, EMBED_RECFORMER = 0, 1
 
 

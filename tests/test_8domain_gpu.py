@@ -1,10 +1,11 @@
 """north_star: "NDCG@10 within 1e-3 of reference across all 8 Amazon domains" -- BASELINE configs[3]'s model (ONE 8-domain task-vector merge
-of BLaIR-base at true dimensions) evaluated on every domain's full catalog (4,968 ... 27,932 items, 114,075 in all), 1,024 users per domain.
+of BLaIR-base at true dimensions) evaluated on every domain's full catalog (4,968 ... 27,932 items, 114,075 in all), 4,096 users per domain.
 
 Fixture: tests/golden/g13_8domain_blair_base.pt, produced in the build container by oracle/gen_golden_8domain.py from the reference itself
 (its load_merging_module / get_state_dict, transformers' RobertaModel, user @ item.T, its Evaluator; CPU, fp32).  Inputs are regenerated from
 seeds here.  Checked per domain, in the arithmetic the reference's default precision flag selects (bf16-mixed -> f16x3) through the drop-in evaluation loop: user embeddings, sampled
-item rows and their logits within 1e-4; the ranked top-50 equal to the reference's up to its own near-ties (2e-6); label ranks equal up to
+item rows and their logits within 3e-6 (north_star: 1e-4); the ranked top-50 equal to the reference's wherever its scores are more than twice the measured
+logit error apart; label ranks equal up to
 near-ties; every Recall / NDCG value within 1e-3; the loss within 1e-3."""
 
 import os
@@ -18,9 +19,11 @@ from tests.conftest import load_golden, prefetched, register_prefetch, seeded_st
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 LOGIT_TOL = 1e-4       # north_star
-NEAR_TIE = 2.5e-6      # two items whose REFERENCE scores are this close may swap places: each logit is within 1.9e-6 of the reference's
-                       # (measured below), so gaps up to 3.8e-6 could legitimately flip; 2e-6 covered every case at 1,024 users per domain,
-                       # the 4,096-user domains (r03) contain one label move across a 2.09e-6 gap (Sports)
+LOGIT_BOUND = 3e-6     # what fp32 summation order costs on these init-like weights (r02-r04 measured 1.6-2.3e-6 in every arithmetic): asserted on
+                       # every logit the fixture lets us compare -- a sampled block, every user's reference top-52, every label
+# Near-tie budget: DERIVED per domain from the logit error measured in that run (r04; ADVICE r03 -- through r03 it was a constant moved from
+# 2e-6 to 2.5e-6 after an observed crossing): if every logit is within eps of the reference's, two items can swap places only when their
+# REFERENCE scores are within 2 eps of each other.  Every differing rank position / label move is verified to be such a pair.
 NDCG_TOL = 1e-3        # north_star
 
 
@@ -71,7 +74,8 @@ def test_all_eight_domains_match_the_reference(merged, tmp_path):
     for name, d in fx["domains"].items():
         if only and name not in only.split(","):
             continue
-        n_users = d.get("n_users", fx["n_users"])  # r03: 4,096 on the domains where one near-tie move used up the whole bound at 1,024
+        n_users = d.get("n_users", fx["n_users"])
+        assert n_users == fx["n_users"] == 4096, "r04: one user count for all eight domains (ADVICE r03)"
         ar = torch.arange(n_users)
         dom = make_domain(name, d["n_items"], n_users, 32, cfg.vocab, d["seed"])
         seqs, at = [], 0
@@ -88,11 +92,13 @@ def test_all_eight_domains_match_the_reference(merged, tmp_path):
         rows, nu = d["E_rows"].long(), d["U"].shape[0]   # the fixture keeps the first users' embeddings and sampled catalog rows
         assert float((U[:nu] - d["U"]).abs().max()) < LOGIT_TOL and float((E[rows] - d["E_sample"]).abs().max()) < LOGIT_TOL
         assert abs(float(E.double().sum()) - d["E_checksum"]) < 1e-4 * d["n_items"]
-        logit_err = float((got[:nu][:, rows] - d["U"] @ d["E_sample"].T).abs().max())
-        assert logit_err < LOGIT_TOL, (name, logit_err)
+        ref_idx, ref_val = d["ref_top52_idx"].long(), d["ref_top52_val"]
+        logit_err = max(float((got[:nu][:, rows] - d["U"] @ d["E_sample"].T).abs().max()), float((got.gather(1, ref_idx) - ref_val).abs().max()),
+                        float((got[ar, labels[0]] - d["label_score"]).abs().max()))
+        assert logit_err < LOGIT_BOUND < LOGIT_TOL, (name, logit_err)
+        NEAR_TIE = 2 * logit_err
         # (2) ranked indices: the reference's top-50, except where the reference's own scores are within NEAR_TIE of each other
         idx = module.eval_topk_indices.cpu()
-        ref_idx, ref_val = d["ref_top52_idx"].long(), d["ref_top52_val"]
         diff = idx != ref_idx[:, :50]
         for u, p in torch.nonzero(diff).tolist():
             hit = torch.nonzero(ref_idx[u] == idx[u, p]).flatten()
@@ -100,12 +106,13 @@ def test_all_eight_domains_match_the_reference(merged, tmp_path):
             assert abs(float(ref_val[u, int(hit)] - ref_val[u, p])) <= NEAR_TIE, (name, u, p)
         gap = ref_val[:, :50] - ref_val[:, 1:51]
         above = torch.cat([torch.full_like(gap[:, :1], float("inf")), gap[:, :-1]], dim=1)
-        clear = (gap > 2 * NEAR_TIE) & (above > 2 * NEAR_TIE)
+        clear = (gap > NEAR_TIE) & (above > NEAR_TIE)   # separated from both neighbours by more than twice the logit error
         assert bool((idx[clear] == ref_idx[:, :50][clear]).all()), (name, "a clearly separated rank position holds a different item")
         # (3) label ranks: a label may move only across items the reference scores within NEAR_TIE of it
         my_rank = (got > got[ar, labels[0]][:, None]).sum(1)
         ref_rank = d["label_rank"].long()
-        half = (d["label_window"].shape[1] - 1) // 2  # reference scores kept either side of the label's rank: 3 (r02 entries) or 8
+        half = (d["label_window"].shape[1] - 1) // 2  # reference scores kept either side of the label's rank
+        assert half == 8, "every domain entry written by the committed generator revision (17-column label windows)"
         for u in torch.nonzero(my_rank != ref_rank).flatten().tolist():
             shift = int(my_rank[u] - ref_rank[u])
             assert abs(shift) <= half, (name, u, shift)

@@ -383,6 +383,37 @@ def test_precision_flag_selects_arithmetic():
     assert abs(m32[0]["test/loss"] - m16[0]["test/loss"]) < 1e-3 and m32[0].keys() == m16[0].keys()
 
 
+def test_pooling_methods():
+    """encoder/_base.py:41-49: 'cls' (default) = last_hidden_state[:, 0]; 'pooler' = RobertaPooler's tanh(dense(h_cls)) on the library's own
+    CLS rows of fixture g3; 'mean' is refused with the reason; junk raises upstream's ValueError."""
+    from mergerec_amd.module import ModelType
+    from tests.conftest import load_golden
+
+    g3 = load_golden("g3_roberta.pt")
+    c = g3["cfg"]
+    over = dict(hidden=c["hidden"], heads=c["heads"], layers=c["layers"], intermediate=c["intermediate"], vocab=c["vocab"], max_pos=c["max_pos"])
+    batch = {"input_ids": g3["input_ids"].to(DEV), "attention_mask": g3["attention_mask"].to(DEV)}
+    sd = g3["state_dict"]
+    for method in ("cls", "pooler"):
+        model = ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "spec_overrides": over, "device": DEV, "gemm_mode": "f32"}, pooling_method=method)
+        model.load_state_dict(sd)
+        out = model(batch).cpu()
+        want = g3["cls"] if method == "cls" else torch.tanh(torch.nn.functional.linear(g3["cls"], sd["model.pooler.dense.weight"], sd["model.pooler.dense.bias"]))
+        assert float((out - want).abs().max()) < 1e-4, method
+        norm = model.encode_normalized(batch, True).cpu()
+        assert torch.allclose(norm, torch.nn.functional.normalize(want, dim=-1), atol=1e-5)
+    with pytest.raises(NotImplementedError, match="padded batch length"):
+        ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "spec_overrides": over, "device": DEV}, pooling_method="mean")
+    with pytest.raises(ValueError, match="Invalid pooling method"):
+        ModelType.BLAIR_BASE.value(model_kwargs={"init_seed": 0, "spec_overrides": over, "device": DEV}, pooling_method="max")
+    with pytest.raises(RuntimeError, match="pooler head"):
+        rec = ModelType.RECFORMER_BASE.value(model_kwargs={"init_seed": 0, "device": DEV, "spec_overrides": dict(hidden=128, heads=2, layers=1, intermediate=128, vocab=300, max_pos=200)},
+                                             pooling_method="pooler")
+        ids = torch.tensor([[0, 5, 6, 2]], device=DEV)
+        rec({"input_ids": ids, "attention_mask": torch.ones_like(ids), "global_attention_mask": torch.tensor([[1, 0, 0, 0]], device=DEV),
+             "token_type_ids": torch.tensor([[0, 1, 2, 2]], device=DEV), "item_position_ids": torch.tensor([[0, 1, 1, 1]], device=DEV)})
+
+
 def test_lazy_eval_scores_are_the_epochs_bits_even_if_the_catalog_is_rewritten_afterwards():
     """module.py:344-352: ``eval_scores`` is what the epoch computed.  Here it is produced on first access -- from a snapshot of the table
     the kernel ranked, not from the live ``item_embeddings``, which a catalog refresh or the next domain's encode may rewrite in place."""

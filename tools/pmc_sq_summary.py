@@ -82,7 +82,7 @@ def main():
             ent["sq_busy_over_gui"] = ent["SQ_BUSY_CYCLES"] / gui
         res[fam] = ent
         if fam.endswith("bf16x"):
-            res[fam + "3"] = res[fam + "6"] = ent
+            res[fam + "3"] = res[fam + "6"] = res[fam.replace("bf16x", "f16x3")] = ent
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if not k.endswith(("x3", "x6"))}, indent=1))
 

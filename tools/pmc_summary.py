@@ -58,7 +58,7 @@ def main():
             ent["l2_hit_rate"] = sum(h) / max(sum(h) + sum(m), 1.0)
         res[fam] = ent
         if fam.endswith("bf16x"):  # bench.py names the family by its product count
-            res[fam + "3"] = res[fam + "6"] = ent
+            res[fam + "3"] = res[fam + "6"] = res[fam.replace("bf16x", "f16x3")] = ent  # (f16x3 runs the same kernel templates)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if not k.endswith(("x3", "x6"))}, indent=1))
 

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Regenerates profiles/<round>_* on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh [modes...]'      (default mode list: bf16x3)
+#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh [modes...]'      (default mode list: f16x3)
 # Everything large stays in /tmp; only the reduced summaries are written under gpurun_out/profiles/ (copy them to profiles/).
-# Order per mode: kernel trace + stats, traffic / clock counter passes, SQ passes (bf16x3; SQ=0 skips), then the plain bench, whose
+# Order per mode: kernel trace + stats, traffic / clock counter passes, SQ passes (f16x3; SQ=0 skips), then the plain bench, whose
 # line quotes the counter files just produced (MERGEREC_COUNTER_DIR).  Any failing step ends the script (set -e).
 set -eo pipefail
 RND=r04
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
-MODES=${@:-bf16x3}
+MODES=${@:-f16x3}
 cd /tmp && export TMPDIR=/tmp
 for m in $MODES; do
   rm -rf /tmp/prof_$m
@@ -32,10 +32,10 @@ for m in $MODES; do
   rm -rf /tmp/prof_$m /tmp/pmcf_$m /tmp/pmcw_$m /tmp/pmcl_$m /tmp/pmcc_$m
   # SQ passes (matrix-pipe busy) for the headline mode, then the plain bench LAST: its line reads the counter files of THIS source
   # tree from profiles/ (roofline.traffic, roofline.mfma_busy; a hash of csrc/ flags them stale otherwise)
-  if [ $m = bf16x3 ] && [ "${SQ:-1}" = 1 ]; then bash $R/tools/sq_pass.sh $m > /tmp/sq_$m.log 2>&1 || { tail -8 /tmp/sq_$m.log; exit 1; }; echo "sq $m done"; fi
+  if [ $m = f16x3 ] && [ "${SQ:-1}" = 1 ]; then bash $R/tools/sq_pass.sh $m > /tmp/sq_$m.log 2>&1 || { tail -8 /tmp/sq_$m.log; exit 1; }; echo "sq $m done"; fi
   # the bench reads the counter reductions of THIS call from $OUT (recorded in its line as traffic_source); the tracked profiles/ directory
   # is only ever written by a reviewed copy + commit afterwards
-  extra="--no-cpu-baseline"; [ $m = bf16x3 ] && extra=""
+  extra="--no-cpu-baseline"; [ $m = f16x3 ] && extra=""
   MERGEREC_COUNTER_DIR=$OUT timeout -k 10 400 python3 $R/bench.py --steps 10 --warmup 2 --gemm-mode $m $extra > $OUT/${RND}_bench_$m.json 2> /tmp/bench_$m.err || { tail -5 /tmp/bench_$m.err; exit 1; }
   echo "bench $m done"
 done

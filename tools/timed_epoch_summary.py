@@ -21,7 +21,12 @@ def main():
                 per[fam].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
                 break
     bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
-    events = {k.rstrip("36") if k.endswith(("bf16x3", "bf16x6")) else k: v for k, v in bench.get("kernels", {}).items()}
+    def fam_of(k):  # bench.py names the split-precision families by arithmetic; the kernel templates are shared
+        if k.endswith(("bf16x3", "bf16x6")):
+            return k[:-1]
+        return k[:-6] + "_bf16x" if k.endswith("_f16x3") else k
+
+    events = {fam_of(k): v for k, v in bench.get("kernels", {}).items()}
     res = {"_timed_steps": steps, "_bench_ms_per_step_under_rocprof": bench["ms_per_step"]}
     for key, (fam, per_pass) in FAMILIES.items():
         if fam not in per:
