@@ -450,15 +450,18 @@ int mr_skinny_bwd_f32(const float* dz, int64_t lddz, int n, const float* E, int6
  *      (trans_a = 1: the bias gradient that belongs to the weight gradient).
  *   epilogue, in this order: + bias[n]; dropout with the counter mask of csrc/dropout.h under (drop_p, drop_key), row = m, column = n;
  *   + R[m][n]; epi = MR_EPI_GELU_FWD: C = v, C2 = gelu_erf(v) (the pre-activation the backward needs AND the activation);
- *   epi = MR_EPI_GELU_BWD: C = v * gelu'(E[m][n]).   bn: 0 = choose the tile width, 32 / 64 = force it. */
+ *   epi = MR_EPI_GELU_BWD: C = v * gelu'(E[m][n]).   bn: 0 = choose the tile width, 32 / 64 = force it.
+ *   products: 0 = exact fp32 on v_mfma_f32_16x16x4_f32 (every output element the ascending-k FMA chain, bit for bit); 6 = bf16x6 split
+ *   precision (three bf16 pieces per operand split while the tile is staged, six v_mfma_f32_16x16x32_bf16 products, fp32 accumulation:
+ *   ~2^-24 per product over fp32's whole range -- 1e-6-sized gradients included -- at 2.7 x fewer matrix-pipe cycles). */
 #define MR_EPI_NONE 0
 #define MR_EPI_GELU_FWD 1
 #define MR_EPI_GELU_BWD 2
 int mr_gemm_tile_f32(const float* A, int64_t lda, int trans_a, const float* b0, const float* b1, const float* b2, int64_t ldb, int trans_b,
                      int nseg_b, int seg_b, const float* bias0, const float* bias1, const float* bias2, int M, int N, int K, const float* R,
                      int64_t ldr, float* c0, float* c1, float* c2, int64_t ldc, int nseg_c, int seg_c, float* colsum0, float* colsum1,
-                     float* colsum2, int epi, const float* E, int64_t lde, float* C2, int64_t ldc2, float drop_p, uint32_t drop_key, int bn,
-                     mr_stream_t stream);
+                     float* colsum2, int epi, const float* E, int64_t lde, float* C2, int64_t ldc2, float drop_p, uint32_t drop_key, int products,
+                     int bn, mr_stream_t stream);
 
 /* Softmax self-attention backward on packed sequences: qkv (T, 3 H dh) = [Q | K | V] and ctx (T, H dh) as in mr_attn_f32,
  * dctx = d loss / d ctx; rowstat (T, H, 2) is workspace; dqkv (T, 3 H dh) receives [dQ | dK | dV].  dh must be 64.

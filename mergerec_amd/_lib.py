@@ -72,7 +72,7 @@ SIGNATURES = {
     "mr_gemm_nt_bf16x6_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_i64, c_i, c_p]),
     "mr_split_weights_kblock_f16_f32": (c_i, [c_p, c_p, c_p, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "mr_gemm_tile_f32": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i,
-                               c_p, c_p, c_p, c_i, c_p, c_i64, c_p, c_i64, c_f, c_u32, c_i, c_p]),
+                               c_p, c_p, c_p, c_i, c_p, c_i64, c_p, c_i64, c_f, c_u32, c_i, c_i, c_p]),
     "mr_distill_loss_rows_var_f32": (c_i, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_i64, c_f, c_p]),
     "mr_skinny_scores_f32": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_i64, c_i, c_p, c_i64, c_p]),
     "mr_skinny_bwd_ws_bytes": (c_sz, [c_i, c_i64, c_i]),

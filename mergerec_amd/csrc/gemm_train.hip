@@ -44,6 +44,27 @@ struct Args {
     int tiles_m, tiles_n, nwg;
 };
 
+// ---- bf16x6 arithmetic (ARITH = 1): x = hi + mid + lo with three bf16 pieces, six products, fp32 accumulation (as csrc/gemm_bf16.hip)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPitchB = 144;   // bytes per row of a piece image: 64 bf16 (one k-tile) + 16 -> the 16 rows of a ds_read_b128 hit 64 distinct banks
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void split4(const float4 x, uint2& h, uint2& m, uint2& l) {
+    h.x = pack2(x.x, x.y);
+    h.y = pack2(x.z, x.w);
+    const float r0 = x.x - lo_f(h.x), r1 = x.y - hi_f(h.x), r2 = x.z - lo_f(h.y), r3 = x.w - hi_f(h.y);
+    m.x = pack2(r0, r1);
+    m.y = pack2(r2, r3);
+    l.x = pack2(r0 - lo_f(m.x), r1 - hi_f(m.x));
+    l.y = pack2(r2 - lo_f(m.y), r3 - hi_f(m.y));
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad(float x) {  // as csrc/backward.hip gelu_bwd_kernel
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
@@ -67,16 +88,23 @@ struct Tile {
 };
 
 // ZF: K is not a multiple of BK -- the last k-tile is zero-filled past K (token-deep weight gradients); otherwise no select is compiled in
-template <bool TA, bool TB, int BN, int BK, int KD, bool ZF>
+// ARITH: 0 = exact fp32 (v_mfma_f32_16x16x4_f32; every output element the single ascending-k FMA chain); 1 = bf16x6 split precision
+// (three bf16 pieces per operand, six v_mfma_f32_16x16x32_bf16 products per 32 k: fp32-grade ~2^-24 per product, full fp32 range -- gradients
+// of 1e-6 included, which fp16 pieces would not hold -- at 2.7 x fewer matrix-pipe cycles; the producers split while they stage).
+template <bool TA, bool TB, int BN, int BK, int KD, bool ZF, int ARITH = 0>
 __global__ __launch_bounds__(kThreads, 1) void gemm_tile_kernel(const Args g) {
     constexpr bool WIDE = BN == 64;
+    static_assert(ARITH == 0 || BK == 64, "the piece images hold one 64-k tile per row");
     using TAi = Tile<TA, BM, BK, WIDE>;
     using TBi = Tile<TB, BN, BK, WIDE>;
     constexpr int SA = TAi::S, SB = TBi::S;
     constexpr int kDepth = KD;                // k-tiles in flight (even: the LDS buffer of a ring slot is then a compile-time constant)
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    float* const As0 = lds_dyn;               // [2][BK * SA]
+    float* const As0 = lds_dyn;               // [2][BK * SA]                       (ARITH 0)
     float* const Bs0 = lds_dyn + 2 * BK * SA; // [2][BK * SB]
+    // ARITH 1: per buffer three piece images of A (64 rows x kPitchB bytes each) then three of B (BN rows): [row][k] with k contiguous
+    unsigned char* const Hs0 = reinterpret_cast<unsigned char*>(lds_dyn);
+    constexpr int kImgA = BM * kPitchB, kImgB = BN * kPitchB, kBufH = 3 * (kImgA + kImgB);
 
     // tile order: row tile fastest -- the (few) row tiles that share a weight panel run together on one XCD
     const int pid = mr::xcd_remap(blockIdx.x, g.nwg);
@@ -160,10 +188,67 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tile_kernel(const Args g) {
             }
         }
     };
-    auto lstore = [&](int buf, const Stage& st, int kt) {   // kt = the k-tile the stage holds (for the zero fill past K)
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // ARITH 1, TA: this producer thread's share of sum_k Aop[m][k] (the bias gradient)
+    auto lstore = [&](int buf, const Stage& st, int kt, bool real) {   // kt = the k-tile the stage holds (zero fill past K); real: not the re-read behind the last tile
         float* as = As0 + buf * (BK * SA);
         float* bs = Bs0 + buf * (BK * SB);
         const int k0 = kt * BK;
+        if (ARITH == 1) {
+            unsigned char* ha = Hs0 + buf * kBufH;
+            unsigned char* hb = ha + 3 * kImgA;
+#pragma unroll
+            for (int p = 0; p < TAi::NV; ++p) {
+                const bool ok = !ZF || (TA ? (k0 + ra_ + p * TAi::PER_PASS < K) : (k0 + 4 * ca < K));
+                const float4 v = ok ? st.a[p] : zero4;
+                uint2 h, m, l;
+                split4(v, h, m, l);
+                if (TA) {   // four rows m .. m + 3 at ONE k: a 16-bit store per row and piece
+                    const int kr = ra_ + p * TAi::PER_PASS;
+                    if (real) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
+                    unsigned char* d = ha + (4 * ca) * kPitchB + 2 * kr;
+                    const uint2 pc[3] = {h, m, l};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        unsigned char* dq = d + q * kImgA;
+                        *reinterpret_cast<uint16_t*>(dq) = (uint16_t)(pc[q].x & 0xffffu);
+                        *reinterpret_cast<uint16_t*>(dq + kPitchB) = (uint16_t)(pc[q].x >> 16);
+                        *reinterpret_cast<uint16_t*>(dq + 2 * kPitchB) = (uint16_t)(pc[q].y & 0xffffu);
+                        *reinterpret_cast<uint16_t*>(dq + 3 * kPitchB) = (uint16_t)(pc[q].y >> 16);
+                    }
+                } else {    // four consecutive k of ONE row: an 8-byte store per piece
+                    unsigned char* d = ha + (ra_ + p * TAi::PER_PASS) * kPitchB + 8 * ca;
+                    *reinterpret_cast<uint2*>(d) = h;
+                    *reinterpret_cast<uint2*>(d + kImgA) = m;
+                    *reinterpret_cast<uint2*>(d + 2 * kImgA) = l;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < TBi::NV; ++p) {
+                const bool ok = !ZF || (TB ? (k0 + rb_ + p * TBi::PER_PASS < K) : (k0 + 4 * cb < K));
+                const float4 v = ok ? st.b[p] : zero4;
+                uint2 h, m, l;
+                split4(v, h, m, l);
+                if (TB) {
+                    const int kr = rb_ + p * TBi::PER_PASS;
+                    unsigned char* d = hb + (4 * cb) * kPitchB + 2 * kr;
+                    const uint2 pc[3] = {h, m, l};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        unsigned char* dq = d + q * kImgB;
+                        *reinterpret_cast<uint16_t*>(dq) = (uint16_t)(pc[q].x & 0xffffu);
+                        *reinterpret_cast<uint16_t*>(dq + kPitchB) = (uint16_t)(pc[q].x >> 16);
+                        *reinterpret_cast<uint16_t*>(dq + 2 * kPitchB) = (uint16_t)(pc[q].y & 0xffffu);
+                        *reinterpret_cast<uint16_t*>(dq + 3 * kPitchB) = (uint16_t)(pc[q].y >> 16);
+                    }
+                } else {
+                    unsigned char* d = hb + (rb_ + p * TBi::PER_PASS) * kPitchB + 8 * cb;
+                    *reinterpret_cast<uint2*>(d) = h;
+                    *reinterpret_cast<uint2*>(d + kImgB) = m;
+                    *reinterpret_cast<uint2*>(d + 2 * kImgB) = l;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < TAi::NV; ++p) {
             const bool ok = !ZF || (TA ? (k0 + ra_ + p * TAi::PER_PASS < K) : (k0 + 4 * ca < K));
@@ -195,11 +280,37 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tile_kernel(const Args g) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
-    const bool want_colsum = (g.colsum[0] != nullptr) && tn == 0 && wn == 0;  // wave-uniform
+    const bool want_colsum = ARITH == 0 && (g.colsum[0] != nullptr) && tn == 0 && wn == 0;  // wave-uniform (ARITH 1: the producers do it)
     float cs[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) cs[i] = 0.f;
     auto compute = [&](int buf) {
+        if (ARITH == 1) {   // lane (row / col li, k group lk): 8 consecutive k = one 16-byte read per piece and fragment
+            const unsigned char* ha = Hs0 + buf * kBufH + (wm * (16 * NI) + li) * kPitchB + 16 * lk;
+            const unsigned char* hb = Hs0 + buf * kBufH + 3 * kImgA + (wn * 16 + li) * kPitchB + 16 * lk;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {   // two 32-k steps per k-tile
+                bf16x8 b[3], a[NI][3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    b[q] = *reinterpret_cast<const bf16x8*>(hb + q * kImgB + 64 * s);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) a[i][q] = *reinterpret_cast<const bf16x8*>(ha + q * kImgA + i * 16 * kPitchB + 64 * s);
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {   // smallest terms first, hi * hi last (csrc/gemm_bf16.hip)
+                    f32x4 c = acc[i];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
+                    acc[i] = c;
+                }
+            }
+            return;
+        }
         const float* ap = As0 + buf * (BK * SA) + lk * SA + wm * (16 * NI) + li;
         const float* bp = Bs0 + buf * (BK * SB) + lk * SB + wn * 16 + li;
 #pragma unroll
@@ -221,7 +332,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tile_kernel(const Args g) {
         Stage ring[kDepth];   // register ring: tile kt + kDepth is requested while tile kt + 1 is written to LDS
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) gload(ktile(j), ring[j]);
-        lstore(0, ring[0], 0);
+        lstore(0, ring[0], 0, true);
         __syncthreads();                                   // tile 0 is in LDS
         for (int kt0 = 0; kt0 < nk; kt0 += kDepth) {
 #pragma unroll
@@ -229,18 +340,37 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tile_kernel(const Args g) {
                 const int kt = kt0 + j;
                 if (kt < nk) {  // uniform
                     gload(ktile(kt + kDepth), ring[j]);    // slot j's tile (kt) is already in LDS: refill it
-                    lstore((kt + 1) & 1, ring[(j + 1) % kDepth], ktile(kt + 1));  // buffer (kt + 1) & 1 was last read for tile kt - 1
+                    lstore((kt + 1) & 1, ring[(j + 1) % kDepth], ktile(kt + 1), kt + 1 < nk);  // buffer (kt + 1) & 1 was last read for tile kt - 1
                     __syncthreads();                       // consumers finished tile kt; tile kt + 1 is in LDS
                 }
             }
         }
-        return;   // the epilogue belongs to the consumer waves (no barrier behind this point)
+        if (ARITH == 1 && TA && g.colsum[0] != nullptr && tn == 0) {
+            // bias gradient: sum_k Aop[m][k] = the fp32 values this thread staged (its k rows, columns 4 ca .. + 3), then the 16 threads of a
+            // column group in k-row order -- through LDS buffer 0, which nobody reads any more (one barrier, matched by the consumers below)
+            float4* red = reinterpret_cast<float4*>(lds_dyn);   // [16 k-row groups][16 column groups]
+            red[ra_ * 16 + ca] = csum;
+            __syncthreads();
+            if (tid < 16) {
+                float4 t = red[tid];
+                for (int r = 1; r < 16; ++r) { const float4 u = red[r * 16 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+                const int cseg_ = (m0 >= g.seg_c) + (m0 >= 2 * g.seg_c);
+                float* out = g.colsum[cseg_] + (m0 - cseg_ * g.seg_c) + 4 * tid;
+                const int m = m0 + 4 * tid;
+                if (m < M) out[0] = t.x;
+                if (m + 1 < M) out[1] = t.y;
+                if (m + 2 < M) out[2] = t.z;
+                if (m + 3 < M) out[3] = t.w;
+            }
+        }
+        return;   // the epilogue belongs to the consumer waves
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         compute(kt & 1);
         __syncthreads();
     }
+    if (ARITH == 1 && TA && g.colsum[0] != nullptr && tn == 0) __syncthreads();   // the producers' bias-gradient reduction (above)
 
     // ---- epilogue
     const int cseg = (m0 >= g.seg_c) + (m0 >= 2 * g.seg_c);  // a row tile lies inside one C segment (seg_c % 64 == 0, or one segment)
@@ -291,10 +421,11 @@ extern "C" int mr_gemm_tile_f32(const float* A, int64_t lda, int trans_a, const 
                                 int nseg_b, int seg_b, const float* bias0, const float* bias1, const float* bias2, int M, int N, int K,
                                 const float* R, int64_t ldr, float* c0, float* c1, float* c2, int64_t ldc, int nseg_c, int seg_c, float* colsum0,
                                 float* colsum1, float* colsum2, int epi, const float* E, int64_t lde, float* C2, int64_t ldc2, float drop_p,
-                                uint32_t drop_key, int bn, mr_stream_t stream) {
+                                uint32_t drop_key, int products, int bn, mr_stream_t stream) {
     if (!A || !b0 || !c0 || M < 0 || N < 1 || K < 1 || nseg_b < 1 || nseg_b > 3 || nseg_c < 1 || nseg_c > 3) return MR_EINVAL;
     if ((nseg_b > 1 && !b1) || (nseg_b > 2 && !b2) || (nseg_c > 1 && !c1) || (nseg_c > 2 && !c2)) return MR_EINVAL;
     if (epi != MR_EPI_NONE && epi != MR_EPI_GELU_FWD && epi != MR_EPI_GELU_BWD) return MR_EUNSUPPORTED;
+    if (products != 0 && products != 6) return MR_EUNSUPPORTED;   // 0 = exact fp32 (the FMA chain), 6 = bf16x6 split precision
     if ((epi == MR_EPI_GELU_FWD && !C2) || (epi == MR_EPI_GELU_BWD && !E)) return MR_EINVAL;
     uint32_t thresh;
     float inv;
@@ -345,14 +476,19 @@ extern "C" int mr_gemm_tile_f32(const float* A, int64_t lda, int trans_a, const 
     const bool zf = (K % 64) != 0;
     static const int kd_env = [] { const char* e = getenv("MR_GEMM_TILE_KD"); return e ? atoi(e) : 0; }();  // A/B: 2 / 3 / 4 tiles in flight
     const int kd = (kd_env >= 2 && kd_env <= 4) ? kd_env : 3;
-#define MR_GT(TA_, TB_, BN_, ZF_, KD_)                                                                                                       \
-    do {                                                                                                                                     \
-        constexpr size_t shm_ = (size_t)2 * 64 * (Tile<TA_, BM, 64, BN_ == 64>::S + Tile<TB_, BN_, 64, BN_ == 64>::S) * sizeof(float);        \
-        static mr::DynLdsCeiling lds_ceiling;                                                                                                \
-        if (const int e_ = lds_ceiling.ensure(reinterpret_cast<const void*>(&gemm_tile_kernel<TA_, TB_, BN_, 64, KD_, ZF_>), shm_)) return e_; \
-        hipLaunchKernelGGL((gemm_tile_kernel<TA_, TB_, BN_, 64, KD_, ZF_>), dim3(g.nwg), dim3(kThreads), shm_, st, g);                        \
+#define MR_GT(TA_, TB_, BN_, ZF_, KD_, AR_)                                                                                                      \
+    do {                                                                                                                                         \
+        constexpr size_t shm_ = AR_ ? (size_t)2 * 3 * kPitchB * (BM + BN_)                                                                        \
+                                    : (size_t)2 * 64 * (Tile<TA_, BM, 64, BN_ == 64>::S + Tile<TB_, BN_, 64, BN_ == 64>::S) * sizeof(float);       \
+        static mr::DynLdsCeiling lds_ceiling;                                                                                                    \
+        if (const int e_ = lds_ceiling.ensure(reinterpret_cast<const void*>(&gemm_tile_kernel<TA_, TB_, BN_, 64, KD_, ZF_, AR_>), shm_)) return e_; \
+        hipLaunchKernelGGL((gemm_tile_kernel<TA_, TB_, BN_, 64, KD_, ZF_, AR_>), dim3(g.nwg), dim3(kThreads), shm_, st, g);                        \
     } while (0)
-#define MR_GT4(TA_, TB_, BN_, ZF_) do { if (kd == 2) MR_GT(TA_, TB_, BN_, ZF_, 2); else if (kd == 3) MR_GT(TA_, TB_, BN_, ZF_, 3); else MR_GT(TA_, TB_, BN_, ZF_, 4); } while (0)
+#define MR_GT4(TA_, TB_, BN_, ZF_)                                                                                           \
+    do {                                                                                                                     \
+        if (products == 6) MR_GT(TA_, TB_, BN_, ZF_, 3, 1);                                                                  \
+        else if (kd == 2) MR_GT(TA_, TB_, BN_, ZF_, 2, 0); else if (kd == 3) MR_GT(TA_, TB_, BN_, ZF_, 3, 0); else MR_GT(TA_, TB_, BN_, ZF_, 4, 0); \
+    } while (0)
 #define MR_GT3(TA_, TB_, BN_) do { if (zf) MR_GT4(TA_, TB_, BN_, true); else MR_GT4(TA_, TB_, BN_, false); } while (0)
     if (bn == 64) {
         if (trans_a) { if (trans_b) MR_GT3(true, true, 64); else MR_GT3(true, false, 64); }

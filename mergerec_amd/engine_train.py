@@ -45,6 +45,7 @@ class Dropout:
 
 # A/B switch of the r04 token-sized tile kernel in the exact-fp32 graph (1 = default; 0 = the r03 route: NT kernel + split-K + transposes)
 _TILE = os.environ.get("MR_TRAIN_TILE", "1") != "0"
+_TILE_PRODUCTS = int(os.environ.get("MR_TRAIN_TILE_PRODUCTS", "0"))
 
 _LINEARS = ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "intermediate.dense", "output.dense")
 
@@ -127,12 +128,19 @@ class EncoderTrainGraph:
         self.window = spec.one_sided_window if self.rec else -1
         self.drop = dropout if (dropout is not None and dropout.active) else None  # None: the deterministic graph, bit for bit
         self._saved = None
+        # arithmetic of the token-sized products in "f32" mode: bf16x6 (fp32-grade: ~2^-24 per product over fp32's whole range, gradients of
+        # 1e-6 included; 2.7 x fewer matrix-pipe cycles than the fp32 MFMA) unless MR_TRAIN_TILE_PRODUCTS=0 asks for the exact FMA chain
+        self.tile_products = _TILE_PRODUCTS
 
     # ---------------------------------------------------------------------------------------------- products
+    def _gt(self, *args, **kwargs):
+        """ops.gemm_tile in this graph's token-sized arithmetic (``tile_products``: 0 = exact fp32 FMA chain, 6 = bf16x6 split precision)"""
+        return ops.gemm_tile(*args, products=self.tile_products, **kwargs)
+
     def _linear(self, x, w, name: str, residual=None, out=None):
         """x W^T + b for the Linear ``name`` (arena key without ".weight")."""
         if self.mode == "f32" and _TILE:
-            return ops.gemm_tile(x, [w[name + ".weight"]], biases=[w[name + ".bias"]], residual=residual, out=out)
+            return self._gt(x, [w[name + ".weight"]], biases=[w[name + ".bias"]], residual=residual, out=out)
         if self.mode == "f32":
             return ops.gemm_nt_train(x, w[name + ".weight"], w[name + ".bias"], residual=residual, out=out)
         n, k = self.layout.shapes[name + ".weight"]
@@ -166,7 +174,7 @@ class EncoderTrainGraph:
             names = [f"{lp}attention.self.{n}" for n in ("query", "key", "value")]
             qkv = torch.empty(pb.T, 3 * sp.hidden, dtype=torch.float32, device=x.device)
             if self.mode == "f32" and _TILE:  # one launch over the three weights (csrc/gemm_train.hip: no split-K, no reduce)
-                ops.gemm_tile(x, [w[n + ".weight"] for n in names], biases=[w[n + ".bias"] for n in names], out=qkv)
+                self._gt(x, [w[n + ".weight"] for n in names], biases=[w[n + ".bias"] for n in names], out=qkv)
             elif self.mode == "f32":
                 for s, n in enumerate(names):
                     ops.gemm_nt_train(x, w[n + ".weight"], w[n + ".bias"], out=qkv[:, s * sp.hidden:(s + 1) * sp.hidden])
@@ -184,7 +192,7 @@ class EncoderTrainGraph:
                 kvg = torch.empty(pb.T, 2 * sp.hidden, dtype=torch.float32, device=x.device)
                 if self.mode == "f32" and _TILE:
                     gn = [f"{lp}attention.self.{n}" for n in ("key_global", "value_global")]
-                    ops.gemm_tile(x, [w[n + ".weight"] for n in gn], biases=[w[n + ".bias"] for n in gn], out=kvg)
+                    self._gt(x, [w[n + ".weight"] for n in gn], biases=[w[n + ".bias"] for n in gn], out=kvg)
                 else:
                     for s, n in enumerate(("key_global", "value_global")):
                         self._linear(x, w, f"{lp}attention.self.{n}", out=kvg[:, s * sp.hidden:(s + 1) * sp.hidden])
@@ -192,12 +200,12 @@ class EncoderTrainGraph:
                                          drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_GLOBAL_ROW) if pa > 0.0 else 0)
             if self.mode == "f32" and _TILE:  # the product's epilogue carries bias, dropout mask, residual and GELU: one launch per Linear
                 n_o, n_1, n_2 = lp + "attention.output.dense", lp + "intermediate.dense", lp + "output.dense"
-                a = ops.gemm_tile(ctx, [w[n_o + ".weight"]], biases=[w[n_o + ".bias"]], residual=x, drop_p=ph,
+                a = self._gt(ctx, [w[n_o + ".weight"]], biases=[w[n_o + ".bias"]], residual=x, drop_p=ph,
                                   drop_key=dr.key(l, ops.DROP_SITE_ATTN_OUT) if ph > 0.0 else 0)
                 h = ops.layernorm(a, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps)
                 i = torch.empty(pb.T, sp.intermediate, dtype=torch.float32, device=x.device)
-                u = ops.gemm_tile(h, [w[n_1 + ".weight"]], biases=[w[n_1 + ".bias"]], epi=ops.EPI_GELU_FWD, out2=i)
-                o = ops.gemm_tile(i, [w[n_2 + ".weight"]], biases=[w[n_2 + ".bias"]], residual=h, drop_p=ph,
+                u = self._gt(h, [w[n_1 + ".weight"]], biases=[w[n_1 + ".bias"]], epi=ops.EPI_GELU_FWD, out2=i)
+                o = self._gt(i, [w[n_2 + ".weight"]], biases=[w[n_2 + ".bias"]], residual=h, drop_p=ph,
                                   drop_key=dr.key(l, ops.DROP_SITE_FFN_OUT) if ph > 0.0 else 0)
             else:
                 if ph > 0.0:  # a = dropout(ctx Wo^T + bo) + x ; o = dropout(i W2^T + b2) + h: the residual joins after the mask
@@ -276,15 +284,15 @@ class EncoderTrainGraph:
             do = ops.layernorm_bwd(s["o"], dx, w[lp + "output.LayerNorm.weight"], sp.ln_eps, g[lp + "output.LayerNorm.weight"],
                                    g[lp + "output.LayerNorm.bias"])
             dod = ops.dropout_rows(do, ph, dr.key(l, ops.DROP_SITE_FFN_OUT)) if ph > 0.0 else do   # the dense sees the masked gradient
-            ops.gemm_tile(dod, [s["i"]], trans_a=T, trans_b=T, out=[g[n_2 + ".weight"]], colsum=[g[n_2 + ".bias"]])       # dW2 = dY^T i, db2
-            du = ops.gemm_tile(dod, [w[n_2 + ".weight"]], trans_b=T, epi=ops.EPI_GELU_BWD, E=s["u"])                      # (dY W2) * gelu'(u)
-            ops.gemm_tile(du, [s["h"]], trans_a=T, trans_b=T, out=[g[n_1 + ".weight"]], colsum=[g[n_1 + ".bias"]])         # dW1, db1
-            dh = ops.gemm_tile(du, [w[n_1 + ".weight"]], trans_b=T, residual=do)                                          # + the residual path of o
+            self._gt(dod, [s["i"]], trans_a=T, trans_b=T, out=[g[n_2 + ".weight"]], colsum=[g[n_2 + ".bias"]])       # dW2 = dY^T i, db2
+            du = self._gt(dod, [w[n_2 + ".weight"]], trans_b=T, epi=ops.EPI_GELU_BWD, E=s["u"])                      # (dY W2) * gelu'(u)
+            self._gt(du, [s["h"]], trans_a=T, trans_b=T, out=[g[n_1 + ".weight"]], colsum=[g[n_1 + ".bias"]])         # dW1, db1
+            dh = self._gt(du, [w[n_1 + ".weight"]], trans_b=T, residual=do)                                          # + the residual path of o
             da = ops.layernorm_bwd(s["a"], dh, w[lp + "attention.output.LayerNorm.weight"], sp.ln_eps,
                                    g[lp + "attention.output.LayerNorm.weight"], g[lp + "attention.output.LayerNorm.bias"])
             dad = ops.dropout_rows(da, ph, dr.key(l, ops.DROP_SITE_ATTN_OUT)) if ph > 0.0 else da
-            ops.gemm_tile(dad, [s["ctx"]], trans_a=T, trans_b=T, out=[g[n_o + ".weight"]], colsum=[g[n_o + ".bias"]])     # dWo, dbo
-            dctx = ops.gemm_tile(dad, [w[n_o + ".weight"]], trans_b=T)
+            self._gt(dad, [s["ctx"]], trans_a=T, trans_b=T, out=[g[n_o + ".weight"]], colsum=[g[n_o + ".bias"]])     # dWo, dbo
+            dctx = self._gt(dad, [w[n_o + ".weight"]], trans_b=T)
             dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window, max_len=pb.max_len, seq_order=pb.seq_order,
                                      drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_ATTN_PROBS) if pa > 0.0 else 0, work=pb.attn_work)
             if self.rec:
@@ -292,16 +300,16 @@ class EncoderTrainGraph:
                                                          pb.cu_seqlens, pb.B, sp.heads,
                                                          drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_GLOBAL_ROW) if pa > 0.0 else 0)
                 gn = [f"{lp}attention.self.{n}" for n in ("key_global", "value_global")]
-                ops.gemm_tile(dkvg, [s["x"]], trans_a=T, trans_b=T, out=[g[n + ".weight"] for n in gn], colsum=[g[n + ".bias"] for n in gn])
-                da = ops.gemm_tile(dkvg, [w[n + ".weight"] for n in gn], trans_b=T, residual=da)
+                self._gt(dkvg, [s["x"]], trans_a=T, trans_b=T, out=[g[n + ".weight"] for n in gn], colsum=[g[n + ".bias"] for n in gn])
+                da = self._gt(dkvg, [w[n + ".weight"] for n in gn], trans_b=T, residual=da)
                 # query_global reads the CLS rows only
                 name = f"{lp}attention.self.query_global"
                 x_cls = ops.gather_rows(s["x"], pb.cls_rows)
-                ops.gemm_tile(dqg, [x_cls], trans_a=T, trans_b=T, out=[g[name + ".weight"]], colsum=[g[name + ".bias"]])
-                ops.scatter_add_rows(ops.gemm_tile(dqg, [w[name + ".weight"]], trans_b=T), pb.cls_rows, da)
+                self._gt(dqg, [x_cls], trans_a=T, trans_b=T, out=[g[name + ".weight"]], colsum=[g[name + ".bias"]])
+                ops.scatter_add_rows(self._gt(dqg, [w[name + ".weight"]], trans_b=T), pb.cls_rows, da)
             qn = [f"{lp}attention.self.{n}" for n in ("query", "key", "value")]
-            ops.gemm_tile(dqkv, [s["x"]], trans_a=T, trans_b=T, out=[g[n + ".weight"] for n in qn], colsum=[g[n + ".bias"] for n in qn])
-            dx = ops.gemm_tile(dqkv, [w[n + ".weight"] for n in qn], trans_b=T, residual=da)                               # + the residual path of a
+            self._gt(dqkv, [s["x"]], trans_a=T, trans_b=T, out=[g[n + ".weight"] for n in qn], colsum=[g[n + ".bias"] for n in qn])
+            dx = self._gt(dqkv, [w[n + ".weight"] for n in qn], trans_b=T, residual=da)                               # + the residual path of a
         e = p + "embeddings."
         if ph > 0.0:  # x0 = dropout(LN(emb))
             dx = ops.dropout_rows(dx, ph, dr.key(0, ops.DROP_SITE_EMBED), out=dx)

@@ -696,13 +696,14 @@ EPI_NONE, EPI_GELU_FWD, EPI_GELU_BWD = 0, 1, 2
 
 def gemm_tile(A: torch.Tensor, Bs, trans_a: bool = False, trans_b: bool = False, biases=None, residual: Optional[torch.Tensor] = None, out=None,
               colsum=None, epi: int = EPI_NONE, E: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, drop_p: float = 0.0,
-              drop_key: int = 0, bn: int = 0) -> torch.Tensor:
+              drop_key: int = 0, bn: int = 0, products: int = 0) -> torch.Tensor:
     """Token-sized exact-fp32 product of the training graph (mr_gemm_tile_f32): ``Aop @ Bop^T`` with either operand in either orientation,
     no transposed copies, no split-K; every output element is the ascending-k FMA chain.
       A: (M, K), or with trans_a (K, M).   Bs: 1..3 matrices -- (seg_n, K) each, stacked along N; with trans_b (seg_k, N) each, stacked along K.
       out: an (M, N) tensor, or (trans_a only) a list of 1..3 (seg_m, N) tensors stacked along M with optional ``colsum`` (seg_m,) each.
       epilogue: + bias (per N segment; one bias with trans_b), dropout (drop_p, drop_key; row = m, column = n), + residual,
-      EPI_GELU_FWD (out = pre-activation, out2 = gelu) or EPI_GELU_BWD (out = product * gelu'(E))."""
+      EPI_GELU_FWD (out = pre-activation, out2 = gelu) or EPI_GELU_BWD (out = product * gelu'(E)).
+      products: 0 = exact fp32 (the FMA chain), 6 = bf16x6 split precision (fp32-grade, 2.7 x fewer matrix-pipe cycles)."""
     Bs = list(Bs)
     if not (A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.stride(1) == 1):
         raise ValueError("A must be a 2-D fp32 GPU tensor with unit inner stride (the HIP path has no CPU fallback)")
@@ -735,7 +736,7 @@ def gemm_tile(A: torch.Tensor, Bs, trans_a: bool = False, trans_b: bool = False,
         Bs[0].stride(0) if Bs[0].shape[0] > 1 else Bs[0].shape[1], int(trans_b), nb, seg_b, ptr(biases[0]), ptr(biases[1]),
         ptr(biases[2]), M, N, K, ptr(residual), 0 if residual is None else residual.stride(0), ptr(Cp[0]), ptr(Cp[1]), ptr(Cp[2]), outs[0].stride(0), nc,
         seg_c, ptr(cs[0]), ptr(cs[1]), ptr(cs[2]), epi, ptr(E), 0 if E is None else E.stride(0), ptr(out2), 0 if out2 is None else out2.stride(0),
-        float(drop_p), int(drop_key), bn, _stream(A)), "mr_gemm_tile_f32")
+        float(drop_p), int(drop_key), products, bn, _stream(A)), "mr_gemm_tile_f32")
     PROF.end(ev, A.device, "gemm_tile", flops=2.0 * M * N * K, nbytes=4.0 * (M * K + N * K + M * N))
     return outs[0] if nc == 1 else outs
 

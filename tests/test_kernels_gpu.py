@@ -719,3 +719,26 @@ def test_gemm_tile_segments_and_epilogues(ops):
     y = ops.gemm_tile(xd, [Ws[0].to(DEV)], biases=[bs[0].to(DEV)], residual=res.to(DEV), drop_p=0.1, drop_key=key).cpu()
     plain = (CO.gemm_nt(x, Ws[0]) + bs[0]).to(DEV)
     assert torch.equal(y, ops.dropout_rows(plain, 0.1, key, residual=res.to(DEV)).cpu())
+
+
+@pytest.mark.parametrize("bn", [32, 64])
+@pytest.mark.parametrize("ta,tb,M,N,K", [(False, False, 602, 768, 768), (False, True, 602, 768, 2304), (True, True, 768, 768, 602), (True, True, 2304, 768, 37),
+                                        (False, False, 70, 192, 3072), (True, False, 64, 100, 32)])
+def test_gemm_tile_bf16x6_is_fp32_grade_over_the_whole_range(ops, bn, ta, tb, M, N, K):
+    """products = 6: three bf16 pieces per operand split while the tile is staged, six MFMA products -- ~2^-24 per product for operands of
+    ANY magnitude (rows of 1e-6-sized gradients beside O(1) activations: fp16 pieces would flush them), every orientation and tile width;
+    the bias gradient that rides along (trans_a) against float64."""
+    g = _g(M + 3 * N + 7 * K + bn + 1)
+    Aop, Bop = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    Aop[::3] *= 1e-6
+    Bop[1::4] *= 3e3
+    A = (Aop.t().contiguous() if ta else Aop).to(DEV)
+    B = (Bop.t().contiguous() if tb else Bop).to(DEV)
+    cs = torch.full((M,), 7.5, device=DEV) if (ta and tb) else None
+    got = ops.gemm_tile(A, [B], trans_a=ta, trans_b=tb, bn=bn, products=6, colsum=[cs] if cs is not None else None).cpu().double()
+    want = Aop.double() @ Bop.double().T
+    scale = Aop.abs().double() @ Bop.abs().double().T
+    err = float(((got - want).abs() / scale).max())
+    assert err <= 2.0 ** -21, err    # per element: relative to sum_k |a||b| (fp32 accumulation over K terms included)
+    if cs is not None:
+        assert torch.allclose(cs.cpu().double(), Aop.double().sum(1), rtol=1e-5, atol=1e-5 * float(Aop.abs().sum(1).max()))
