@@ -65,6 +65,23 @@ __device__ __forceinline__ float hi_h(uint32_t u) {
     asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(u));
     return r;
 }
+// the fp16 low piece of (a, b) given their packed high piece w: f16(a - float(w.lo)), f16(b - float(w.hi)).  One v_fma_mix per value
+// (fp16 operand read in place, difference exact in fp32, one rounding to fp16) instead of convert + subtract + a shared pack: the same
+// bits as pack2h(a - lo_h(w), b - hi_h(w))
+__device__ __forceinline__ uint32_t resid2h(float a, float b, uint32_t w) {
+    uint32_t r;
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, -%1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(r)
+        : "v"(w), "v"(a), "v"(b));
+    return r;
+}
+// x of lane i and of lane i ^ 32, the same pair in both halves (gfx950 v_permlane32_swap: no LDS round trip)
+__device__ __forceinline__ void half_pair(float x, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
 template <bool F16> __device__ __forceinline__ uint32_t pk(float a, float b) { return F16 ? pack2h(a, b) : pack2(a, b); }
 template <bool F16> __device__ __forceinline__ float lo_v(uint32_t u) { return F16 ? lo_h(u) : lo_f(u); }
 template <bool F16> __device__ __forceinline__ float hi_v(uint32_t u) { return F16 ? hi_h(u) : hi_f(u); }
@@ -342,6 +359,10 @@ __global__ __launch_bounds__(kThreads, (NP == 3 ? 2 : 3)) void attn_split_kernel
 // heaviest sequences first.  K / V rows come through buffer loads whose range ends at the sequence's last row (rows past it read
 // as zeros and are masked as before): two vector adds per key tile instead of the clamped 64-bit row arithmetic.
 // Per (query row, key tile) the operations and their order are those of attn_split_kernel: results are bit-identical.
+// r04: interior key tiles of two-tile full attention (NP = 2) run in software-pipelined order -- the softmax and the P split of one
+// query tile issue under the other tile's MFMAs, the next K / V tile's split + LDS stores under the last product -- with the fp16 low
+// pieces from one v_fma_mix per value and the cross-half maximum / sum through v_permlane32_swap: 340 -> 224 vector instructions per
+// 48 MFMAs, still bit-identical to attn_split_kernel (which keeps the plain formulation as the test twin).
 template <int J>
 struct QIdx { static constexpr int value = J; };
 
@@ -353,6 +374,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
     int window, float* __restrict__ ctx, int nseq, uint32_t drop_thresh = 0u, float drop_inv = 1.f, uint32_t drop_key = 0u) {
     constexpr int BUFB = 2 * NP * KPIECE;  // K pieces, then V pieces
     constexpr int QROWS = 128 * QT;
+    constexpr bool PIPED = QT == 2 && !WINDOWED && !DROP && NP == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 * BUFB
     const int id = blockIdx.x, slot = id >> 3;
     const int e = slot / H, h = slot - e * H;
@@ -429,6 +451,12 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
     const int kw1 = (sr + 16) * KROWB + ((((sc4 >> 1) ^ (((sr + 16) >> 1) & 7)) << 4) | ((sc4 & 1) << 3));
     auto store_k = [&](const u32x4 xb, unsigned char* dst) {
         float r0 = __uint_as_float(xb[0]), r1 = __uint_as_float(xb[1]), r2 = __uint_as_float(xb[2]), r3 = __uint_as_float(xb[3]);
+        if (F16) {  // NP == 2
+            const uint32_t w0 = pack2h(r0, r1), w1 = pack2h(r2, r3);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
+            *reinterpret_cast<uint2*>(dst + KPIECE) = make_uint2(resid2h(r0, r1, w0), resid2h(r2, r3, w1));
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const uint32_t w0 = pk<F16>(r0, r1), w1 = pk<F16>(r2, r3);
@@ -483,7 +511,136 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
             if (WINDOWED) rel[j] = rel[j] && (kb == 0 || (kb + 31 >= q0[j] - window && kb <= q0[j] + 31 + window));
         }
         const bool both = QT == 2 && rel[0] && rel[QT - 1];
-        if (rel[0] || rel[QT - 1]) {
+        bool staged = false;
+        if (PIPED && both && kb + 32 <= len) {
+            // ---- interior key tile, both query tiles live (the common case of full attention): the four products and the two softmaxes
+            // in software-pipelined order, so that the vector work of one query tile issues under the matrix work of the other --
+            //   A  S0 = K Q0^T            B  S1 = K Q1^T   || softmax(S0) -> P0      C  O0 += V^T P0^T || softmax(S1) -> P1
+            //   D  O1 += V^T P1^T || split + store of the next K / V tile
+            // Per (query row, key tile) the operations and their order are those of the general path below: bit-identical results.
+            f32x16 s0, s1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+            auto kfrag = [&](int st, u32x4 (&ka)[NP]) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    ka[p] = *reinterpret_cast<const u32x4*>(buf + p * KPIECE + lr * KROWB + (((2 * st + lh) ^ kswz) << 4));
+            };
+            const unsigned char* vbase = buf + NP * KPIECE;
+            auto vfrag = [&](int dt, int st, u32x4 (&va)[NP]) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const unsigned char* a0 = vbase + p * KPIECE + vtr[dt] + (16 * st) * KROWB;
+                    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                   (__attribute__((address_space(3))) s16x4*)a0));
+                    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                   (__attribute__((address_space(3))) s16x4*)(a0 + 8 * KROWB)));
+                    va[p][0] = lo.x; va[p][1] = lo.y; va[p][2] = hi.x; va[p][3] = hi.y;
+                }
+            };
+            // branch-free softmax of an unmasked tile: returns the rescale factor of the running output
+            auto softmax_in = [&](auto J, const f32x16& sc, u32x4 (&pq)[2][NP]) -> float {
+                constexpr int j = decltype(J)::value;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+                float ma, mb;
+                half_pair(mx, ma, mb);
+                mx = fmaxf(ma, mb);
+                const float m_new = fmaxf(m[j], mx);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float corr =
+                    (m[j] == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : __builtin_amdgcn_exp2f(m[j] - m_use);
+                const float sub = F16 ? m_use - 10.f : m_use;
+                float ps = 0.f;
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = __builtin_amdgcn_exp2f(sc[r] - sub);
+                    ps += pv[r];
+                }
+                float pa, pb;
+                half_pair(ps, pa, pb);
+                ps = pa + pb;
+                l[j] = l[j] * corr + ps;
+                m[j] = m_new;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a = pv[8 * st + 2 * q], c = pv[8 * st + 2 * q + 1];
+                        const uint32_t w = pk<F16>(a, c);
+                        pq[st][0][q] = w;
+                        pq[st][1][q] = F16 ? resid2h(a, c, w) : pk<F16>(a - lo_v<F16>(w), c - hi_v<F16>(w));
+                    }
+                return corr;
+            };
+            u32x4 pp0[2][NP], pp1[2][NP];
+            // A: all eight K fragment loads in flight together
+            u32x4 ka[4][NP];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) kfrag(st, ka[st]);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s0 = mfma_split<NP, F16>(ka[st], qp[0][st], s0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // B
+#pragma unroll
+            for (int st = 0; st < 4; ++st) kfrag(st, ka[st]);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s1 = mfma_split<NP, F16>(ka[st], qp[QT - 1][st], s1);
+            const float corr0 = softmax_in(QIdx<0>{}, s0, pp0);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (__builtin_amdgcn_ballot_w64(corr0 != 1.f) != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[0][0][r] *= corr0; o[0][1][r] *= corr0; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // C
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    u32x4 va[NP];
+                    vfrag(dt, st, va);
+                    o[0][dt] = mfma_split<NP, F16>(va, pp0[st], o[0][dt]);
+                }
+            const float corr1 = softmax_in(QIdx<QT - 1>{}, s1, pp1);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (__builtin_amdgcn_ballot_w64(corr1 != 1.f) != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[QT - 1][0][r] *= corr1; o[QT - 1][1][r] *= corr1; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // D
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    u32x4 va[NP];
+                    vfrag(dt, st, va);
+                    o[QT - 1][dt] = mfma_split<NP, F16>(va, pp1[st], o[QT - 1][dt]);
+                }
+            lstore(lds + ((it + 1) & 1) * BUFB);
+            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            staged = true;
+        } else if (rel[0] || rel[QT - 1]) {
             // ---- S^T tiles = K Q^T: one read of the K fragments serves both query tiles
             f32x16 s[QT];
 #pragma unroll
@@ -626,7 +783,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
         }
         MR_PH(3)
         __builtin_amdgcn_sched_barrier(0);
-        lstore(lds + ((it + 1) & 1) * BUFB);
+        if (!staged) lstore(lds + ((it + 1) & 1) * BUFB);
         MR_PH(4)
         __syncthreads();
         MR_PH(5)
