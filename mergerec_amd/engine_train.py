@@ -46,6 +46,8 @@ class Dropout:
 # A/B switch of the r04 token-sized tile kernel in the exact-fp32 graph (1 = default; 0 = the r03 route: NT kernel + split-K + transposes)
 _TILE = os.environ.get("MR_TRAIN_TILE", "1") != "0"
 _TILE_PRODUCTS = int(os.environ.get("MR_TRAIN_TILE_PRODUCTS", "0"))
+# weight-gradient products of the tile backward on a second stream (they feed nothing in the backward chain): MR_TRAIN_WGRAD_STREAM=0 keeps one stream
+_WGRAD_STREAM = os.environ.get("MR_TRAIN_WGRAD_STREAM", "1") != "0"
 
 _LINEARS = ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "intermediate.dense", "output.dense")
 
@@ -277,6 +279,22 @@ class EncoderTrainGraph:
         dr = self.drop
         ph, pa = (dr.p_hidden, dr.p_attn) if dr else (0.0, 0.0)
         T = True
+        # The weight gradients feed nothing in this chain (they meet the rest of the step again in the alpha-gradient contraction), and a
+        # 600-token product is one 12-wave workgroup per CU whose fill / drain / per-tile barriers leave the CU idle: they run on a second
+        # stream beside the input-gradient chain.  Same launches, same operands, disjoint outputs: bit-identical.  Every tensor a
+        # side-stream launch reads stays referenced until the main stream has waited for the side stream (allocator reuse).
+        main = torch.cuda.current_stream(d_cls.device)
+        side = self._wgrad_stream(d_cls.device) if _WGRAD_STREAM else None
+        keep = []
+
+        def wgrad(dy, xs, **kw):
+            if side is None:
+                return self._gt(dy, xs, trans_a=T, trans_b=T, **kw)
+            side.wait_stream(main)  # everything issued so far: dy, the zeroed gradient arena
+            with torch.cuda.stream(side):
+                self._gt(dy, xs, trans_a=T, trans_b=T, **kw)
+            keep.append((dy, xs))
+
         for l in reversed(range(sp.layers)):
             lp = f"{p}encoder.layer.{l}."
             s = sv["layers"][l]
@@ -284,14 +302,14 @@ class EncoderTrainGraph:
             do = ops.layernorm_bwd(s["o"], dx, w[lp + "output.LayerNorm.weight"], sp.ln_eps, g[lp + "output.LayerNorm.weight"],
                                    g[lp + "output.LayerNorm.bias"])
             dod = ops.dropout_rows(do, ph, dr.key(l, ops.DROP_SITE_FFN_OUT)) if ph > 0.0 else do   # the dense sees the masked gradient
-            self._gt(dod, [s["i"]], trans_a=T, trans_b=T, out=[g[n_2 + ".weight"]], colsum=[g[n_2 + ".bias"]])       # dW2 = dY^T i, db2
+            wgrad(dod, [s["i"]], out=[g[n_2 + ".weight"]], colsum=[g[n_2 + ".bias"]])       # dW2 = dY^T i, db2
             du = self._gt(dod, [w[n_2 + ".weight"]], trans_b=T, epi=ops.EPI_GELU_BWD, E=s["u"])                      # (dY W2) * gelu'(u)
-            self._gt(du, [s["h"]], trans_a=T, trans_b=T, out=[g[n_1 + ".weight"]], colsum=[g[n_1 + ".bias"]])         # dW1, db1
+            wgrad(du, [s["h"]], out=[g[n_1 + ".weight"]], colsum=[g[n_1 + ".bias"]])         # dW1, db1
             dh = self._gt(du, [w[n_1 + ".weight"]], trans_b=T, residual=do)                                          # + the residual path of o
             da = ops.layernorm_bwd(s["a"], dh, w[lp + "attention.output.LayerNorm.weight"], sp.ln_eps,
                                    g[lp + "attention.output.LayerNorm.weight"], g[lp + "attention.output.LayerNorm.bias"])
             dad = ops.dropout_rows(da, ph, dr.key(l, ops.DROP_SITE_ATTN_OUT)) if ph > 0.0 else da
-            self._gt(dad, [s["ctx"]], trans_a=T, trans_b=T, out=[g[n_o + ".weight"]], colsum=[g[n_o + ".bias"]])     # dWo, dbo
+            wgrad(dad, [s["ctx"]], out=[g[n_o + ".weight"]], colsum=[g[n_o + ".bias"]])     # dWo, dbo
             dctx = self._gt(dad, [w[n_o + ".weight"]], trans_b=T)
             dqkv = ops.attention_bwd(s["qkv"], s["ctx"], dctx, pb.cu_seqlens, pb.B, sp.heads, window=self.window, max_len=pb.max_len, seq_order=pb.seq_order,
                                      drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_ATTN_PROBS) if pa > 0.0 else 0, work=pb.attn_work)
@@ -300,15 +318,15 @@ class EncoderTrainGraph:
                                                          pb.cu_seqlens, pb.B, sp.heads,
                                                          drop_p=pa, drop_key=dr.key(l, ops.DROP_SITE_GLOBAL_ROW) if pa > 0.0 else 0)
                 gn = [f"{lp}attention.self.{n}" for n in ("key_global", "value_global")]
-                self._gt(dkvg, [s["x"]], trans_a=T, trans_b=T, out=[g[n + ".weight"] for n in gn], colsum=[g[n + ".bias"] for n in gn])
+                wgrad(dkvg, [s["x"]], out=[g[n + ".weight"] for n in gn], colsum=[g[n + ".bias"] for n in gn])
                 da = self._gt(dkvg, [w[n + ".weight"] for n in gn], trans_b=T, residual=da)
                 # query_global reads the CLS rows only
                 name = f"{lp}attention.self.query_global"
                 x_cls = ops.gather_rows(s["x"], pb.cls_rows)
-                self._gt(dqg, [x_cls], trans_a=T, trans_b=T, out=[g[name + ".weight"]], colsum=[g[name + ".bias"]])
+                wgrad(dqg, [x_cls], out=[g[name + ".weight"]], colsum=[g[name + ".bias"]])
                 ops.scatter_add_rows(self._gt(dqg, [w[name + ".weight"]], trans_b=T), pb.cls_rows, da)
             qn = [f"{lp}attention.self.{n}" for n in ("query", "key", "value")]
-            self._gt(dqkv, [s["x"]], trans_a=T, trans_b=T, out=[g[n + ".weight"] for n in qn], colsum=[g[n + ".bias"] for n in qn])
+            wgrad(dqkv, [s["x"]], out=[g[n + ".weight"] for n in qn], colsum=[g[n + ".bias"] for n in qn])
             dx = self._gt(dqkv, [w[n + ".weight"] for n in qn], trans_b=T, residual=da)                               # + the residual path of a
         e = p + "embeddings."
         if ph > 0.0:  # x0 = dropout(LN(emb))
@@ -321,8 +339,17 @@ class EncoderTrainGraph:
             ops.scatter_add_rows(de, pb.tok_ip, g[e + "item_position_embeddings.weight"])
         else:
             ops.colsum(de, g[e + "token_type_embeddings.weight"][0])
+        if side is not None:
+            main.wait_stream(side)  # the gradient arena is complete for whatever the main stream runs next
+        del keep
         self._saved = None
         return g_flat
+
+    def _wgrad_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None:
+            st = self._side = torch.cuda.Stream(device=device)
+        return st
 
     def backward(self, d_cls: torch.Tensor) -> torch.Tensor:
         """d loss / d CLS rows (B, d) -> d loss / d parameters, flat, arena layout (pads zero)."""
