@@ -106,6 +106,22 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[NP]) {
     }
 }
 
+// split8 of the work-list kernels: fp16 low pieces through resid2h (attn_split_kernel keeps split8, so the bit-identity test of the two
+// kernels also compares the two formulations)
+template <int NP, bool F16>
+__device__ __forceinline__ void split8w(const float (&x)[8], u32x4 (&out)[NP]) {
+    if (F16) {  // NP == 2
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w = pack2h(x[2 * j], x[2 * j + 1]);
+            out[0][j] = w;
+            out[1][j] = resid2h(x[2 * j], x[2 * j + 1], w);
+        }
+        return;
+    }
+    split8<NP, false>(x, out);
+}
+
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
     union { u32x4 u; bf16x8 b; } c;
     c.u = v;
@@ -415,7 +431,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                 const float4 x1 = *reinterpret_cast<const float4*>(qr + 16 * s + 4);
                 const float x[8] = {x0.x * scale_log2e, x0.y * scale_log2e, x0.z * scale_log2e, x0.w * scale_log2e,
                                     x1.x * scale_log2e, x1.y * scale_log2e, x1.z * scale_log2e, x1.w * scale_log2e};
-                split8<NP, F16>(x, qp[j][s]);
+                split8<NP, F16>(x, qp[j][s]);  // once per workgroup: the plain form (the compiler contracts q * scale - hi into one fma there; keep its bits)
             }
         }
     }
@@ -698,7 +714,11 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                         mx = fmaxf(mx, s[j][r]);
                     }
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                {
+                    float ma, mb;
+                    half_pair(mx, ma, mb);
+                    mx = fmaxf(ma, mb);
+                }
                 const float m_new = fmaxf(m[j], mx);
                 const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
                 const float corr =
@@ -713,7 +733,11 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                     pv[r] = __builtin_amdgcn_exp2f(s[j][r] - (F16 ? m_use - 10.f : m_use));
                     ps += pv[r];
                 }
-                ps += __shfl_xor(ps, 32, 64);
+                {
+                    float pa, pb;
+                    half_pair(ps, pa, pb);
+                    ps = pa + pb;
+                }
                 l[j] = l[j] * corr + ps;
                 m[j] = m_new;
                 if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0) {  // wave-uniform: the running maxima usually stop moving early
@@ -732,7 +756,7 @@ __global__ __launch_bounds__(kThreads, (QT == 2 ? 2 : (NP == 3 ? 2 : 3))) void a
                 for (int st = 0; st < 2; ++st) {
                     const float x[8] = {pv[8 * st], pv[8 * st + 1], pv[8 * st + 2], pv[8 * st + 3],
                                         pv[8 * st + 4], pv[8 * st + 5], pv[8 * st + 6], pv[8 * st + 7]};
-                    split8<NP, F16>(x, pp[j][st]);
+                    split8w<NP, F16>(x, pp[j][st]);
                 }
             };
             if (rel[0]) softmax(QIdx<0>{});

@@ -800,3 +800,48 @@ def test_models_apply_dropout_in_train_mode_only_with_hf_default_rates():
     assert torch.equal(mm_on.forward_with_grad(batch), t0)
     with pytest.raises(ValueError):
         _tiny_model(cfgd, hidden_dropout_prob=1.0)
+
+
+@pytest.mark.parametrize("kind", ["roberta", "recformer"])
+def test_side_stream_weight_gradients_are_bit_identical_to_the_one_stream_backward(kind, monkeypatch):
+    """the dW products issued on a second stream beside the dX chain (engine_train._WGRAD_STREAM) give the same gradient arena, bit for bit,
+    as the backward on one stream -- with dropout on, repeated so that a missing dependency would show as a stale read"""
+    from mergerec_amd import engine_train as ET
+    from mergerec_amd.engine import ArenaLayout, EncoderRunner
+    from tests.test_path_gpu import _spec
+
+    if kind == "roberta":
+        g3 = load_golden("g3_roberta.pt")
+        cfgd, sd, b = g3["cfg"], g3["state_dict"], {"input_ids": g3["input_ids"], "attention_mask": g3["attention_mask"]}
+    else:
+        case = load_golden("g4_recformer.pt")["cases"][0]
+        cfgd, sd, b = case["cfg"], case["state_dict"], case["batch"]
+    views = OrderedDict((k, v.to(torch.float32)) for k, v in sd.items())
+    layout = ArenaLayout(OrderedDict((k, tuple(v.shape)) for k, v in views.items()))
+    spec = _spec(cfgd, kind) if kind == "recformer" else _spec(cfgd)
+    pb = EncoderRunner(spec).pack(b, DEV)
+    R = torch.randn(pb.B, spec.hidden, generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def grads(side: bool):
+        monkeypatch.setattr(ET, "_WGRAD_STREAM", side)
+        flat = layout.pack(views, DEV).requires_grad_(True)
+        out = ET.encode_with_grad(ET.EncoderTrainGraph(spec, layout, dropout=ET.Dropout(0.1, 0.1, 17, 3)), flat, pb)
+        (torch.nn.functional.normalize(out, dim=-1) * R).sum().backward()
+        torch.cuda.synchronize()
+        return flat.grad.clone()
+
+    def same(a, b):
+        # the embedding tables are accumulated with atomicAdd (several tokens share a row: order, hence the last bit, is not fixed from run
+        # to run on either route); every other gradient has one owner per element
+        va, vb = layout.views(a), layout.views(b)
+        for k in va:
+            if k.endswith("_embeddings.weight"):
+                assert torch.allclose(va[k], vb[k], rtol=1e-5, atol=1e-7), k
+            else:
+                assert torch.equal(va[k], vb[k]), k
+
+    one = grads(False)
+    assert float(one.abs().max()) > 0.0
+    same(grads(False), one)
+    for _ in range(3):
+        same(grads(True), one)
