@@ -55,6 +55,12 @@ def read_safetensors(path: str) -> "OrderedDict[str, torch.Tensor]":
     meta.pop("__metadata__", None)
     raw = np.memmap(path, dtype=np.uint8, mode="r", offset=base) if size > base else np.zeros(0, np.uint8)
     out = OrderedDict()
+    for name, ent in meta.items():
+        ok = isinstance(ent, dict) and isinstance(ent.get("dtype"), str) and isinstance(ent.get("shape"), list) \
+            and isinstance(ent.get("data_offsets"), list) and len(ent["data_offsets"]) == 2 \
+            and all(isinstance(v, int) and v >= 0 for v in (*ent["shape"], *ent["data_offsets"]))
+        if not ok:
+            raise CheckpointError(f"{path}: header entry {name!r} is not {{dtype, shape, data_offsets}}")
     for name, ent in sorted(meta.items(), key=lambda kv: kv[1]["data_offsets"][0]):
         if ent["dtype"] not in _ST_DTYPES:
             raise CheckpointError(f"{path}: tensor {name!r} has unsupported dtype {ent['dtype']}")

@@ -105,6 +105,12 @@ def test_malformed_files_and_configs_are_refused(tmp_path):
     p.write_bytes(struct.pack("<Q", len(head)) + head + b"\0" * 4)
     with pytest.raises(C.CheckpointError, match="unsupported dtype"):
         C.read_safetensors(str(p))
+    for ent in ({"dtype": "F32", "shape": [4]}, {"dtype": "F32", "shape": [4], "data_offsets": [0]}, [1, 2],
+                {"dtype": "F32", "shape": [-4], "data_offsets": [0, 16]}):  # header entries that are not {dtype, shape, data_offsets}
+        head = json.dumps({"w": ent}).encode()
+        p.write_bytes(struct.pack("<Q", len(head)) + head + b"\0" * 16)
+        with pytest.raises(C.CheckpointError, match="header entry"):
+            C.read_safetensors(str(p))
     (tmp_path / "d").mkdir()
     (tmp_path / "d" / "config.json").write_text("{}")
     with pytest.raises(FileNotFoundError):
