@@ -48,6 +48,8 @@ _TILE = os.environ.get("MR_TRAIN_TILE", "1") != "0"
 _TILE_PRODUCTS = int(os.environ.get("MR_TRAIN_TILE_PRODUCTS", "0"))
 # weight-gradient products of the tile backward on a second stream (they feed nothing in the backward chain): MR_TRAIN_WGRAD_STREAM=0 keeps one stream
 _WGRAD_STREAM = os.environ.get("MR_TRAIN_WGRAD_STREAM", "1") != "0"
+# the alpha-learning step's merge and alpha-gradient contraction in arena ranges on that second stream (merger.weight_learning.MergeOverlap)
+_MERGE_OVERLAP = os.environ.get("MR_TRAIN_MERGE_OVERLAP", "1") != "0"
 
 _LINEARS = ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "intermediate.dense", "output.dense")
 
@@ -130,6 +132,7 @@ class EncoderTrainGraph:
         self.window = spec.one_sided_window if self.rec else -1
         self.drop = dropout if (dropout is not None and dropout.active) else None  # None: the deterministic graph, bit for bit
         self._saved = None
+        self.overlap = None  # a MergeOverlap: ``flat`` arrives range by range from a second stream; per-layer d alpha contractions in backward
         # arithmetic of the token-sized products in "f32" mode: bf16x6 (fp32-grade: ~2^-24 per product over fp32's whole range, gradients of
         # 1e-6 included; 2.7 x fewer matrix-pipe cycles than the fp32 MFMA) unless MR_TRAIN_TILE_PRODUCTS=0 asks for the exact FMA chain
         self.tile_products = _TILE_PRODUCTS
@@ -159,6 +162,9 @@ class EncoderTrainGraph:
         sp, p = self.spec, self.prefix
         w = self.layout.views(flat)
         e = p + "embeddings."
+        ov = self.overlap
+        if ov is not None:
+            ov.wait("others", first_only=True)  # the embedding range
         # pre-LayerNorm embedding sum (the fused inference kernel does not expose it): three row gathers
         emb = ops.gather_rows(w[e + "word_embeddings.weight"], pb.tok_word) + ops.gather_rows(w[e + "position_embeddings.weight"], pb.tok_pos)
         if self.rec:  # recformer/models.py:104-136: + token_type[tt] + item_position[ip]
@@ -173,6 +179,8 @@ class EncoderTrainGraph:
         saved = dict(pb=pb, flat=flat, emb=emb, layers=[])
         for l in range(sp.layers):
             lp = f"{p}encoder.layer.{l}."
+            if ov is not None:
+                ov.wait(str(l))
             names = [f"{lp}attention.self.{n}" for n in ("query", "key", "value")]
             qkv = torch.empty(pb.T, 3 * sp.hidden, dtype=torch.float32, device=x.device)
             if self.mode == "f32" and _TILE:  # one launch over the three weights (csrc/gemm_train.hip: no split-K, no reduce)
@@ -227,6 +235,8 @@ class EncoderTrainGraph:
             saved["layers"].append(dict(x=x, qkv=qkv, ctx=ctx, a=a, h=h, u=u, i=i, o=o, qg=qg, kvg=kvg, l=l))
             x = x_next
         self._saved = saved
+        if ov is not None:
+            ov.wait()  # whatever is left (the pooler range): the vector is whole before anything outside this graph reads it
         return ops.gather_rows(x, pb.cls_rows)
 
     # ---------------------------------------------------------------------------------------------- backward
@@ -284,7 +294,8 @@ class EncoderTrainGraph:
         # stream beside the input-gradient chain.  Same launches, same operands, disjoint outputs: bit-identical.  Every tensor a
         # side-stream launch reads stays referenced until the main stream has waited for the side stream (allocator reuse).
         main = torch.cuda.current_stream(d_cls.device)
-        side = self._wgrad_stream(d_cls.device) if _WGRAD_STREAM else None
+        ov = self.overlap
+        side = (ov.stream if ov is not None else self._wgrad_stream(d_cls.device)) if (_WGRAD_STREAM or ov is not None) else None
         keep = []
 
         def wgrad(dy, xs, **kw):
@@ -328,6 +339,8 @@ class EncoderTrainGraph:
             qn = [f"{lp}attention.self.{n}" for n in ("query", "key", "value")]
             wgrad(dqkv, [s["x"]], out=[g[n + ".weight"] for n in qn], colsum=[g[n + ".bias"] for n in qn])
             dx = self._gt(dqkv, [w[n + ".weight"] for n in qn], trans_b=T, residual=da)                               # + the residual path of a
+            if ov is not None:
+                ov.contract(str(l), g_flat)  # this layer's gradients are complete: its d alpha range, under the next layer's backward
         e = p + "embeddings."
         if ph > 0.0:  # x0 = dropout(LN(emb))
             dx = ops.dropout_rows(dx, ph, dr.key(0, ops.DROP_SITE_EMBED), out=dx)
@@ -339,6 +352,8 @@ class EncoderTrainGraph:
             ops.scatter_add_rows(de, pb.tok_ip, g[e + "item_position_embeddings.weight"])
         else:
             ops.colsum(de, g[e + "token_type_embeddings.weight"][0])
+        if ov is not None:
+            ov.contract("others", g_flat)  # embeddings (complete only now) and pooler
         if side is not None:
             main.wait_stream(side)  # the gradient arena is complete for whatever the main stream runs next
         del keep

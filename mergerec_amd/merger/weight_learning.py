@@ -25,22 +25,98 @@ from .enums import LearnType, MergeType
 StateDict = Dict[str, torch.Tensor]
 
 
+class MergeOverlap:
+    """Chunk plan of ONE alpha-learning step: the merge and the alpha-gradient contraction are parameter-sized HBM streams, the encoder's
+    600-token products beside them barely touch HBM -- so both streams run in arena ranges (the embeddings, each encoder layer, the
+    pooler: ``ArenaLayout.group_segments``) on a SECOND stream, under the encoder's kernels.  Forward: every range is merged in arena
+    order and the training graph waits for a layer's event just before that layer's first product.  Backward: a layer's range is
+    contracted with the task vectors as soon as the layer's gradients are complete (the weight gradients already run on that stream);
+    only the embedding range -- complete last -- is left at the end.  Same kernels on sub-ranges: the merged parameters are bit-identical;
+    d alpha is the same sums grouped per range (ranges in arena order: deterministic)."""
+
+    def __init__(self, layout: ArenaLayout, stream: "torch.cuda.Stream"):
+        groups, seg_off, seg_gid = layout.group_segments()
+        self.bounds = [int(v) for v in seg_off.tolist()]
+        self.keys = [groups[g] for g in seg_gid]            # "others" (embeddings), "0", "1", ..., "others" (pooler)
+        self.stream = stream
+        self.events = [None] * len(self.keys)
+        self.partials = [None] * len(self.keys)
+        self.hold = []                                        # what the side stream reads, until the main stream has joined it
+        self.tv = self.g_ptr = None
+
+    # ---- forward
+    def merge(self, base, tv, alpha, seg_off, out):
+        main = torch.cuda.current_stream(base.device)
+        self.stream.wait_stream(main)                         # alpha's two torch ops; the previous readers of the recycled `out` block
+        self.hold += [alpha, out]
+        self.tv = tv
+        with torch.cuda.stream(self.stream):
+            for c in range(len(self.keys)):
+                b, e = self.bounds[c], self.bounds[c + 1]
+                ops.merge_nway(base, tv, alpha, seg_off, out=out, p_begin=b, p_count=e - b)
+                self.events[c] = torch.cuda.Event()
+                self.events[c].record(self.stream)
+        return out
+
+    def wait(self, key: Optional[str] = None, first_only: bool = False):
+        """the main stream waits for the merged range(s) of group ``key`` (None: everything not yet waited for)"""
+        main = torch.cuda.current_stream()
+        for c, k in enumerate(self.keys):
+            if self.events[c] is not None and (key is None or k == key):
+                main.wait_event(self.events[c])
+                self.events[c] = None
+                if first_only:
+                    return
+
+    # ---- backward
+    def contract(self, key: str, g_flat: torch.Tensor):
+        """d alpha of group ``key``'s range(s), on the side stream, ordered after everything issued so far on both streams"""
+        main = torch.cuda.current_stream(g_flat.device)
+        self.stream.wait_stream(main)
+        self.g_ptr = g_flat.data_ptr()
+        self.hold.append(g_flat)
+        with torch.cuda.stream(self.stream):
+            for c, k in enumerate(self.keys):
+                if k == key and self.partials[c] is None:
+                    self.partials[c] = ops.merge_bwd_alpha(self.tv, g_flat, p_begin=self.bounds[c], p_count=self.bounds[c + 1] - self.bounds[c])
+
+    def dalpha(self, g: torch.Tensor, n_segments: int) -> Optional[torch.Tensor]:
+        """(S, N) from the per-range contractions, or None when they do not cover this gradient vector (the caller contracts in one launch)"""
+        if self.g_ptr != g.data_ptr() or any(p is None for p in self.partials):
+            return None
+        torch.cuda.current_stream(g.device).wait_stream(self.stream)
+        for t in self.partials:
+            t.record_stream(torch.cuda.current_stream(g.device))
+        rows = torch.cat(self.partials, dim=0)               # (ranges, N), arena order
+        self.hold.clear()
+        return rows if n_segments == rows.shape[0] else rows.sum(dim=0, keepdim=True)
+
+
 class _MergeFunction(torch.autograd.Function):
     """a20: the merge as an autograd node.  forward = mr_merge_nway_f32, backward = mr_merge_bwd_alpha_f32
     (dalpha[s, i] = <tau_i[segment s], dL/dtheta[segment s]>), i.e. the gradient the reference obtains by
-    differentiating task_wise.py:43-47 / layer_wise.py:75-81 inside merge_train.py's training step."""
+    differentiating task_wise.py:43-47 / layer_wise.py:75-81 inside merge_train.py's training step.
+    ``plan`` (a MergeOverlap): both streams in arena ranges on a second stream, under the encoder's kernels."""
 
     @staticmethod
-    def forward(ctx, alpha, base, tv, seg_off, out):
-        ctx.tv, ctx.seg_off = tv, seg_off
-        ops.merge_nway(base, tv, alpha.detach().contiguous(), seg_off, out=out)
+    def forward(ctx, alpha, base, tv, seg_off, out, plan=None):
+        ctx.tv, ctx.seg_off, ctx.plan = tv, seg_off, plan
+        a = alpha.detach().contiguous()
+        if plan is not None:
+            return plan.merge(base, tv, a, seg_off, out)
+        ops.merge_nway(base, tv, a, seg_off, out=out)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         g = grad_out.contiguous()
-        dalpha = ops.merge_bwd_alpha(ctx.tv, g, ctx.seg_off)
-        return dalpha, None, None, None, None
+        S = 1 if ctx.seg_off is None else ctx.seg_off.numel() - 1
+        dalpha = ctx.plan.dalpha(g, S) if ctx.plan is not None else None
+        if dalpha is None:
+            if ctx.plan is not None:
+                torch.cuda.current_stream(g.device).wait_stream(ctx.plan.stream)
+            dalpha = ops.merge_bwd_alpha(ctx.tv, g, ctx.seg_off)
+        return dalpha, None, None, None, None, None
 
 
 def _check_isinstance_state_dict(t):
@@ -147,9 +223,16 @@ class TaskVectorMergingModuleBase(nn.Module):
         if self.slice_plan is not None:
             raise RuntimeError("alpha learning needs every task vector on every rank (d loss / d alpha contracts the full gradient with "
                                "each of them): build the module with placement='replicated' (merge_train.py does)")
-        merged = self.merged_params()
-        sw = None
+        from .. import engine_train as _ET
+
         mode = self.train_mode if self.model.spec.hidden % 128 == 0 else "f32"
+        plan = None
+        if mode == "f32" and _ET._TILE and _ET._MERGE_OVERLAP:   # the tile graph knows the per-layer hooks; MR_TRAIN_MERGE_OVERLAP=0: one launch each
+            if getattr(self, "_overlap_stream", None) is None:
+                self._overlap_stream = torch.cuda.Stream(device=self.base_model_tensor.device)
+            plan = MergeOverlap(self.layout, self._overlap_stream)
+        merged = self.merged_params(plan)
+        sw = None
         if mode == "bf16x3":  # the merged weights are new every step: re-split them (and their transposes) from the merged arena
             sw = getattr(self, "_split_weights", None)
             if sw is None:
@@ -159,6 +242,7 @@ class TaskVectorMergingModuleBase(nn.Module):
         # is in training mode, rates / seed / counter from the wrapped model
         graph = RobertaTrainGraph(self.model.spec, self.layout, prefix=self.model.runner.prefix, mode=mode, split_weights=sw,
                                   dropout=self.model.next_dropout(training=self.training))
+        graph.overlap = plan
         pb = self.model.runner.pack(batch, self.base_model_tensor.device)
         return encode_with_grad(graph, merged, pb)
 
@@ -195,11 +279,12 @@ class TaskVectorMergingModuleBase(nn.Module):
         parallel.sharded_merge(merge_slice, arena, self.slice_plan, self._scratch)
         return arena[: self.layout.padded_numel]
 
-    def merged_params(self) -> torch.Tensor:
+    def merged_params(self, plan: Optional[MergeOverlap] = None) -> torch.Tensor:
         """Differentiable merge: returns the merged arena vector with an autograd edge back to
-        global_weights / global_biases / per_weights (the backward runs the HIP alpha-gradient kernel)."""
+        global_weights / global_biases / per_weights (the backward runs the HIP alpha-gradient kernel).  With ``plan`` the vector is
+        written range by range on the plan's stream: its consumer waits per range (``MergeOverlap.wait``)."""
         return _MergeFunction.apply(self.effective_alpha(), self.base_model_tensor.data, self.task_vectors_tensor.data,
-                                    self._seg_off, torch.empty_like(self._merged))
+                                    self._seg_off, torch.empty_like(self._merged), plan)
 
     # -- pipelined re-merge (evaluation loops that re-merge per step, as the reference does on every forward) ---------------------------
     def pipeline_merges(self, on: bool = True):

@@ -160,15 +160,25 @@ def merge_running(base: Optional[torch.Tensor], models: torch.Tensor, weights: t
     return out
 
 
-def merge_bwd_alpha(tv: torch.Tensor, g: torch.Tensor, seg_off: Optional[torch.Tensor] = None) -> torch.Tensor:
+def merge_bwd_alpha(tv: torch.Tensor, g: torch.Tensor, seg_off: Optional[torch.Tensor] = None, p_begin: int = 0,
+                    p_count: Optional[int] = None) -> torch.Tensor:
+    """dalpha[s, i] = <tv[i, segment s], g[segment s]>.  ``p_begin`` / ``p_count`` (multiples of 4; one segment only): the contraction over
+    the arena range [p_begin, p_begin + p_count) alone -- the alpha-learning step contracts each layer's range as soon as its gradients exist."""
     _dev(tv, "tv", torch.float32), _dev(g, "g", torch.float32)
     N, P = tv.shape
     S = 1 if seg_off is None else seg_off.numel() - 1
+    shift = 0
+    if p_begin or p_count is not None:
+        p_count = P - p_begin if p_count is None else p_count
+        if seg_off is not None or p_begin < 0 or p_count < 0 or p_begin + p_count > P or (p_begin | p_count) & 3 or g.numel() < p_begin + p_count:
+            raise ValueError("a sub-range contraction takes one segment, a range inside the vectors, offsets in multiples of 4")
+        shift, P = 4 * p_begin, p_count
     lib = _lib.load()
     nbytes = lib.mr_merge_bwd_alpha_ws_bytes(N, S, P)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=tv.device)
     out = torch.empty(S, N, dtype=torch.float32, device=tv.device)
-    check(lib.mr_merge_bwd_alpha_f32(ptr(tv), tv.stride(0), ptr(g), ptr(seg_off), N, S, P, ptr(out), ptr(ws), nbytes, _stream(tv)), "mr_merge_bwd_alpha_f32")
+    check(lib.mr_merge_bwd_alpha_f32(tv.data_ptr() + shift, tv.stride(0), g.data_ptr() + shift, ptr(seg_off), N, S, P, ptr(out), ptr(ws), nbytes,
+                                     _stream(tv)), "mr_merge_bwd_alpha_f32")
     return out
 
 

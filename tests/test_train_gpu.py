@@ -845,3 +845,48 @@ def test_side_stream_weight_gradients_are_bit_identical_to_the_one_stream_backwa
     same(grads(False), one)
     for _ in range(3):
         same(grads(True), one)
+
+
+@pytest.mark.parametrize("learn", ["TASK_WISE", "LAYER_WISE"])
+def test_merge_and_alpha_gradient_in_arena_ranges_on_the_second_stream_match_the_one_launch_step(learn, monkeypatch):
+    """merger.weight_learning.MergeOverlap (the alpha-learning step's merge and d alpha contraction range by range on a second stream, under
+    the encoder's kernels) against the same step with one merge launch and one contraction launch: the loss -- a function of the merged
+    parameters -- bit for bit; d alpha to the rounding of sums grouped per range (1e-5 relative); repeated so that a missing dependency
+    between the streams would show as a stale read"""
+    from mergerec_amd import engine_train as ET
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchDistillationSequence
+    from mergerec_amd.module import DistillSequenceModule
+    from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
+    from tests.test_path_gpu import _tiny_model
+
+    g2 = load_golden("g2_merger.pt")
+    cfgd, ids, mask = g2["cfg"], g2["input_ids"], g2["attention_mask"]
+    B = ids.shape[0]
+    gen = torch.Generator().manual_seed(9)
+    items = [torch.nn.functional.normalize(torch.randn(m, cfgd["hidden"], generator=gen), dim=-1) for m in (50, 77)]
+    teachers = [torch.randn(B, m, generator=gen).clamp(-1, 1) for m in (50, 77)]
+    batch = BatchDistillationSequence(dataset_indexes=[i % 2 for i in range(B)], sequence_ids=torch.arange(B),
+                                      sequence={"input_ids": ids, "attention_mask": mask}).to(DEV)
+
+    def step(overlap: bool):
+        monkeypatch.setattr(ET, "_MERGE_OVERLAP", overlap)
+        mm = load_merging_module(MergeType.TASK_VECTOR, LearnType[learn], _tiny_model(cfgd), g2["pretrain"], [dict(f) for f in g2["finetunes"]], set(),
+                                 disable_softmax=True, initial_per_weight=0.3)
+        mod = DistillSequenceModule(mm, teachers, SinglePseudoLabelKDLoss(0.05, 1000.0), "cosine",
+                                    trainable_args_kwargs={"freeze_global_weight": True, "freeze_global_bias": True})
+        mod.item_embeddings = items
+        mod.eval()  # no dropout: the two routes then differ in nothing but the grouping of the d alpha sums
+        with torch.enable_grad():
+            loss = mod.training_step(batch, 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in mm.per_weights.items()}
+
+    l0, g0 = step(False)
+    assert all(float(v.abs().max()) > 0.0 for v in g0.values())
+    for _ in range(3):
+        l1, g1 = step(True)
+        assert l1 == l0
+        for k in g0:
+            assert torch.allclose(g1[k], g0[k], rtol=1e-5, atol=1e-6 * float(g0[k].abs().max())), (k, g1[k], g0[k])
