@@ -84,6 +84,14 @@ int mr_merge_nway_f32(const float* base, const float* tv, int64_t tv_stride, con
                       const int64_t* seg_off, int N, int S, int64_t p_begin, int64_t p_count, float* out,
                       mr_stream_t stream);
 
+/* Rows of ONE table inside the arena, merged alone: out[table_off + r*d + c] = base[..] + sum_i alpha[i] * tv[i][..] for the T rows r = idx[t]
+ * (int32, 0 <= r < rows; duplicates allowed; other values are skipped), element for element the operations of mr_merge_nway_f32 in its order
+ * (bit-identical rows).  alpha: the N coefficients of the segment that holds the table.  The alpha-learning step
+ * (weight_learning/module/_base.py:78-81 under merge_train.py) reads only its batch's word-embedding rows of the merged model: this writes those
+ * ~600 rows instead of streaming the 38.6 M-element table.  d % 4 == 0, table_off % 4 == 0. */
+int mr_merge_rows_f32(const float* base, const float* tv, int64_t tv_stride, const float* alpha, int N, const int32_t* idx, int T,
+                      int rows, int d, int64_t table_off, float* out, mr_stream_t stream);
+
 /* dalpha[s*N + i] = sum_{p in segment s} tv[i*tv_stride + p] * g[p]   (the backward of the merge w.r.t.
  * the effective coefficients).  Deterministic two-stage reduction (fixed chunking, fixed order).
  * replaces: autograd backward through task_wise.py:43-47 / layer_wise.py:75-81 (merge_train.py path). */

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mr_task_vector_f32": (c_i, [c_p, c_p, c_i64, c_p, c_p]),
     "mr_merge_nway_f32": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i, c_i, c_i64, c_i64, c_p, c_p]),
     "mr_merge_running_f32": (c_i, [c_p, c_p, c_i64, c_p, c_i, c_i64, c_p, c_p]),
+    "mr_merge_rows_f32": (c_i, [c_p, c_p, c_i64, c_p, c_i, c_p, c_i, c_i, c_i, c_i64, c_p, c_p]),
     "mr_merge_bwd_alpha_ws_bytes": (c_sz, [c_i, c_i, c_i64]),
     "mr_merge_bwd_alpha_f32": (c_i, [c_p, c_i64, c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_sz, c_p]),
     "mr_select_ws_bytes": (c_sz, [c_i64]),

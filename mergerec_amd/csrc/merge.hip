@@ -94,6 +94,37 @@ __global__ __launch_bounds__(kThreads) void merge_nway_kernel(const float* __res
     }
 }
 
+// Rows of ONE table of the arena (the alpha-learning step reads only its batch's word-embedding rows): out[off + r d + c] for the rows r
+// listed in idx (duplicates write the same bits), the per-element operations of merge_nway_kernel in its order.  One wave per listed row.
+__global__ __launch_bounds__(kThreads) void merge_rows_kernel(const float* __restrict__ base, const float* __restrict__ tv, int64_t tv_stride,
+                                                             const float* __restrict__ alpha, int N, const int32_t* __restrict__ idx, int T,
+                                                             int rows, int d, int64_t off, float* __restrict__ out) {
+    const int t = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const int r = idx[t];
+    if (r < 0 || r >= rows) return;  // (ids are validated when the batch is packed; never index outside the table)
+    const int64_t p0 = off + (int64_t)r * d;
+    for (int c = (threadIdx.x & 63) * 4; c < d; c += 256) {
+        const int64_t p = p0 + c;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < N; ++i) {
+            const float al = alpha[i];
+            const float4 tt = ld4(tv + (int64_t)i * tv_stride + p);
+            acc.x = __fadd_rn(acc.x, __fmul_rn(al, tt.x));
+            acc.y = __fadd_rn(acc.y, __fmul_rn(al, tt.y));
+            acc.z = __fadd_rn(acc.z, __fmul_rn(al, tt.z));
+            acc.w = __fadd_rn(acc.w, __fmul_rn(al, tt.w));
+        }
+        const float4 b = ld4(base + p);
+        float4 o;
+        o.x = __fadd_rn(b.x, acc.x);
+        o.y = __fadd_rn(b.y, acc.y);
+        o.z = __fadd_rn(b.z, acc.z);
+        o.w = __fadd_rn(b.w, acc.w);
+        *reinterpret_cast<float4*>(out + p) = o;
+    }
+}
+
 // generic N (> 8): runtime loop, one float4 per thread per step
 template <bool SEG>
 __global__ __launch_bounds__(kThreads) void merge_nway_generic_kernel(const float* __restrict__ base,
@@ -367,6 +398,16 @@ extern "C" int mr_merge_nway_f32(const float* base, const float* tv, int64_t tv_
             else
                 hipLaunchKernelGGL((merge_nway_generic_kernel<false>), dim3(nb), dim3(kThreads), 0, st, base, tv, tv_stride, alpha, seg_off, N, S, p_begin, p_count, out);
     }
+    return mr::check_launch();
+}
+
+extern "C" int mr_merge_rows_f32(const float* base, const float* tv, int64_t tv_stride, const float* alpha, int N, const int32_t* idx, int T,
+                                 int rows, int d, int64_t table_off, float* out, mr_stream_t stream) {
+    if (!base || !tv || !alpha || !out || N < 1 || T < 0 || rows < 1 || d < 4 || table_off < 0 || (T > 0 && !idx)) return MR_EINVAL;
+    if ((d & 3) || (table_off & 3) || (tv_stride & 3) || !mr::aligned16(base) || !mr::aligned16(tv) || !mr::aligned16(out)) return MR_EALIGN;
+    if (T == 0) return MR_OK;
+    hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)((T + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0, (hipStream_t)stream, base, tv,
+                       tv_stride, alpha, N, idx, T, rows, d, table_off, out);
     return mr::check_launch();
 }
 

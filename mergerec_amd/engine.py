@@ -158,6 +158,9 @@ class ArenaLayout:
         """a5: layer-wise groups (layer_wise.py:13-33: ``name.split('.')[3]`` if 'encoder.layer.' in name
         else 'others'), as maximal runs of adjacent same-group tensors in arena coordinates.
         Returns (group keys in first-seen order, seg_off int64 (S+1), group index per segment)."""
+        memo = getattr(self, "_group_segments", None)
+        if memo is not None:
+            return memo[0], memo[1].clone(), memo[2]
         groups: List[str] = []
         seg_start: List[int] = []
         seg_gid: List[int] = []
@@ -170,6 +173,7 @@ class ArenaLayout:
                 seg_start.append(self.offsets[k])
                 seg_gid.append(gid)
         seg_off = torch.tensor(seg_start + [self.padded_numel], dtype=torch.int64)
+        self._group_segments = (groups, seg_off.clone(), seg_gid)
         return groups, seg_off, seg_gid
 
 
@@ -354,14 +358,14 @@ class EncoderRunner:
         if B:
             cu[1:] = lens.cumsum(0).to(torch.int32)
         T = int(cu[-1])
-        cu_d = cu.to(device, non_blocking=True)
+        cu_d = ops.h2d(cu, device)
         tt = ip = gm = None
         if self.spec.kind == "recformer":
             for key in ("token_type_ids", "item_position_ids", "global_attention_mask"):
                 if key not in batch:
                     raise ValueError(f"Missing required key in batch: {key}")  # interface.py:71-74
             tt, ip, gm = batch["token_type_ids"], batch["item_position_ids"], batch["global_attention_mask"]
-        dev = lambda t: None if t is None else t.to(device, torch.int64, non_blocking=True).contiguous()
+        dev = lambda t: None if t is None else (t.to(device, torch.int64) if t.is_cuda else ops.h2d(t.to(torch.int64), device)).contiguous()
         err = self._err_word(device) if validate else None
         tw, tp, ttp, tip = ops.pack_tokens(dev(ids), dev(mask), cu_d, T, self.spec.pad_id, dev(tt), dev(ip), dev(gm) if validate else None, err,
                                            self.spec.vocab, self.spec.token_type_size, self.spec.max_item_embeddings)
@@ -371,12 +375,12 @@ class EncoderRunner:
         attn_work = None
         if B:
             plans = [ops.attn_work_plan(lens, q) for q in (128, 256)]
-            both = torch.cat([p[0] for p in plans]).to(device, non_blocking=True)
+            both = ops.h2d(torch.cat([p[0] for p in plans]), device)
             n128 = plans[0][0].numel()
             attn_work = {128: (both[:n128], plans[0][1]), 256: (both[n128:], plans[1][1])}
         return PackedBatch(B=B, T=T, max_len=int(lens.max()) if B else 0, cu_seqlens=cu_d, cls_rows=cu_d[:-1].contiguous(), attn_work=attn_work,
                            tok_word=tw, tok_pos=tp, tok_tt=ttp, tok_ip=tip, sum_len_sq=float((lens.double() ** 2).sum()) if B else 0.0,
-                           seq_order=torch.argsort(lens, descending=True, stable=True).to(torch.int32).to(device, non_blocking=True) if B > 1 else None)
+                           seq_order=ops.h2d(torch.argsort(lens, descending=True, stable=True).to(torch.int32), device) if B > 1 else None)
 
     # ---- forward ---------------------------------------------------------------------------------
     def embed(self, w: Dict[str, torch.Tensor], pb: PackedBatch) -> torch.Tensor:

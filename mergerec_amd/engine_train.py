@@ -50,6 +50,8 @@ _TILE_PRODUCTS = int(os.environ.get("MR_TRAIN_TILE_PRODUCTS", "0"))
 _WGRAD_STREAM = os.environ.get("MR_TRAIN_WGRAD_STREAM", "1") != "0"
 # the alpha-learning step's merge and alpha-gradient contraction in arena ranges on that second stream (merger.weight_learning.MergeOverlap)
 _MERGE_OVERLAP = os.environ.get("MR_TRAIN_MERGE_OVERLAP", "1") != "0"
+# ... with the word-embedding table merged and contracted in the batch's rows only (MR_TRAIN_SPARSE_WORD_ROWS=0: the whole table, as every other range)
+_SPARSE_WORD_ROWS = os.environ.get("MR_TRAIN_SPARSE_WORD_ROWS", "1") != "0"
 
 _LINEARS = ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "intermediate.dense", "output.dense")
 
@@ -132,10 +134,28 @@ class EncoderTrainGraph:
         self.window = spec.one_sided_window if self.rec else -1
         self.drop = dropout if (dropout is not None and dropout.active) else None  # None: the deterministic graph, bit for bit
         self._saved = None
+        # persistent (buffer, named views) pairs of the caller for the flat parameter vector and for the gradient arena: 200-odd view objects
+        # per vector and step are host time the 600-token step does not have (the step is launch-bound once the streams overlap)
+        self.param_cache = None   # (tensor, views): used when forward()'s ``flat`` is that tensor's memory
+        self.grad_cache = None    # (tensor, views): the gradient arena, zero-filled here at the start of every backward
         self.overlap = None  # a MergeOverlap: ``flat`` arrives range by range from a second stream; per-layer d alpha contractions in backward
         # arithmetic of the token-sized products in "f32" mode: bf16x6 (fp32-grade: ~2^-24 per product over fp32's whole range, gradients of
         # 1e-6 included; 2.7 x fewer matrix-pipe cycles than the fp32 MFMA) unless MR_TRAIN_TILE_PRODUCTS=0 asks for the exact FMA chain
         self.tile_products = _TILE_PRODUCTS
+
+    def _views(self, flat: torch.Tensor):
+        c = self.param_cache
+        if c is not None and c[0].data_ptr() == flat.data_ptr() and c[0].numel() == flat.numel():
+            return c[1]
+        return self.layout.views(flat)
+
+    def _grad_arena(self, like: torch.Tensor):
+        c = self.grad_cache
+        if c is not None and c[0].numel() == like.numel() and c[0].device == like.device:
+            c[0].zero_()
+            return c
+        g_flat = torch.zeros_like(like)
+        return g_flat, self.layout.views(g_flat)
 
     # ---------------------------------------------------------------------------------------------- products
     def _gt(self, *args, **kwargs):
@@ -160,7 +180,7 @@ class EncoderTrainGraph:
     def forward(self, flat: torch.Tensor, pb: PackedBatch) -> torch.Tensor:
         """-> (B, d) CLS rows of the last layer (not normalised); keeps what backward needs."""
         sp, p = self.spec, self.prefix
-        w = self.layout.views(flat)
+        w = self._views(flat)
         e = p + "embeddings."
         ov = self.overlap
         if ov is not None:
@@ -280,9 +300,8 @@ class EncoderTrainGraph:
         + 8 split-K reductions + 14 transposes + 4 row sums + a GELU-backward launch."""
         sv = self._saved
         sp, p, pb = self.spec, self.prefix, sv["pb"]
-        w = self.layout.views(sv["flat"])
-        g_flat = torch.zeros_like(sv["flat"])
-        g = self.layout.views(g_flat)
+        w = self._views(sv["flat"])
+        g_flat, g = self._grad_arena(sv["flat"])
         d = sp.hidden
         dx = torch.zeros(pb.T, d, dtype=torch.float32, device=d_cls.device)
         ops.scatter_add_rows(d_cls.contiguous(), pb.cls_rows, dx)
@@ -353,7 +372,7 @@ class EncoderTrainGraph:
         else:
             ops.colsum(de, g[e + "token_type_embeddings.weight"][0])
         if ov is not None:
-            ov.contract("others", g_flat)  # embeddings (complete only now) and pooler
+            ov.contract("others", g_flat, d_emb=de)  # embeddings (complete only now) and pooler
         if side is not None:
             main.wait_stream(side)  # the gradient arena is complete for whatever the main stream runs next
         del keep
@@ -374,9 +393,8 @@ class EncoderTrainGraph:
         if self.mode == "f32" and _TILE:
             return self._backward_f32(d_cls)
         sp, p, pb = self.spec, self.prefix, sv["pb"]
-        w = self.layout.views(sv["flat"])
-        g_flat = torch.zeros_like(sv["flat"])
-        g = self.layout.views(g_flat)
+        w = self._views(sv["flat"])
+        g_flat, g = self._grad_arena(sv["flat"])
         d = sp.hidden
         dx = torch.zeros(pb.T, d, dtype=torch.float32, device=d_cls.device)
         ops.scatter_add_rows(d_cls.contiguous(), pb.cls_rows, dx)

@@ -34,7 +34,7 @@ class MergeOverlap:
     only the embedding range -- complete last -- is left at the end.  Same kernels on sub-ranges: the merged parameters are bit-identical;
     d alpha is the same sums grouped per range (ranges in arena order: deterministic)."""
 
-    def __init__(self, layout: ArenaLayout, stream: "torch.cuda.Stream"):
+    def __init__(self, layout: ArenaLayout, stream: "torch.cuda.Stream", word_key: Optional[str] = None, tok_word: Optional[torch.Tensor] = None):
         groups, seg_off, seg_gid = layout.group_segments()
         self.bounds = [int(v) for v in seg_off.tolist()]
         self.keys = [groups[g] for g in seg_gid]            # "others" (embeddings), "0", "1", ..., "others" (pooler)
@@ -43,6 +43,22 @@ class MergeOverlap:
         self.partials = [None] * len(self.keys)
         self.hold = []                                        # what the side stream reads, until the main stream has joined it
         self.tv = self.g_ptr = None
+        # The word-embedding table is a third (BLaIR-base) / an eighth (Recformer-large) of the parameters and a step reads ~600 of its
+        # 50,265 rows: with the batch's row list the table is merged and contracted in those rows only (``word``: range, rows, width, chunk).
+        self.word, self.tok_word = None, tok_word
+        if word_key is not None and tok_word is not None and word_key in layout.offsets and len(layout.shapes[word_key]) == 2:
+            w0, (V, d) = int(layout.offsets[word_key]), layout.shapes[word_key]
+            c = max(i for i in range(len(self.keys)) if self.bounds[i] <= w0)
+            if d % 4 == 0 and w0 % 4 == 0 and w0 + V * d <= self.bounds[c + 1]:
+                self.word = (w0, int(V), int(d), c)
+
+    def _dense_ranges(self, c: int):
+        """the arena ranges of chunk c that are streamed whole (everything but the word table when its rows are listed)"""
+        b, e = self.bounds[c], self.bounds[c + 1]
+        if self.word is None or self.word[3] != c:
+            return [(b, e)]
+        w0, V, d, _ = self.word
+        return [r for r in ((b, w0), (w0 + V * d, e)) if r[1] > r[0]]
 
     # ---- forward
     def merge(self, base, tv, alpha, seg_off, out):
@@ -52,8 +68,12 @@ class MergeOverlap:
         self.tv = tv
         with torch.cuda.stream(self.stream):
             for c in range(len(self.keys)):
-                b, e = self.bounds[c], self.bounds[c + 1]
-                ops.merge_nway(base, tv, alpha, seg_off, out=out, p_begin=b, p_count=e - b)
+                if self.word is not None and self.word[3] == c:   # the batch's rows of the word table (the other rows stay unwritten: nothing reads them)
+                    w0, V, d, _ = self.word
+                    a_row = alpha.view(-1, tv.shape[0])[c if seg_off is not None else 0]
+                    ops.merge_rows(base, tv, a_row, self.tok_word, V, d, w0, out)
+                for b, e in self._dense_ranges(c):
+                    ops.merge_nway(base, tv, alpha, seg_off, out=out, p_begin=b, p_count=e - b)
                 self.events[c] = torch.cuda.Event()
                 self.events[c].record(self.stream)
         return out
@@ -69,16 +89,30 @@ class MergeOverlap:
                     return
 
     # ---- backward
-    def contract(self, key: str, g_flat: torch.Tensor):
-        """d alpha of group ``key``'s range(s), on the side stream, ordered after everything issued so far on both streams"""
+    def contract(self, key: str, g_flat: torch.Tensor, d_emb: Optional[torch.Tensor] = None):
+        """d alpha of group ``key``'s range(s), on the side stream, ordered after everything issued so far on both streams.  ``d_emb`` (T, d):
+        d loss / d (embedding sum) per token -- the word table's share is then sum_t <tau_i[row(t)], d_emb[t]> over the batch's rows (what the
+        dense contraction of the scatter-added table gives, without streaming the table)."""
         main = torch.cuda.current_stream(g_flat.device)
         self.stream.wait_stream(main)
         self.g_ptr = g_flat.data_ptr()
         self.hold.append(g_flat)
         with torch.cuda.stream(self.stream):
             for c, k in enumerate(self.keys):
-                if k == key and self.partials[c] is None:
-                    self.partials[c] = ops.merge_bwd_alpha(self.tv, g_flat, p_begin=self.bounds[c], p_count=self.bounds[c + 1] - self.bounds[c])
+                if k != key or self.partials[c] is not None:
+                    continue
+                sparse = self.word is not None and self.word[3] == c and d_emb is not None
+                ranges = self._dense_ranges(c) if sparse else [(self.bounds[c], self.bounds[c + 1])]
+                parts = [ops.merge_bwd_alpha(self.tv, g_flat, p_begin=b, p_count=e - b) for b, e in ranges]
+                if sparse:
+                    w0, V, d, _ = self.word
+                    self.hold.append(d_emb)
+                    rows = torch.stack([ops.gather_rows(self.tv[i, w0:w0 + V * d].view(V, d), self.tok_word) for i in range(self.tv.shape[0])])
+                    parts.append(ops.merge_bwd_alpha(rows.view(rows.shape[0], -1), d_emb.reshape(-1)))
+                total = parts[0]
+                for q in parts[1:]:
+                    total = total + q
+                self.partials[c] = total
 
     def dalpha(self, g: torch.Tensor, n_segments: int) -> Optional[torch.Tensor]:
         """(S, N) from the per-range contractions, or None when they do not cover this gradient vector (the caller contracts in one launch)"""
@@ -227,11 +261,20 @@ class TaskVectorMergingModuleBase(nn.Module):
 
         mode = self.train_mode if self.model.spec.hidden % 128 == 0 else "f32"
         plan = None
+        pb = self.model.runner.pack(batch, self.base_model_tensor.device)
         if mode == "f32" and _ET._TILE and _ET._MERGE_OVERLAP:   # the tile graph knows the per-layer hooks; MR_TRAIN_MERGE_OVERLAP=0: one launch each
             if getattr(self, "_overlap_stream", None) is None:
                 self._overlap_stream = torch.cuda.Stream(device=self.base_model_tensor.device)
-            plan = MergeOverlap(self.layout, self._overlap_stream)
-        merged = self.merged_params(plan)
+            rows = _ET._SPARSE_WORD_ROWS
+            plan = MergeOverlap(self.layout, self._overlap_stream, self.model.runner.prefix + "embeddings.word_embeddings.weight" if rows else None,
+                                pb.tok_word if rows else None)
+        # the merged vector and the gradient arena of the step live in two persistent buffers of this module (their 200-odd named views
+        # are built once): every step writes both in full before reading them, on streams ordered behind the previous step's readers
+        cache = getattr(self, "_train_cache", None)
+        if cache is None:
+            pbuf, gbuf = torch.empty_like(self._merged), torch.empty_like(self._merged)
+            cache = self._train_cache = ((pbuf, self.layout.views(pbuf)), (gbuf, self.layout.views(gbuf)))
+        merged = self.merged_params(plan, out=cache[0][0].detach())
         sw = None
         if mode == "bf16x3":  # the merged weights are new every step: re-split them (and their transposes) from the merged arena
             sw = getattr(self, "_split_weights", None)
@@ -243,7 +286,7 @@ class TaskVectorMergingModuleBase(nn.Module):
         graph = RobertaTrainGraph(self.model.spec, self.layout, prefix=self.model.runner.prefix, mode=mode, split_weights=sw,
                                   dropout=self.model.next_dropout(training=self.training))
         graph.overlap = plan
-        pb = self.model.runner.pack(batch, self.base_model_tensor.device)
+        graph.param_cache, graph.grad_cache = cache
         return encode_with_grad(graph, merged, pb)
 
     # -- merge -----------------------------------------------------------------------------------
@@ -279,12 +322,12 @@ class TaskVectorMergingModuleBase(nn.Module):
         parallel.sharded_merge(merge_slice, arena, self.slice_plan, self._scratch)
         return arena[: self.layout.padded_numel]
 
-    def merged_params(self, plan: Optional[MergeOverlap] = None) -> torch.Tensor:
+    def merged_params(self, plan: Optional[MergeOverlap] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Differentiable merge: returns the merged arena vector with an autograd edge back to
         global_weights / global_biases / per_weights (the backward runs the HIP alpha-gradient kernel).  With ``plan`` the vector is
         written range by range on the plan's stream: its consumer waits per range (``MergeOverlap.wait``)."""
         return _MergeFunction.apply(self.effective_alpha(), self.base_model_tensor.data, self.task_vectors_tensor.data,
-                                    self._seg_off, torch.empty_like(self._merged), plan)
+                                    self._seg_off, torch.empty_like(self._merged) if out is None else out, plan)
 
     # -- pipelined re-merge (evaluation loops that re-merge per step, as the reference does on every forward) ---------------------------
     def pipeline_merges(self, on: bool = True):

@@ -60,3 +60,13 @@ class BatchDistillationSequence(ToDeviceMixin):  # model_batch.py:62-66
     dataset_indexes: list
     sequence_ids: list
     sequence: Any
+
+    host_sequence_ids = None  # ``sequence_ids`` as it was in host memory before ``.to(device)`` (a tensor there): the loss groups the batch by
+    # dataset on the host, and reading the ids back from the device would stall the host behind the whole encoder forward
+
+    def to(self, device):
+        moved = super().to(device)
+        ids = self.sequence_ids
+        moved.host_sequence_ids = self.host_sequence_ids if self.host_sequence_ids is not None else (
+            ids if isinstance(ids, torch.Tensor) and not ids.is_cuda else None)
+        return moved

@@ -80,7 +80,7 @@ class _BatchedLossFn(torch.autograd.Function):
             row_m[off:off + n] = M
             ops.skinny_scores(reps_c[off:off + n], module._items[d_i], out=z[off:off + n, :M])
             ops.gather_rows(module.score_embeddings[d_i], sid_dev[off:off + n], out=t[off:off + n, :M])
-        row_m_dev = row_m.to(dev, non_blocking=True)
+        row_m_dev = ops.h2d(row_m, dev)
         need_grad = reps_sorted.requires_grad
         dz = torch.empty(B, ld, dtype=torch.float32, device=dev) if need_grad else None
         rows, _ = ops.distill_loss_rows(z[:, :m_max], t[:, :m_max], grad_scale=1.0 / batch_size, dz=None if dz is None else dz[:, :m_max], row_M=row_m_dev,
@@ -163,7 +163,7 @@ class DistillSequenceModule(nn.Module):
         # group the batch by dataset on the host, ship ONE index tensor (row permutation | teacher row ids) to the device
         perm = torch.argsort(ds, stable=True)
         counts = torch.bincount(ds, minlength=len(self._items)).tolist()
-        idx_dev = torch.cat([perm, sid[perm]]).to(torch.int32).to(self.device, non_blocking=True)
+        idx_dev = ops.h2d(torch.cat([perm, sid[perm]]).to(torch.int32), self.device)
         perm_dev, sid_dev = idx_dev[:B], idx_dev[B:]
         reps_sorted = representations.index_select(0, perm_dev.long())
         groups = [(d_i, off0, n) for d_i, n, off0 in zip(range(len(counts)), counts, [sum(counts[:i]) for i in range(len(counts))]) if n]
@@ -180,7 +180,8 @@ class DistillSequenceModule(nn.Module):
 
     def _forward_distill(self, batch: BatchDistillationSequence):
         reps = self._forward_sequence_encoding(batch.sequence)
-        return self.distill_loss(reps, batch.dataset_indexes, batch.sequence_ids)
+        ids = getattr(batch, "host_sequence_ids", None)
+        return self.distill_loss(reps, batch.dataset_indexes, batch.sequence_ids if ids is None else ids)
 
     def log(self, name, value, **kwargs):
         self.logged[name] = float(value.detach()) if isinstance(value, torch.Tensor) else float(value)

@@ -81,6 +81,17 @@ def _dev(t: torch.Tensor, name: str, dtype=None):
     return t
 
 
+def h2d(t: torch.Tensor, device) -> torch.Tensor:
+    """A small host tensor to the device WITHOUT stalling the host: staged through pinned memory (torch's caching host allocator, which
+    keeps the block until the copy has run), so the copy is one more stream-ordered command.  From pageable memory the same call blocks
+    the host until everything queued before it has finished -- once per batch that drains the launch queue the host had built up."""
+    if t.is_cuda:
+        return t.to(device)
+    p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    p.copy_(t)
+    return p.to(device, non_blocking=True)
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the handle without building a torch.cuda.Stream object per launch
 
 
@@ -140,6 +151,20 @@ def merge_nway(
         "mr_merge_nway_f32",
     )
     PROF.end(ev, base.device, "merge_nway", nbytes=(N + 2) * p_count * 4)
+    return out
+
+
+def merge_rows(base: torch.Tensor, tv: torch.Tensor, alpha_row: torch.Tensor, idx: torch.Tensor, rows: int, d: int, table_off: int,
+               out: torch.Tensor) -> torch.Tensor:
+    """out[table_off + r d + c] = base[..] + sum_i alpha_row[i] tv[i, ..] for the rows r = idx[t] of the (rows, d) table at arena offset
+    ``table_off`` -- the same operations per element as ``merge_nway`` (bit-identical rows); the rest of ``out`` is not touched."""
+    _dev(base, "base", torch.float32), _dev(tv, "tv", torch.float32), _dev(alpha_row, "alpha_row", torch.float32), _dev(idx, "idx", torch.int32)
+    _dev(out, "out", torch.float32)
+    N, P = tv.shape
+    if alpha_row.numel() != N or table_off < 0 or table_off + rows * d > min(P, base.numel(), out.numel()):
+        raise ValueError("alpha_row must hold N coefficients and the table must lie inside the vectors")
+    check(_lib.load().mr_merge_rows_f32(ptr(base), ptr(tv), tv.stride(0), ptr(alpha_row), N, ptr(idx), idx.numel(), rows, d, table_off, ptr(out),
+                                        _stream(base)), "mr_merge_rows_f32")
     return out
 
 

@@ -742,3 +742,30 @@ def test_gemm_tile_bf16x6_is_fp32_grade_over_the_whole_range(ops, bn, ta, tb, M,
     assert err <= 2.0 ** -21, err    # per element: relative to sum_k |a||b| (fp32 accumulation over K terms included)
     if cs is not None:
         assert torch.allclose(cs.cpu().double(), Aop.double().sum(1), rtol=1e-5, atol=1e-5 * float(Aop.abs().sum(1).max()))
+
+
+def test_merge_rows_writes_the_listed_rows_with_the_bits_of_the_whole_merge(ops):
+    """mr_merge_rows_f32: the rows of one table inside the arena, element for element the operations of mr_merge_nway_f32 (bit-identical),
+    duplicates in the list harmless, every other element of the output untouched, out-of-table ids skipped"""
+    g = torch.Generator().manual_seed(5)
+    N, V, d, off = 8, 300, 64, 128
+    P = off + V * d + 256
+    base, tv = torch.randn(P, generator=g), torch.randn(N, P, generator=g)
+    alpha = torch.randn(N, generator=g)
+    whole = ops.merge_nway(base.to(DEV), tv.to(DEV), alpha.to(DEV))
+    idx = torch.tensor([7, 0, 299, 7, 150, 151, 7, 42], dtype=torch.int32)
+    out = torch.full((P,), 123.0, device=DEV)
+    ops.merge_rows(base.to(DEV), tv.to(DEV), alpha.to(DEV), idx.to(DEV), V, d, off, out)
+    touched = torch.zeros(P, dtype=torch.bool)
+    for r in idx.tolist():
+        touched[off + r * d: off + (r + 1) * d] = True
+    assert torch.equal(out.cpu()[touched], whole.cpu()[touched])
+    assert bool((out.cpu()[~touched] == 123.0).all())
+    out2 = torch.full((P,), 5.0, device=DEV)
+    ops.merge_rows(base.to(DEV), tv.to(DEV), alpha.to(DEV), torch.tensor([-1, V, 3], dtype=torch.int32, device=DEV), V, d, off, out2)
+    t3 = torch.zeros(P, dtype=torch.bool); t3[off + 3 * d: off + 4 * d] = True
+    assert torch.equal(out2.cpu()[t3], whole.cpu()[t3]) and bool((out2.cpu()[~t3] == 5.0).all())
+    with pytest.raises(ValueError):
+        ops.merge_rows(base.to(DEV), tv.to(DEV), alpha.to(DEV)[:3].contiguous(), idx.to(DEV), V, d, off, out)
+    with pytest.raises(ValueError):
+        ops.merge_rows(base.to(DEV), tv.to(DEV), alpha.to(DEV), idx.to(DEV), V, d, P - 64, out)

@@ -69,11 +69,13 @@ K = int(os.environ.get("TB_STEPS", 20))
 t0 = time.perf_counter()
 for _ in range(K):
     loss = step()
+host_ms = (time.perf_counter() - t0) * 1e3 / K   # the host thread's own time per step (launches, no wait): level with `ms` = host-bound
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 1e3 / K
 P = mm.layout.numel
 print(f"{MODEL} {learn} [{mm.train_mode}]: N={N} domains, B={B} sequences ({int(lens.sum())} tokens), P={P/1e6:.1f} M parameters, M={M}: {ms:.2f} ms/step "
       f"({1e3/ms:.1f} steps/s, {B*1e3/ms:.0f} sequences/s); loss {loss.item():.4f}")
+print(f"  host thread: {host_ms:.2f} ms per step issuing the launches (device-bound when well below the step time)")
 print(f"  parameter-sized streams per step: merge fwd {(N+2)*P*4/1e9:.2f} GB + alpha-gradient {(N+1)*P*4/1e9:.2f} GB "
       f"-> {((2*N+3)*P*4/1e9)/(ms/1e3)/1e3:.2f} TB/s of the step if nothing else moved")
 if os.environ.get("TB_HOSTPROF", "0") == "1":  # where the host thread spends a step (cProfile inflates Python frames; read the shares)
