@@ -101,6 +101,23 @@ class _BatchedLossFn(torch.autograd.Function):
         return d_reps * grad_out, None, None, None, None, None
 
 
+class _LazyLog(dict):
+    """name -> last logged value; device tensors are converted to float when READ (one synchronisation, at the reader's time)"""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        return float(v) if isinstance(v, torch.Tensor) else v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
 class DistillSequenceModule(nn.Module):
     def __init__(self, merged_model, score_embeddings: List[torch.Tensor], loss_fn: DistillLossBase, similarity: Literal["dot", "cosine"],
                  learning_rate: float = 5e-5, trainable_args_kwargs: Optional[dict] = None, device=None):
@@ -117,7 +134,7 @@ class DistillSequenceModule(nn.Module):
         self._items: Optional[List[torch.Tensor]] = None
         self._items_t: Optional[List[torch.Tensor]] = None
         self._valid_metrics: list = []
-        self.logged: dict = {}
+        self.logged: dict = _LazyLog()
 
     # -- item embeddings (set by the item-encoding callback in the reference) -------------------------
     @property
@@ -184,7 +201,9 @@ class DistillSequenceModule(nn.Module):
         return self.distill_loss(reps, batch.dataset_indexes, batch.sequence_ids if ids is None else ids)
 
     def log(self, name, value, **kwargs):
-        self.logged[name] = float(value.detach()) if isinstance(value, torch.Tensor) else float(value)
+        # the tensor, not its value: ``float()`` here would stall the host behind the whole encoder forward in every training step (Lightning's
+        # ``self.log`` does not synchronise either); ``logged[name]`` converts when somebody reads it
+        self.logged[name] = value.detach() if isinstance(value, torch.Tensor) else float(value)
 
     def training_step(self, batch: BatchDistillationSequence, batch_idx: int):
         loss = self._forward_distill(batch)

@@ -82,12 +82,13 @@ if os.environ.get("TB_HOSTPROF", "0") == "1":  # where the host thread spends a 
     import cProfile, pstats
 
     pr = cProfile.Profile()
-    pr.enable()
-    for _ in range(K):
-        step()
-    torch.cuda.synchronize()
-    pr.disable()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+    with torch.autograd.set_multithreading_enabled(False):  # the backward's launches in THIS thread, so that the profile sees them
+        pr.enable()
+        for _ in range(K):
+            step()
+        torch.cuda.synchronize()
+        pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(int(os.environ.get("TB_HOSTROWS", 28)))
 
 if os.environ.get("TB_CPU", "0") == "1" and not REC:
     # the same step through the CPU oracle (merge + encoder + loss restatements) with torch autograd, 16 threads
