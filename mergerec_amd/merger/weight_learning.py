@@ -249,7 +249,13 @@ class TaskVectorMergingModuleBase(nn.Module):
         """Deferred input-contract check of the wrapped encoder (``BaseEncoderModel.check_inputs``): raises ``engine.InputError``."""
         self.model.check_inputs()
 
-    train_mode = "f32"  # "bf16x3": split-precision MFMA products in the training graph (DistillTrainer sets it for bf16-mixed / 16-mixed)
+    # arithmetic of the training graph's products: "f32" exact-fp32 MFMA on the token-sized tile kernel; "bf16x3" split-precision MFMA on the
+    # library's 256-wide tiles (the weights are re-split every step); "auto" = by the batch's token count -- the tile kernel below
+    # AUTO_SPLIT_TOKENS tokens, the split graph from there on (measured at BLaIR-base x 8: 602 tokens 8.4 vs 11.5 ms, 1,202 tokens 12.5 vs
+    # 12.6, 1,859 tokens 17.7 vs 14.0, 4,782 tokens 39.9 vs 20.5).  DistillTrainer sets "auto" for the reduced-precision flags
+    # (bf16-mixed, the reference's default, 16-mixed, ...) and "f32" for 32-true.
+    train_mode = "f32"
+    AUTO_SPLIT_TOKENS = 1280
 
     def forward_with_grad(self, batch):
         from ..engine_train import RobertaTrainGraph, SplitWeights, encode_with_grad
@@ -259,9 +265,13 @@ class TaskVectorMergingModuleBase(nn.Module):
                                "each of them): build the module with placement='replicated' (merge_train.py does)")
         from .. import engine_train as _ET
 
-        mode = self.train_mode if self.model.spec.hidden % 128 == 0 else "f32"
-        plan = None
         pb = self.model.runner.pack(batch, self.base_model_tensor.device)
+        mode = self.train_mode
+        if mode == "auto":
+            mode = "bf16x3" if pb.T >= self.AUTO_SPLIT_TOKENS else "f32"
+        if self.model.spec.hidden % 128:
+            mode = "f32"
+        plan = None
         if mode == "f32" and _ET._TILE and _ET._MERGE_OVERLAP:   # the tile graph knows the per-layer hooks; MR_TRAIN_MERGE_OVERLAP=0: one launch each
             if getattr(self, "_overlap_stream", None) is None:
                 self._overlap_stream = torch.cuda.Stream(device=self.base_model_tensor.device)

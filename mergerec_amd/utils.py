@@ -187,11 +187,12 @@ class DistillTrainer:
 
     def __init__(self, max_epochs: Optional[int] = None, max_steps: Optional[int] = None, callbacks: Sequence = (), precision: str = "32-true",
                  coalesce_tokens: int = 65536, log_every_n_steps: int = 1, verbose: bool = True):
-        # Every Lightning precision string is accepted; the training graph keeps exact-fp32 products: a step is 16 short pseudo-user
-        # sequences (~600 tokens) against freshly merged weights, so re-splitting the weights for the bf16x3 graph costs what its faster
-        # products save (measured 19.9 vs 19.6 ms at BLaIR-base, 46.4 vs 42.9 ms at Recformer-large; ``merged_model.train_mode`` selects it)
-        precision_to_gemm_mode(precision)  # validates the string
-        self.train_mode = "f32"
+        # Every Lightning precision string is accepted.  "32-true": exact-fp32 products.  The reduced-precision flags (the reference's default
+        # bf16-mixed, 16-mixed, ...): by the batch's token count -- the recipe's step is 16 short pseudo-user sequences (~600 tokens) against
+        # freshly merged weights, where re-splitting the weights for the bf16x3 graph costs more than its faster products save (8.4 vs 11.5 ms
+        # at BLaIR-base x 8), so it stays on the exact-fp32 tile kernel; from ~1,300 tokens per step on the split graph wins (4,782 tokens:
+        # 20.5 vs 39.9 ms) and is taken (``TaskVectorMergingModuleBase.train_mode = "auto"``)
+        self.train_mode = "f32" if precision_to_gemm_mode(precision) is None else "auto"
         if max_epochs is None and (max_steps is None or max_steps < 0):
             raise ValueError("max_steps or max_epochs is required")
         self.max_epochs, self.max_steps, self.callbacks = max_epochs, max_steps, list(callbacks)

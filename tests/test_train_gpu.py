@@ -890,3 +890,49 @@ def test_merge_and_alpha_gradient_in_arena_ranges_on_the_second_stream_match_the
         assert l1 == l0
         for k in g0:
             assert torch.allclose(g1[k], g0[k], rtol=1e-5, atol=1e-6 * float(g0[k].abs().max())), (k, g1[k], g0[k])
+
+
+def test_auto_train_mode_picks_the_graph_by_token_count(monkeypatch):
+    """train_mode = "auto" (what DistillTrainer sets under the reduced-precision flags): the exact-fp32 tile graph below AUTO_SPLIT_TOKENS tokens
+    per step -- bit for bit the "f32" step --, the bf16x3 split graph from there on -- the "bf16x3" step bit for bit, within 5e-3 of the exact one"""
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from mergerec_amd.model_batch import BatchDistillationSequence
+    from mergerec_amd.module import DistillSequenceModule
+    from mergerec_amd.module.loss_fn import SinglePseudoLabelKDLoss
+    from mergerec_amd.utils import DistillTrainer
+    from tests.test_path_gpu import _tiny_model
+
+    assert DistillTrainer(max_steps=1, precision="bf16-mixed", verbose=False).train_mode == "auto"
+    assert DistillTrainer(max_steps=1, precision="32-true", verbose=False).train_mode == "f32"
+    g2 = load_golden("g2_merger.pt")
+    cfgd, ids, mask = g2["cfg"], g2["input_ids"], g2["attention_mask"]
+    B = ids.shape[0]
+    gen = torch.Generator().manual_seed(9)
+    items = [torch.nn.functional.normalize(torch.randn(m, cfgd["hidden"], generator=gen), dim=-1) for m in (50, 77)]
+    teachers = [torch.randn(B, m, generator=gen).clamp(-1, 1) for m in (50, 77)]
+    batch = BatchDistillationSequence(dataset_indexes=[i % 2 for i in range(B)], sequence_ids=torch.arange(B),
+                                      sequence={"input_ids": ids, "attention_mask": mask}).to(DEV)
+
+    def step(mode, threshold=None):
+        mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, _tiny_model(cfgd), g2["pretrain"], [dict(f) for f in g2["finetunes"]], set(),
+                                 disable_softmax=True, initial_per_weight=0.3)
+        mm.train_mode = mode
+        if threshold is not None:
+            mm.AUTO_SPLIT_TOKENS = threshold
+        mod = DistillSequenceModule(mm, teachers, SinglePseudoLabelKDLoss(0.05, 1000.0), "cosine",
+                                    trainable_args_kwargs={"freeze_global_weight": True, "freeze_global_bias": True})
+        mod.item_embeddings = items
+        mod.eval()
+        with torch.enable_grad():
+            loss = mod.training_step(batch, 0)
+        loss.backward()
+        return float(loss.detach()), mm.per_weights["all"].grad.clone()
+
+    l_f32, g_f32 = step("f32")
+    l_lo, g_lo = step("auto", threshold=10 ** 9)
+    assert l_lo == l_f32 and torch.allclose(g_lo, g_f32, rtol=1e-5, atol=0)
+    if cfgd["hidden"] % 128 == 0:
+        l_sp, g_sp = step("bf16x3")
+        l_hi, g_hi = step("auto", threshold=1)
+        assert l_hi == l_sp and torch.equal(g_hi, g_sp)
+        assert float((g_hi - g_f32).abs().max()) <= 5e-3 * float(g_f32.abs().max())
