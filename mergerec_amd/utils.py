@@ -190,7 +190,7 @@ class DistillTrainer:
         # Every Lightning precision string is accepted.  "32-true": exact-fp32 products.  The reduced-precision flags (the reference's default
         # bf16-mixed, 16-mixed, ...): by the batch's token count -- the recipe's step is 16 short pseudo-user sequences (~600 tokens) against
         # freshly merged weights, where re-splitting the weights for the bf16x3 graph costs more than its faster products save (8.4 vs 11.5 ms
-        # at BLaIR-base x 8), so it stays on the exact-fp32 tile kernel; from ~1,300 tokens per step on the split graph wins (4,782 tokens:
+        # at BLaIR-base x 8), so it stays on the exact-fp32 tile kernel; from ~1,100 tokens per step on the split graph wins (4,782 tokens:
         # 20.5 vs 39.9 ms) and is taken (``TaskVectorMergingModuleBase.train_mode = "auto"``)
         self.train_mode = "f32" if precision_to_gemm_mode(precision) is None else "auto"
         if max_epochs is None and (max_steps is None or max_steps < 0):
