@@ -9,7 +9,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kVPT = 2;  // float4 per thread per chunk
+constexpr int kVPT = 4;  // float4 per thread per chunk and stream: (N + 1) x 4 16-byte loads in flight per thread (r04: 2 -> 4, +5 %)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ld4_nt(const float* p) {
@@ -19,6 +19,13 @@ __device__ __forceinline__ float4 ld4_nt(const float* p) {
     v.z = __builtin_nontemporal_load(p + 2);
     v.w = __builtin_nontemporal_load(p + 3);
     return v;
+}
+
+__device__ __forceinline__ void st4_nt(float* p, const float4 v) {
+    __builtin_nontemporal_store(v.x, p);
+    __builtin_nontemporal_store(v.y, p + 1);
+    __builtin_nontemporal_store(v.z, p + 2);
+    __builtin_nontemporal_store(v.w, p + 3);
 }
 
 template <int N, bool SEG>
@@ -59,9 +66,9 @@ __global__ __launch_bounds__(kThreads) void merge_nway_kernel(const float* __res
             const int64_t v = v0 + (int64_t)u * kThreads + threadIdx.x;
             p[u] = (v < nvec) ? p_begin + v * 4 : -1;
             if (p[u] >= 0) {
-                b[u] = ld4(base + p[u]);
+                b[u] = ld4_nt(base + p[u]);  // every operand is read once and the result written once: non-temporal both ways (r04: +9 %)
 #pragma unroll
-                for (int i = 0; i < N; ++i) t[u][i] = ld4(tv + (int64_t)i * tv_stride + p[u]);
+                for (int i = 0; i < N; ++i) t[u][i] = ld4_nt(tv + (int64_t)i * tv_stride + p[u]);
             }
         }
 #pragma unroll
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(kThreads) void merge_nway_kernel(const float* __res
             o.y = __fadd_rn(b[u].y, acc.y);
             o.z = __fadd_rn(b[u].z, acc.z);
             o.w = __fadd_rn(b[u].w, acc.w);
-            *reinterpret_cast<float4*>(out + p[u]) = o;
+            st4_nt(out + p[u], o);
         }
     }
 }
