@@ -164,7 +164,9 @@ int mr_pack_tokens(const int64_t* input_ids, const int64_t* attention_mask, cons
  * Checked: ids in [0, vocab); position 0 attended (CLS pooling reads it, encoder/_base.py:45); token_type_ids / item_position_ids
  * of attended tokens inside their tables; global_attention_mask (may be NULL) == 1 at position 0 and 0 elsewhere (the only
  * pattern the reference's collators emit, utils/recformer_utils.py:51,59); per-row mask count == cu_seqlens span.
- * err_bits == NULL: no checks (== mr_pack_tokens).  The embedding gather clamps indices, so bad ids never fault.
+ * err_bits == NULL: no checks (== mr_pack_tokens).  With vocab / n_type / n_ip > 0 the indices WRITTEN to tok_word / tok_tt / tok_ip are
+ * clamped into their tables (the flag reports the original value): every consumer -- the embedding gather, the training graph's row
+ * gathers and scatter-adds, mr_merge_rows_f32 -- then addresses a real row, so bad ids never fault.
  * replaces: the index errors torch raises inside nn.Embedding for the same inputs (recformer/models.py:121-131). */
 #define MR_IN_BAD_ID 1
 #define MR_IN_NO_CLS 2

@@ -49,10 +49,12 @@ __global__ __launch_bounds__(MR_WAVE) void pack_tokens_kernel(const int64_t* __r
             }
             if (t < t1) {  // cu_seqlens is caller data: never write past this row's slot
                 const int incl = run_pos + __popcll(bnp & lt) + 1;
-                tok_word[t] = (int32_t)id;
+                // what is stored is always a row of its table (the flag above reports the original value): the inference gathers clamp
+                // again, the training graph's row gathers / scatter-adds and the row-sparse merge take these as they are
+                tok_word[t] = (int32_t)(vocab > 0 ? (id < 0 ? 0 : (id >= (int64_t)vocab ? (int64_t)vocab - 1 : id)) : id);
                 tok_pos[t] = nonpad ? incl + pad_id : pad_id;
-                if (tok_tt) tok_tt[t] = (int32_t)ttv;
-                if (tok_ip) tok_ip[t] = (int32_t)ipv;
+                if (tok_tt) tok_tt[t] = (int32_t)(n_type > 0 ? (ttv < 0 ? 0 : (ttv >= (int64_t)n_type ? (int64_t)n_type - 1 : ttv)) : ttv);
+                if (tok_ip) tok_ip[t] = (int32_t)(n_ip > 0 ? (ipv < 0 ? 0 : (ipv >= (int64_t)n_ip ? (int64_t)n_ip - 1 : ipv)) : ipv);
             }
         }
         run_pos += __popcll(bnp);

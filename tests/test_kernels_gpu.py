@@ -769,3 +769,19 @@ def test_merge_rows_writes_the_listed_rows_with_the_bits_of_the_whole_merge(ops)
         ops.merge_rows(base.to(DEV), tv.to(DEV), alpha.to(DEV)[:3].contiguous(), idx.to(DEV), V, d, off, out)
     with pytest.raises(ValueError):
         ops.merge_rows(base.to(DEV), tv.to(DEV), alpha.to(DEV), idx.to(DEV), V, d, P - 64, out)
+
+
+def test_pack_tokens_stores_clamped_indices_and_flags_the_original(ops):
+    """the packed index arrays always address a row of their table (what the training graph's gathers / scatter-adds and the row-sparse merge
+    read without clamping); the error word still reports the out-of-range original"""
+    ids = torch.tensor([[0, 7, 60000, 2, 1], [0, -3, 5, 2, 1]], dtype=torch.int64)
+    mask = torch.tensor([[1, 1, 1, 1, 0], [1, 1, 1, 1, 0]], dtype=torch.int64)
+    tt = torch.tensor([[0, 1, 9, 2, 3], [0, 1, 2, 2, 3]], dtype=torch.int64)
+    ip = torch.tensor([[0, 1, 1, 99, 0], [0, 1, 1, 1, 0]], dtype=torch.int64)
+    cu = torch.tensor([0, 4, 8], dtype=torch.int32)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    tw, tp, ttp, tip = ops.pack_tokens(ids.to(DEV), mask.to(DEV), cu.to(DEV), 8, 1, tt.to(DEV), ip.to(DEV), None, err, vocab=50265, n_type=4, n_ip=51)
+    assert tw.cpu().tolist() == [0, 7, 50264, 2, 0, 0, 5, 2]
+    assert ttp.cpu().tolist() == [0, 1, 3, 2, 0, 1, 2, 2] and tip.cpu().tolist() == [0, 1, 1, 50, 0, 1, 1, 1]
+    bits = int(err.item())
+    assert bits & 1 and bits & 4 and bits & 8  # MR_IN_BAD_ID | MR_IN_BAD_TOKEN_TYPE | MR_IN_BAD_ITEM_POS
