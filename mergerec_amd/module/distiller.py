@@ -178,6 +178,14 @@ class DistillSequenceModule(nn.Module):
         ds = torch.as_tensor(list(dataset_indexes), dtype=torch.int64)
         sid = sequence_ids.detach().to("cpu", torch.int64) if isinstance(sequence_ids, torch.Tensor) else torch.as_tensor(list(sequence_ids), dtype=torch.int64)
         # group the batch by dataset on the host, ship ONE index tensor (row permutation | teacher row ids) to the device
+        if ds.numel() != B or sid.numel() != B:
+            raise ValueError("dataset_indexes / sequence_ids must hold one entry per representation row")
+        if B and (int(ds.min()) < 0 or int(ds.max()) >= len(self._items)):
+            raise IndexError(f"dataset index out of range (have {len(self._items)} item matrices)")  # upstream: list index error at module.py:66
+        rows_of = torch.tensor([t.shape[0] for t in self.score_embeddings], dtype=torch.int64)
+        if B and (int(sid.min()) < 0 or bool((sid >= rows_of[ds]).any())):
+            # upstream indexes the teacher matrix with the id (module.py:68) and torch raises; the row-gather kernel would read past the matrix
+            raise IndexError("sequence id outside its dataset's teacher-score matrix")
         perm = torch.argsort(ds, stable=True)
         counts = torch.bincount(ds, minlength=len(self._items)).tolist()
         idx_dev = ops.h2d(torch.cat([perm, sid[perm]]).to(torch.int32), self.device)

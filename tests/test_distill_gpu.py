@@ -148,6 +148,16 @@ def test_distill_module_matches_reference_loop_and_rep_gradient(batched, monkeyp
     mod.on_validation_epoch_end()
     assert abs(v.item() - loss.item()) <= 1e-6 * abs(loss.item())
     assert "val/average_loss_epoch" in mod.logged
+    # ids outside their tables raise on the host (upstream: torch's IndexError at module.py:66,68) instead of reaching the row-gather kernel
+    n_rows = [t.shape[0] for t in f["score_embeddings"]]
+    bad_sid = list(f["sequence_ids"]) if not isinstance(f["sequence_ids"], torch.Tensor) else f["sequence_ids"].clone()
+    bad_sid[3] = n_rows[int(f["dataset_indexes"][3])]
+    with pytest.raises(IndexError, match="teacher-score"):
+        mod(BatchDistillationSequence(dataset_indexes=f["dataset_indexes"], sequence_ids=bad_sid, sequence=torch.arange(16, device=DEV)))
+    bad_ds = list(f["dataset_indexes"])
+    bad_ds[0] = len(n_rows)
+    with pytest.raises(IndexError, match="dataset index"):
+        mod(BatchDistillationSequence(dataset_indexes=bad_ds, sequence_ids=f["sequence_ids"], sequence=torch.arange(16, device=DEV)))
 
 
 def test_alpha_file_round_trip(tmp_path):
