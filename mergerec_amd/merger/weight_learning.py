@@ -11,6 +11,7 @@ mr_task_vector_f32 / mr_merge_nway_f32 on device-resident arena buffers (mergere
 from __future__ import annotations
 
 from collections import OrderedDict
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -280,11 +281,19 @@ class TaskVectorMergingModuleBase(nn.Module):
                                 pb.tok_word if rows else None)
         # the merged vector and the gradient arena of the step live in two persistent buffers of this module (their 200-odd named views
         # are built once): every step writes both in full before reading them, on streams ordered behind the previous step's readers
-        cache = getattr(self, "_train_cache", None)
-        if cache is None:
-            pbuf, gbuf = torch.empty_like(self._merged), torch.empty_like(self._merged)
-            cache = self._train_cache = ((pbuf, self.layout.views(pbuf)), (gbuf, self.layout.views(gbuf)))
-        merged = self.merged_params(plan, out=cache[0][0].detach())
+        prev = getattr(self, "_train_graph", None)
+        prev = prev() if prev is not None else None   # weak: a graph that was dropped without a backward frees the buffers again
+        if prev is not None and prev._saved is not None:
+            # a second differentiable forward before the first one's backward (two views of a batch, accumulated micro-batches, ...): the
+            # first graph still reads the persistent buffers -- this call gets vectors of its own
+            cache = (None, None)
+            merged = self.merged_params(plan)
+        else:
+            cache = getattr(self, "_train_cache", None)
+            if cache is None:
+                pbuf, gbuf = torch.empty_like(self._merged), torch.empty_like(self._merged)
+                cache = self._train_cache = ((pbuf, self.layout.views(pbuf)), (gbuf, self.layout.views(gbuf)))
+            merged = self.merged_params(plan, out=cache[0][0].detach())
         sw = None
         if mode == "bf16x3":  # the merged weights are new every step: re-split them (and their transposes) from the merged arena
             sw = getattr(self, "_split_weights", None)
@@ -297,6 +306,8 @@ class TaskVectorMergingModuleBase(nn.Module):
                                   dropout=self.model.next_dropout(training=self.training))
         graph.overlap = plan
         graph.param_cache, graph.grad_cache = cache
+        if cache[0] is not None:
+            self._train_graph = weakref.ref(graph)
         return encode_with_grad(graph, merged, pb)
 
     # -- merge -----------------------------------------------------------------------------------

@@ -936,3 +936,37 @@ def test_auto_train_mode_picks_the_graph_by_token_count(monkeypatch):
         l_hi, g_hi = step("auto", threshold=1)
         assert l_hi == l_sp and torch.equal(g_hi, g_sp)
         assert float((g_hi - g_f32).abs().max()) <= 5e-3 * float(g_f32.abs().max())
+
+
+def test_two_differentiable_forwards_before_one_backward_keep_their_own_parameters():
+    """the merging module's persistent step buffers serve one graph at a time: a second forward_with_grad before the first one's backward gets
+    vectors of its own, so both backwards see the parameters (and write the gradients) of their own forward"""
+    from mergerec_amd.merger import LearnType, MergeType, load_merging_module
+    from tests.test_path_gpu import _tiny_model
+
+    g2 = load_golden("g2_merger.pt")
+    cfgd, ids, mask = g2["cfg"], g2["input_ids"], g2["attention_mask"]
+    a = {"input_ids": ids[:3].to(DEV), "attention_mask": mask[:3].to(DEV)}
+    b = {"input_ids": ids[3:].to(DEV), "attention_mask": mask[3:].to(DEV)}
+
+    def fresh():
+        mm = load_merging_module(MergeType.TASK_VECTOR, LearnType.TASK_WISE, _tiny_model(cfgd), g2["pretrain"], [dict(f) for f in g2["finetunes"]], set(),
+                                 disable_softmax=True, initial_per_weight=0.3)
+        mm.eval()
+        return mm
+
+    def grad_of(mm, loss):
+        mm.per_weights["all"].grad = None
+        loss.backward()
+        return mm.per_weights["all"].grad.clone()
+
+    mm = fresh()
+    with torch.enable_grad():
+        ga = grad_of(mm, mm.forward_with_grad(a).square().sum())
+        gb = grad_of(mm, mm.forward_with_grad(b).square().sum())
+        # both graphs alive, backward in either order
+        oa, ob = mm.forward_with_grad(a), mm.forward_with_grad(b)
+        assert torch.equal(grad_of(mm, ob.square().sum()), gb)
+        assert torch.equal(grad_of(mm, oa.square().sum()), ga)
+        # and the persistent buffers are taken up again afterwards
+        assert torch.equal(grad_of(mm, mm.forward_with_grad(a).square().sum()), ga)
