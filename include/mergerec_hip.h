@@ -304,6 +304,14 @@ int mr_attn_global_row_f32(const float* qg, const float* kvg, const int32_t* cu_
 int mr_cls_pool_normalize_f32(const float* x, int64_t ldx, const int32_t* cu_seqlens, int B, int d, int normalize,
                               float* out, mr_stream_t stream);
 
+/* pooling_method = "mean" (encoder/_base.py:42-43): out[b] = mean over the PADDED batch width of the last hidden state, pad positions
+ * included, as ``outputs.last_hidden_state.mean(dim=1)`` computes it on the reference's padded (B, L, d) tensor:
+ * (sum of sequence b's packed token rows + (pad_len[b] - len_b) * xpad[b]) / pad_len[b], optionally L2-normalised (module.py:74-77).
+ * xpad (B, d): the hidden state shared by every pad position of sequence b (a pad token attends to the sequence's valid keys and is no key
+ * itself, so one extra query row per sequence reproduces them); pad_len (int32, B): the padded width of the batch the sequence came in. */
+int mr_mean_pool_f32(const float* x, int64_t ldx, const int32_t* cu_seqlens, const float* xpad, const int32_t* pad_len, int B, int d,
+                     int normalize, float* out, mr_stream_t stream);
+
 /* Gather rows x[row_idx[i], :] -> out[i, :] (the last layer's dense blocks run on CLS rows only; teacher rows
  * S_ds[sequence_id] of module/distiller/sequence/module.py:66).  16-byte vectors when d, ldx, ldo are multiples of 4 and the
  * pointers 16-byte aligned, one dword per lane otherwise. */

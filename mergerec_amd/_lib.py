@@ -97,6 +97,7 @@ SIGNATURES = {
     "mr_attn_global_row_bwd_train_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_u32, c_p, c_p, c_p]),
     "mr_attn_global_row_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "mr_cls_pool_normalize_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "mr_mean_pool_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "mr_gather_rows_f32": (c_i, [c_p, c_i64, c_p, c_i, c_i, c_p, c_i64, c_p]),
     "mr_topk_rows_f32": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
     "mr_topk_max_k": (c_i, []),

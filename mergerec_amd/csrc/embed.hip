@@ -227,6 +227,57 @@ __global__ __launch_bounds__(kThreads) void cls_pool_kernel(const float* __restr
     }
 }
 
+// pooling_method = "mean" (encoder/_base.py:42-43: ``last_hidden_state.mean(dim=1)`` over the PADDED batch length, pad positions included):
+// out[b] = (sum of sequence b's token rows + (pad_len[b] - len_b) * xpad[b]) / pad_len[b], optionally L2-normalised.  xpad[b] is the hidden
+// state every pad position of sequence b has (one query row per sequence carried through the layers, engine.forward_packed); one wave per
+// sequence, tokens summed in ascending order.
+template <int NV>
+__global__ __launch_bounds__(kThreads) void mean_pool_kernel(const float* __restrict__ xin, int64_t ldx, const int32_t* __restrict__ cu,
+                                                            const float* __restrict__ xpad, const int32_t* __restrict__ pad_len, int B, int d,
+                                                            int normalize, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int t0 = cu[b], t1 = cu[b + 1];
+    float4 x[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = t0; t < t1; ++t) {
+        const float* r = xin + (int64_t)t * ldx;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (j * MR_WAVE + lane) * 4;
+            if (c < d) x[j] = add4(x[j], ld4(r + c));
+        }
+    }
+    const int width = pad_len[b] > t1 - t0 ? pad_len[b] : t1 - t0;  // never narrower than the sequence itself
+    const float npad = (float)(width - (t1 - t0)), inv_w = 1.0f / (float)(width > 0 ? width : 1);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * MR_WAVE + lane) * 4;
+        if (c < d) {
+            if (npad > 0.f) {
+                const float4 p = ld4(xpad + (int64_t)b * d + c);
+                x[j].x += npad * p.x; x[j].y += npad * p.y; x[j].z += npad * p.z; x[j].w += npad * p.w;
+            }
+            x[j].x *= inv_w; x[j].y *= inv_w; x[j].z *= inv_w; x[j].w *= inv_w;
+            s += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+        }
+    }
+    float inv = 1.0f;
+    if (normalize) inv = 1.0f / fmaxf(sqrtf(mr::wave_sum(s)), 1e-12f);  // F.normalize eps
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (j * MR_WAVE + lane) * 4;
+        if (c < d) {
+            float4 o = x[j];
+            if (normalize) { o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv; }
+            *reinterpret_cast<float4*>(out + (int64_t)b * d + c) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __restrict__ xin, int64_t ldx,
                                                               const int32_t* __restrict__ idx, int n, int d,
                                                               float* __restrict__ out, int64_t ldo) {
@@ -332,6 +383,18 @@ extern "C" int mr_cls_pool_normalize_f32(const float* x, int64_t ldx, const int3
     const unsigned blocks = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
     MR_DISPATCH_NV(d, hipLaunchKernelGGL((cls_pool_kernel<NV>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x,
                                          ldx, cu_seqlens, B, d, normalize, out));
+    return mr::check_launch();
+}
+
+extern "C" int mr_mean_pool_f32(const float* x, int64_t ldx, const int32_t* cu_seqlens, const float* xpad, const int32_t* pad_len, int B, int d,
+                                int normalize, float* out, mr_stream_t stream) {
+    if (!x || !cu_seqlens || !xpad || !pad_len || !out || B < 0 || d <= 0) return MR_EINVAL;
+    if ((d & 3) || d > 2048) return MR_EUNSUPPORTED;
+    if ((ldx & 3) || !mr::aligned16(x) || !mr::aligned16(xpad) || !mr::aligned16(out)) return MR_EALIGN;
+    if (B == 0) return MR_OK;
+    const unsigned blocks = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
+    MR_DISPATCH_NV(d, hipLaunchKernelGGL((mean_pool_kernel<NV>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, cu_seqlens, xpad,
+                                         pad_len, B, d, normalize, out));
     return mr::check_launch();
 }
 

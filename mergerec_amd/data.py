@@ -75,6 +75,18 @@ class TokenizedDomain:
         torch.save({"items": self.items, "sequences": self.sequences, "labels": self.labels}, path)
 
 
+def _keep_pad_len(out, encs, L: int):
+    """merged encodings whose rows came in batches of different widths carry each row's own padded width (``Encoding.host_pad_len``):
+    pooling_method="mean" averages over the padded width of the batch a sequence came in, as upstream does"""
+    if any(e["input_ids"].shape[1] != L for e in encs) or any(getattr(e, "host_pad_len", None) is not None for e in encs):
+        from .model_batch import Encoding
+
+        out = Encoding(out)
+        out.host_pad_len = torch.cat([torch.as_tensor(getattr(e, "host_pad_len", None)).to(torch.int64) if getattr(e, "host_pad_len", None) is not None
+                                      else torch.full((e["input_ids"].shape[0],), e["input_ids"].shape[1], dtype=torch.int64) for e in encs])
+    return out
+
+
 def _stack(batches, key_of) -> Dict[str, torch.Tensor]:
     encs = [key_of(b) for b in batches]
     L = max(e["input_ids"].shape[1] for e in encs)
@@ -88,7 +100,7 @@ def _stack(batches, key_of) -> Dict[str, torch.Tensor]:
                 t = torch.nn.functional.pad(t, (0, L - t.shape[1]), value=pads.get(k, 0))
             rows.append(t)
         out[k] = torch.cat(rows)
-    return out
+    return _keep_pad_len(out, encs, L)
 
 
 def load_domain(spec: str, kind: str = "roberta", vocab: int = 50265, seed: int = 1234) -> TokenizedDomain:
@@ -126,7 +138,7 @@ def _cat_encodings(encs, pad_id: int = 1):
                 t = torch.nn.functional.pad(t, (0, L - t.shape[1]), value=pad_id if k == "input_ids" else _PAD_VALUES.get(k, 0))
             rows.append(t)
         out[k] = torch.cat(rows)
-    return out
+    return _keep_pad_len(out, encs, L)
 
 
 def coalesce_batches(batches, max_tokens: int = 65536, pad_id: int = 1):

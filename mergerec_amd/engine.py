@@ -275,6 +275,7 @@ class PackedBatch:
     sum_len_sq: float = 0.0  # sum_b L_b^2 (algorithmic attention work, for the profiler)
     seq_order: Optional[torch.Tensor] = None  # int32 (B): sequence ids by decreasing length (attention scheduling hint)
     attn_work: Optional[Dict[int, Tuple[torch.Tensor, int]]] = None  # q_rows -> (device int32 work list, n_slots): ops.attn_work_plan
+    pad_len: Optional[torch.Tensor] = None  # int32 (B) device: padded width of each row's source batch (pooling_method="mean" only)
 
 
 def _lens_from_mask(attention_mask: torch.Tensor) -> torch.Tensor:
@@ -378,7 +379,14 @@ class EncoderRunner:
             both = ops.h2d(torch.cat([p[0] for p in plans]), device)
             n128 = plans[0][0].numel()
             attn_work = {128: (both[:n128], plans[0][1]), 256: (both[n128:], plans[1][1])}
-        return PackedBatch(B=B, T=T, max_len=int(lens.max()) if B else 0, cu_seqlens=cu_d, cls_rows=cu_d[:-1].contiguous(), attn_work=attn_work,
+        pad_len = None
+        if getattr(self, "pooling_method", "cls") == "mean":
+            hp = getattr(batch, "host_pad_len", None)
+            hp = torch.full((B,), L, dtype=torch.int64) if hp is None else torch.as_tensor(hp).to(torch.int64).cpu()
+            if hp.numel() != B or (B and bool((hp < lens).any())):
+                raise ValueError("host_pad_len must hold one padded width per row, none shorter than its row's length")
+            pad_len = ops.h2d(hp.to(torch.int32), device)
+        return PackedBatch(B=B, T=T, max_len=int(lens.max()) if B else 0, cu_seqlens=cu_d, cls_rows=cu_d[:-1].contiguous(), attn_work=attn_work, pad_len=pad_len,
                            tok_word=tw, tok_pos=tp, tok_tt=ttp, tok_ip=tip, sum_len_sq=float((lens.double() ** 2).sum()) if B else 0.0,
                            seq_order=ops.h2d(torch.argsort(lens, descending=True, stable=True).to(torch.int32), device) if B > 1 else None)
 
@@ -457,6 +465,43 @@ class EncoderRunner:
         chain()
         return ops.layernorm(o, w[lp + "output.LayerNorm.weight"], w[lp + "output.LayerNorm.bias"], sp.ln_eps, out=o)
 
+    def _pad_row_layer(self, w, l: int, x_pad: torch.Tensor, kv: torch.Tensor, pb: PackedBatch) -> torch.Tensor:
+        """One block for the pad positions' hidden state (pooling_method="mean"): every pad position of sequence b holds the same vector
+        -- the pad token's embedding, attending to the sequence's valid keys, never a key itself -- so ONE query row per sequence, against
+        the layer's keys / values ``kv`` (T, 2 d) of the real tokens, reproduces what upstream computes at all of them."""
+        sp, lp = self.spec, f"{self.prefix}encoder.layer.{l}."
+        q = self._proj(w, lp, ("query",), x_pad)
+        ctx = torch.empty(pb.B, sp.hidden, dtype=torch.float32, device=x_pad.device)
+        ops.attention_global_row(q, kv, pb.cu_seqlens, pb.B, sp.heads, pb.max_len, ctx, compact=True)
+        h = self._linear(w, ctx, [lp + "attention.output.dense.weight"], [lp + "attention.output.dense.bias"], residual=x_pad)
+        h = ops.layernorm(h, w[lp + "attention.output.LayerNorm.weight"], w[lp + "attention.output.LayerNorm.bias"], sp.ln_eps, out=h)
+        i = self._linear(w, h, [lp + "intermediate.dense.weight"], [lp + "intermediate.dense.bias"], act=ops.ACT_GELU)
+        o = self._linear(w, i, [lp + "output.dense.weight"], [lp + "output.dense.bias"], residual=h)
+        return ops.layernorm(o, w[lp + "output.LayerNorm.weight"], w[lp + "output.LayerNorm.bias"], sp.ln_eps, out=o)
+
+    def _forward_mean(self, w, pb: PackedBatch, normalize: bool) -> torch.Tensor:
+        """pooling_method="mean" (encoder/_base.py:42-43): every layer on all tokens plus the pad row of each sequence; then
+        (sum of the sequence's rows + (padded width - length) x pad row) / padded width."""
+        sp = self.spec
+        if sp.kind != "roberta":
+            raise NotImplementedError("pooling_method='mean' is built for the RoBERTa-family encoders (Longformer pads to window multiples first)")
+        if pb.pad_len is None:
+            raise RuntimeError("pooling_method='mean' needs the padded widths (EncoderRunner.pack with pooling_method == 'mean')")
+        dev = pb.cu_seqlens.device
+        x = self.embed(w, pb)
+        pad_ids = torch.full((pb.B,), sp.pad_id, dtype=torch.int32, device=dev)  # RobertaEmbeddings: pad tokens sit at position padding_idx
+        e = self.prefix + "embeddings."
+        x_pad = ops.embed_gather_ln(pad_ids, pad_ids, None, None, w[e + "word_embeddings.weight"], w[e + "position_embeddings.weight"],
+                                    w[e + "token_type_embeddings.weight"], None, w[e + "LayerNorm.weight"], w[e + "LayerNorm.bias"], sp.ln_eps,
+                                    ops.EMBED_ROBERTA)
+        d = sp.hidden
+        for l in range(sp.layers):
+            lp = f"{self.prefix}encoder.layer.{l}."
+            kv = self._proj(w, lp, ("key", "value"), x)  # the real tokens' keys / values of this layer, as the pad rows see them
+            x_pad = self._pad_row_layer(w, l, x_pad, kv, pb)
+            x = self.layer(w, l, x, pb, cls_only=False)
+        return ops.mean_pool(x, pb.cu_seqlens, x_pad, pb.pad_len, pb.B, normalize)
+
     def forward_packed(self, w, pb: PackedBatch, normalize: bool, return_hidden: bool = False):
         """-> (B, d) CLS embeddings (L2-normalised if ``normalize``); optionally every layer's packed hidden.
         ``w`` is a WeightSet (or a plain name -> tensor mapping, packed on the fly)."""
@@ -465,6 +510,8 @@ class EncoderRunner:
         if pb.B == 0:
             empty = torch.empty(0, d, dtype=torch.float32, device=pb.cu_seqlens.device)
             return (empty, []) if return_hidden else empty
+        if getattr(self, "pooling_method", "cls") == "mean" and not return_hidden:
+            return self._forward_mean(w, pb, normalize)
         x = self.embed(w, pb)
         hidden = [x] if return_hidden else None
         L = self.spec.layers

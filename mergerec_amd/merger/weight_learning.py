@@ -261,6 +261,8 @@ class TaskVectorMergingModuleBase(nn.Module):
     def forward_with_grad(self, batch):
         from ..engine_train import RobertaTrainGraph, SplitWeights, encode_with_grad
 
+        if getattr(self.model, "pooling_method", "cls") != "cls":
+            raise NotImplementedError(f"the training graph pools the CLS row; pooling_method={self.model.pooling_method!r} is an inference option here")
         if self.slice_plan is not None:
             raise RuntimeError("alpha learning needs every task vector on every rank (d loss / d alpha contracts the full gradient with "
                                "each of them): build the module with placement='replicated' (merge_train.py does)")

@@ -14,6 +14,8 @@ class Encoding(dict):
     carrying them along saves the device -> host round trip per batch that re-deriving them from the moved mask would cost."""
 
     host_lens = None
+    host_pad_len = None  # per-row padded width of the batch each row came in (set when batches of different widths are coalesced): what
+    # pooling_method="mean" divides by -- upstream averages over its own batch's padded length
 
 
 def _relocate(value, device):
@@ -26,6 +28,7 @@ def _relocate(value, device):
         if isinstance(mask, torch.Tensor) and not mask.is_cuda and mask.dim() == 2:
             lens = mask.ne(0).sum(dim=1)
         moved.host_lens = lens
+        moved.host_pad_len = getattr(value, "host_pad_len", None)
         return moved
     if isinstance(value, (list, tuple)):
         return type(value)(_relocate(v, device) for v in value)

@@ -42,13 +42,12 @@ class BaseEncoderModel(nn.Module):
         model_kwargs = dict(model_kwargs or {})
         if lora_config is not None:
             raise ValueError("LoRA wrappers are outside the merged-inference hot path (SURVEY section 2, row 4)")
-        if pooling_method == "mean":
-            # upstream: last_hidden_state.mean(dim=1) over the PADDED batch length -- the hidden states of pad positions included, so an
-            # embedding depends on what else is in its batch; no shipped script selects it (configs/base.py:26 default "cls")
-            raise NotImplementedError("pooling_method='mean' (mean over the padded batch length, pad positions included) is not built; "
-                                      "'cls' (default) and 'pooler' are")
-        if pooling_method not in ("cls", "pooler"):
+        if pooling_method not in ("cls", "pooler", "mean"):
             raise ValueError(f"Invalid pooling method: {pooling_method}.")  # encoder/_base.py:48-49
+        if pooling_method == "mean" and self.SPEC().kind != "roberta":
+            # upstream: last_hidden_state.mean(dim=1) over the PADDED batch length, pad positions included; built for the RoBERTa family
+            # (engine._forward_mean); Longformer first pads to a multiple of its window, which this packed encoder never materialises
+            raise NotImplementedError("pooling_method='mean' is built for the BLaIR / RoBERTa encoders; Recformer offers 'cls' (default)")
         if model_name_or_path is None and tokenizer_name_or_path is None:
             model_name_or_path = tokenizer_name_or_path = self.DEFAULT_MODEL_PATH
         self.model_name_or_path = model_name_or_path
@@ -211,6 +210,8 @@ class BaseEncoderModel(nn.Module):
         """(B, d) CLS rows through the training graph (engine_train.EncoderTrainGraph), differentiable w.r.t. ``train_leaf()``."""
         from ..engine_train import EncoderTrainGraph, SplitWeights, encode_with_grad
 
+        if self.pooling_method != "cls":
+            raise NotImplementedError(f"the training graph pools the CLS row; pooling_method={self.pooling_method!r} is an inference option here")
         layout, sw = self._weights.layout, None
         if self.train_mode == "bf16x3":
             sw = getattr(self, "_split_weights", None)

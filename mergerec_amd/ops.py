@@ -527,6 +527,18 @@ def cls_pool_normalize(x: torch.Tensor, cu_seqlens: torch.Tensor, B: int, normal
     return out
 
 
+def mean_pool(x: torch.Tensor, cu_seqlens: torch.Tensor, xpad: torch.Tensor, pad_len: torch.Tensor, B: int, normalize: bool) -> torch.Tensor:
+    """(B, d) mean over each sequence's PADDED width: packed token rows of ``x`` plus (pad_len[b] - len_b) copies of ``xpad[b]`` (the pad
+    positions' shared hidden state), divided by pad_len[b]; L2-normalised if asked."""
+    _dev(xpad, "xpad", torch.float32), _dev(pad_len, "pad_len", torch.int32), _dev(cu_seqlens, "cu_seqlens", torch.int32)
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1) or xpad.shape != (B, x.shape[1]) or pad_len.numel() != B:
+        raise ValueError("x (T, d) fp32 GPU rows, xpad (B, d), pad_len (B,)")
+    out = torch.empty(B, x.shape[1], dtype=torch.float32, device=x.device)
+    check(_lib.load().mr_mean_pool_f32(ptr(x), x.stride(0), ptr(cu_seqlens), ptr(xpad), ptr(pad_len), B, x.shape[1], int(normalize), ptr(out),
+                                       _stream(x)), "mr_mean_pool_f32")
+    return out
+
+
 def gather_rows(x: torch.Tensor, row_idx: torch.Tensor, out=None) -> torch.Tensor:
     n, d = row_idx.numel(), x.shape[1]
     out = torch.empty(n, d, dtype=torch.float32, device=x.device) if out is None else out

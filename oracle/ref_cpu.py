@@ -373,9 +373,10 @@ def roberta_layer(p: StateDict, lp: str, x: torch.Tensor, attention_mask: torch.
 
 def roberta_encode(
     p: StateDict, input_ids: torch.Tensor, attention_mask: torch.Tensor, cfg: EncoderConfig, prefix: str = "",
-    return_hidden: bool = False, dropout: Optional[DropoutPlan] = None,
+    return_hidden: bool = False, dropout: Optional[DropoutPlan] = None, pooling: str = "cls",
 ):
-    """encoder/_base.py:32-49 -- ``self.model(**batch)`` then CLS pooling ``last_hidden_state[:, 0]``.  ``dropout``: the train()-mode
+    """encoder/_base.py:32-49 -- ``self.model(**batch)`` then ``pool``: CLS ``last_hidden_state[:, 0]`` (:44-45) or "mean"
+    ``last_hidden_state.mean(dim=1)`` over the padded length, pad positions included (:42-43).  ``dropout``: the train()-mode
     forward (mask = the build's counter-based function, see DropoutPlan)."""
     x = roberta_embeddings(p, input_ids, cfg, prefix)
     drop = dropout.bind(attention_mask) if dropout is not None else None
@@ -385,7 +386,9 @@ def roberta_encode(
     for l in range(cfg.layers):
         x = roberta_layer(p, f"{prefix}encoder.layer.{l}.", x, attention_mask, cfg, drop, l)
         hidden.append(x)
-    cls = x[:, 0, :]
+    if pooling not in ("cls", "mean"):
+        raise ValueError(f"Invalid pooling method: {pooling}.")
+    cls = x[:, 0, :] if pooling == "cls" else x.mean(dim=1)
     return (cls, hidden) if return_hidden else cls
 
 

@@ -295,3 +295,24 @@ def test_recformer_parameter_gradients_match_reference():
                 continue
             err = float((p[k].grad - g).abs().max())
             assert err <= 5e-4 * max(float(g.abs().max()), 1e-3 * gmax), (k, err, float(g.abs().max()))
+
+
+def test_oracle_mean_pooling_matches_transformers_padded_mean():
+    """encoder/_base.py:42-43: pooling "mean" = last_hidden_state.mean(dim=1) over the padded length; g3 stores the padded hidden states
+    transformers produced (pad positions included).  Also the fact the HIP path builds on: every pad position of a sequence holds the same
+    vector (one extra query row per sequence reproduces them)."""
+    import torch
+    from oracle import ref_cpu as O
+    from tests.conftest import load_golden
+
+    g3 = load_golden("g3_roberta.pt")
+    cfgd = g3["cfg"]
+    cfg = O.EncoderConfig(**{k: cfgd[k] for k in cfgd if k in O.EncoderConfig.__dataclass_fields__})
+    got = O.roberta_encode(g3["state_dict"], g3["input_ids"], g3["attention_mask"], cfg, prefix="model.", pooling="mean")
+    want = g3["hidden_states"][-1].mean(dim=1)
+    assert float((got - want).abs().max()) <= 1e-5
+    h, lens = g3["hidden_states"][-1], g3["attention_mask"].sum(1)
+    for b in range(h.shape[0]):
+        n = int(lens[b])
+        if n < h.shape[1]:
+            assert float((h[b, n:] - h[b, n]).abs().max()) == 0.0
