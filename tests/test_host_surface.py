@@ -76,3 +76,49 @@ def test_alpha_file_round_trip_and_best_alpha(tmp_path):
     trainer.callback_metrics = {"train/loss": torch.tensor(1.0)}
     with pytest.raises(RuntimeError):
         ck.on_validation_epoch_end(trainer, module)
+
+
+def test_coalesced_batches_keep_each_rows_own_padded_width():
+    """pooling_method="mean" averages over the padded width of the batch a sequence came in (encoder/_base.py:42-43 on upstream's own
+    batches): when the evaluation loop merges batches of different widths into one kernel pass, every row keeps its width
+    (Encoding.host_pad_len), through a second merge and through .to(device)"""
+    import torch
+
+    from mergerec_amd.data import coalesce_batches
+    from mergerec_amd.model_batch import BatchItem, BatchSequence
+
+    def enc(rows, width, fill):
+        ids = torch.full((rows, width), 1, dtype=torch.int64)
+        mask = torch.zeros(rows, width, dtype=torch.int64)
+        ids[:, :fill], mask[:, :fill] = 5, 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+    merged = list(coalesce_batches([BatchItem(items=enc(2, 9, 4)), BatchItem(items=enc(3, 23, 20)), BatchItem(items=enc(1, 5, 5))], max_tokens=10 ** 6))
+    assert len(merged) == 1 and merged[0].items["input_ids"].shape == (6, 23)
+    assert merged[0].items.host_pad_len.tolist() == [9, 9, 23, 23, 23, 5]
+    moved = merged[0].to("cpu")
+    assert moved.items.host_pad_len.tolist() == [9, 9, 23, 23, 23, 5] and moved.items.host_lens.tolist() == [4, 4, 20, 20, 20, 5]
+    # equal widths: nothing to carry (the packer then uses the tensor's own width)
+    same = list(coalesce_batches([BatchItem(items=enc(2, 9, 4)), BatchItem(items=enc(3, 9, 9))], max_tokens=10 ** 6))
+    assert getattr(same[0].items, "host_pad_len", None) is None
+    # sequences with labels go the same way; an already merged batch merged again keeps its rows' widths
+    seqs = list(coalesce_batches([BatchSequence(sequence=merged[0].items, labels=torch.zeros(6, dtype=torch.int64)),
+                                  BatchSequence(sequence=enc(2, 30, 30), labels=torch.ones(2, dtype=torch.int64))], max_tokens=10 ** 6))
+    assert seqs[0].sequence.host_pad_len.tolist() == [9, 9, 23, 23, 23, 5, 30, 30] and seqs[0].labels.tolist() == [0] * 6 + [1, 1]
+
+
+def test_distillation_log_keeps_tensors_until_read():
+    """DistillSequenceModule.log stores the loss TENSOR (a float() there is a device -> host wait inside every training step); readers of
+    ``logged`` get floats"""
+    import torch
+
+    from mergerec_amd.module.distiller import _LazyLog
+
+    log = _LazyLog()
+    t = torch.tensor(2.5)
+    log["train/loss"] = t
+    log["lr"] = 1e-3
+    assert dict.__getitem__(log, "train/loss") is t            # kept as given
+    assert log["train/loss"] == 2.5 and isinstance(log["train/loss"], float)
+    assert log.get("missing") is None and log.get("lr") == 1e-3
+    assert sorted(log.items()) == [("lr", 1e-3), ("train/loss", 2.5)] and sorted(log.values()) == [1e-3, 2.5]
